@@ -1,0 +1,209 @@
+/*
+ * penguin_hip.h -- C ABI of libpenguin_hip.so: the MI355X (gfx950) implementation of
+ * Penguin.jl's hot path  Mesh -> Capacity -> DiffusionOps -> DiffusionUnsteadyMono/Diph ->
+ * solve_DiffusionUnsteady*!.
+ *
+ * The reference (100 % Julia) has no FFI for this path; its boundary is the exported Julia API
+ * (src/Penguin.jl:25-75).  Each entry point below names the reference item it replaces
+ * (paths relative to the reference tree).  julia/PenguinHIP.jl ccall's exactly these symbols;
+ * penguin/jl_amd/_lib.py binds the same symbols with ctypes.  See INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns int32 status, 0 = ok; on failure pg_last_error() holds a
+ *     thread-local message (the Julia wrapper turns it into error(msg)).
+ *   - handles are opaque and owned by the library; every array argument is a HOST pointer
+ *     owned by the caller and borrowed for the duration of the call only.
+ *   - all fields live on the padded node grid  M = prod(n_d + 1), linear index
+ *     i + j*(nx+1) + k*(nx+1)*(ny+1) (0-based here; src/solver.jl:362-372, src/utils.jl:21).
+ *   - float64 / int64 across the ABI (SparseMatrixCSC{Float64,Int}).  No torch types.
+ *   - one process drives one GPU; with nranks > 1 every rank owns a slab of planes of the
+ *     slowest dimension and the library exchanges halos / dot products over RCCL itself.
+ *   - handles are not thread-safe; one call at a time per handle.
+ */
+#ifndef PENGUIN_HIP_H
+#define PENGUIN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pg_mesh pg_mesh;         /* Penguin.Mesh{N}            src/mesh.jl:41-79        */
+typedef struct pg_capacity pg_capacity; /* Penguin.Capacity{N}        src/capacity.jl:25-36    */
+typedef struct pg_diffops pg_diffops;   /* Penguin.DiffusionOps{N}    src/operators.jl:49-55   */
+typedef struct pg_solver pg_solver;     /* Penguin.Solver             src/solver.jl:33-42      */
+
+/* ---- enums --------------------------------------------------------------------------- */
+enum { PG_BODY_BALL = 1, PG_BODY_MULTIBALL = 2 }; /* closed-form level sets evaluated in-kernel */
+enum { PG_FLAG_COMPLEMENT = 1, PG_FLAG_NO_CENTROIDS = 2 };
+/* capacity fields for pg_capacity_get (d = dimension for A,B,W,C_omega,C_gamma) */
+enum { PG_CAP_V = 0, PG_CAP_GAMMA = 1, PG_CAP_CELL_TYPES = 2, PG_CAP_A = 3, PG_CAP_B = 4,
+       PG_CAP_W = 5, PG_CAP_C_OMEGA = 6, PG_CAP_C_GAMMA = 7 };
+enum { PG_OP_G = 0, PG_OP_H = 1, PG_OP_WINV = 2 };
+/* interface / border condition kinds                         src/boundary.jl:12-50 */
+enum { PG_BC_NONE = 0, PG_BC_DIRICHLET = 1, PG_BC_NEUMANN = 2, PG_BC_ROBIN = 3, PG_BC_PERIODIC = 4 };
+/* border keys, in the reference's (unusual) naming           src/solver.jl:379-409 */
+enum { PG_KEY_LEFT = 0 /* dim2 = 1 */, PG_KEY_RIGHT = 1 /* dim2 = n2 */, PG_KEY_BOTTOM = 2 /* dim1 = 1 */,
+       PG_KEY_TOP = 3 /* dim1 = n1 */, PG_KEY_BACKWARD = 4 /* dim3 = 1 */, PG_KEY_FORWARD = 5 /* dim3 = n3 */ };
+enum { PG_SCHEME_BE = 0, PG_SCHEME_CN = 1 };                 /* "BE" / "CN" strings of the reference */
+enum { PG_METHOD_BICGSTAB = 0, PG_METHOD_CG = 1 };           /* IterativeSolvers methods kept     */
+
+/* ---- plain structs ------------------------------------------------------------------- */
+typedef struct {
+  int32_t kind;   /* PG_BC_DIRICHLET / NEUMANN / ROBIN   (build_I_bc, src/solver.jl:203-223) */
+  double alpha;   /* Robin only */
+  double beta;    /* Robin only */
+  double value;   /* constant value, used when value_array == NULL */
+  const double* value_array; /* M host values g(C_gamma, t) or NULL (build_g_g, src/solver.jl:293-323) */
+} pg_bc_desc;
+
+typedef struct {
+  int32_t key;    /* PG_KEY_*  */
+  int32_t kind;   /* PG_BC_DIRICHLET / PERIODIC / NEUMANN(1-D only)  (src/solver.jl:450-499) */
+  double value;   /* constant; per-cell values may be set later with pg_solver_set_border_values */
+} pg_border_desc;
+
+typedef struct {
+  double alpha1, alpha2, g;  /* ScalarJump  src/boundary.jl:96-100 ; row 2 of the 4-block system */
+  double beta1, beta2, h;    /* FluxJump    src/boundary.jl:111-115; row 4 */
+  const double* g_array;     /* M values or NULL */
+  const double* h_array;     /* M values or NULL */
+} pg_jump_desc;
+
+typedef struct {
+  int32_t method;   /* PG_METHOD_*                                  */
+  double reltol;    /* ||r|| <= max(reltol*||b||, abstol)            */
+  double abstol;
+  int32_t maxiter;  /* <= 0: size of the reduced system              */
+  int32_t check_every; /* host convergence poll period in iterations (<=0: default 4) */
+} pg_krylov_opts;
+
+typedef struct {
+  int32_t iters;      /* Krylov iterations of this step                        */
+  int32_t converged;
+  double resnorm;     /* final ||r||                                           */
+  double bnorm;
+  double extremum;    /* maximum(abs.(s.x)) -- the "Solver Extremum" line, src/solver/diffusion.jl:279 */
+  double time;        /* t after the step (fp64 accumulation t += dt, :287)     */
+} pg_step_info;
+
+typedef struct {
+  int64_t steps;            /* number of loop iterations executed (states = steps + 1)         */
+  int64_t total_iters;
+  double t_final;
+  double extremum;
+  double solve_ms;          /* wall time of the whole run on this rank                          */
+  /* profiling (pg_set_profiling(1)): HIP-event time of every SpMV launch in the run           */
+  double spmv_ms_total;
+  int64_t spmv_launches;
+} pg_run_info;
+
+typedef struct {
+  int64_t n_own;      /* rows of the reduced system owned by this rank (n of BASELINE.md)       */
+  int64_t nnz;        /* stored entries of those rows                                           */
+  int64_t n_ghost;    /* ghost unknowns received from neighbours per SpMV                       */
+  int64_t n_omega;    /* owned active bulk unknowns                                             */
+  int64_t n_gamma;    /* owned active interface unknowns                                        */
+  int64_t M_global;   /* prod(n_d+1)                                                            */
+} pg_system_info;
+
+/* ---- library / device -------------------------------------------------------------------- */
+int32_t pg_last_error(char* buf, size_t n);
+/* single-GPU: pg_init(device).  multi-GPU: rank 0 calls pg_get_unique_id, the launcher broadcasts
+   the 128 bytes (torch.distributed in bench.py), every rank calls pg_init_distributed. */
+int32_t pg_init(int32_t device_id);
+int32_t pg_get_unique_id(void* out128);
+int32_t pg_init_distributed(int32_t device_id, int32_t rank, int32_t nranks, const void* unique_id128);
+int32_t pg_finalize(void);
+int32_t pg_device_synchronize(void);
+int32_t pg_set_profiling(int32_t on);
+int32_t pg_device_name(char* buf, size_t n);
+
+/* ---- Mesh                                       replaces Mesh(n, L, x0), src/mesh.jl:47-78 ---- */
+int32_t pg_mesh_create(int32_t N, const int64_t* n, const double* L, const double* x0, pg_mesh** out);
+int32_t pg_mesh_destroy(pg_mesh* m);
+int32_t pg_mesh_get_centers(const pg_mesh* m, int32_t d, double* out, int64_t len);   /* len = n_d     */
+int32_t pg_mesh_get_nodes(const pg_mesh* m, int32_t d, double* out, int64_t len);     /* len = n_d + 1 */
+int32_t pg_mesh_num_border_cells(const pg_mesh* m, int64_t* out);
+/* idx: nb*N 1-based Cartesian indices, pos: nb*N centre coordinates, key: nb PG_KEY_*, in the
+   reference's order (src/mesh.jl:57-74 + unique!) */
+int32_t pg_mesh_get_border_cells(const pg_mesh* m, int64_t* idx, double* pos, int32_t* key);
+
+/* ---- Capacity                      replaces Capacity(body, mesh; method="VOFI"), capacity.jl:51-123 */
+/* BALL: params = {c_1..c_N, r}.  MULTIBALL: params = {r, nballs, c^1_1..c^1_N, c^2_1, ...}. */
+int32_t pg_capacity_create_levelset(pg_mesh* m, int32_t body_kind, const double* params, int32_t nparams,
+                                    int32_t flags, pg_capacity** out);
+/* fallback for arbitrary Julia bodies: arrays computed by the caller (single rank only).
+   A,B,W,C_omega,C_gamma: N pointers each to M doubles; C_gamma may be NULL. */
+int32_t pg_capacity_create_from_arrays(pg_mesh* m, const double* V, const double* const* A,
+                                       const double* const* B, const double* const* W, const double* Gamma,
+                                       const double* const* C_omega, const double* const* C_gamma,
+                                       const double* cell_types, pg_capacity** out);
+int32_t pg_capacity_destroy(pg_capacity* c);
+/* out: M doubles (global padded layout; with nranks>1 only the planes this rank stores are filled,
+   the rest are left untouched) */
+int32_t pg_capacity_get(const pg_capacity* c, int32_t field, int32_t d, double* out, int64_t len);
+int32_t pg_capacity_kernel_ms(const pg_capacity* c, double* ms); /* device time of K1-K5 for the bench */
+
+/* ---- DiffusionOps                         replaces DiffusionOps(capacity), operators.jl:127-178 */
+int32_t pg_diffops_create(pg_capacity* c, pg_diffops** out);
+int32_t pg_diffops_destroy(pg_diffops* o);
+/* two-call pattern: nzval == NULL -> only *nnz is written.  CSC of G, H (N*M x M) or Winv (N*M x N*M),
+   0-based colptr (ncols+1) / rowval, single rank only. */
+int32_t pg_diffops_export_csc(const pg_diffops* o, int32_t which, int64_t* colptr, int64_t* rowval,
+                              double* nzval, int64_t* nnz);
+int32_t pg_diffops_grad(const pg_diffops* o, const double* p /*2M*/, double* out /*N*M*/);      /* ∇  :20-23 */
+int32_t pg_diffops_div(const pg_diffops* o, const double* qw /*N*M*/, const double* qg /*N*M*/,
+                       double* out /*M*/);                                                     /* ∇₋ :30-34 */
+
+/* ---- Solver          replaces DiffusionUnsteadyMono(phase, bc_b, bc_i, Δt, Tᵢ, scheme), diffusion.jl:192-210
+   Dcoef: M values D(C_omega) or NULL (=1).  source: M values f(C_omega, Δt) for the first step or NULL (=0).
+   T0: 2M.  Builds A (scheme), b(t=0) and applies the border rows with t = 0 exactly as the ctor does. */
+int32_t pg_solver_create_unsteady_mono(pg_capacity* c, pg_diffops* o, const pg_bc_desc* bc_interface,
+                                       const pg_border_desc* borders, int32_t nborders, const double* Dcoef,
+                                       const double* source, double dt, const double* T0, int32_t scheme,
+                                       pg_solver** out);
+/* DiffusionUnsteadyDiph(phase1, phase2, bc_b, ic, Δt, Tᵢ, scheme), diffusion.jl:319-332.  T0: 4M. */
+int32_t pg_solver_create_unsteady_diph(pg_capacity* c1, pg_diffops* o1, pg_capacity* c2, pg_diffops* o2,
+                                       const pg_jump_desc* ic, const pg_border_desc* borders, int32_t nborders,
+                                       const double* D1, const double* D2, const double* f1, const double* f2,
+                                       double dt, const double* T0, int32_t scheme, pg_solver** out);
+int32_t pg_solver_destroy(pg_solver* s);
+
+/* per-step data for time-dependent closures; the host evaluates them at the reference's points and
+   times (C_omega / C_gamma / mesh.centers; t+Δt -- diffusion.jl:248-249) and passes arrays.
+   f_n, g_n (values at t) are only read by the CN scheme; NULL keeps the previous / constant data. */
+int32_t pg_solver_set_source(pg_solver* s, int32_t phase, const double* f_n /*M*/, const double* f_np1 /*M*/);
+int32_t pg_solver_set_interface_value(pg_solver* s, const double* g_n /*M*/, const double* g_np1 /*M*/);
+int32_t pg_solver_set_border_values(pg_solver* s, const double* values /*nb, mesh border order*/);
+
+/* first solve of solve_DiffusionUnsteadyMono! (diffusion.jl:275): uses the ctor's A, b. */
+int32_t pg_solver_initial_solve(pg_solver* s, const pg_krylov_opts* opts, pg_step_info* info);
+/* one loop iteration (diffusion.jl:286-300): t += Δt; b; border rows; solve. scheme = run scheme. */
+int32_t pg_solver_step(pg_solver* s, int32_t scheme, const pg_krylov_opts* opts, pg_step_info* info);
+/* whole loop `while t < Tend` with constant-in-time data; max_steps < 0: unbounded.
+   do_initial != 0 runs the initial solve first.  save_every > 0 keeps every k-th state on the device. */
+int32_t pg_solver_run(pg_solver* s, double Tend, int32_t scheme, const pg_krylov_opts* opts, int32_t do_initial,
+                      int64_t max_steps, int32_t save_every, pg_run_info* info);
+int32_t pg_solver_num_states(const pg_solver* s, int64_t* out);
+/* x: full unknown vector (2M mono / 4M diph) with zeros at eliminated unknowns (solver.jl:186-187).
+   state_index < 0: current s.x.  With nranks>1 only owned entries are written (others untouched). */
+int32_t pg_solver_get_state(const pg_solver* s, int64_t state_index, double* x, int64_t len);
+int32_t pg_solver_system_info(const pg_solver* s, int32_t which /*0 = ctor A, 1 = run A*/, pg_system_info* out);
+/* reduced system of this rank as CSR (rowptr n_own+1, col nnz (local numbering: owned then ghosts), val nnz)
+   plus b (n_own) and the map idx[n_own] -> index in the full 2M/4M vector (the reference's common_idx). */
+int32_t pg_solver_get_system_csr(const pg_solver* s, int32_t which, int64_t* rowptr, int64_t* col, double* val,
+                                 double* b, int64_t* idx);
+/* bench helper: `reps` launches of y = A x on the run matrix, HIP-event timed on the library stream. */
+int32_t pg_solver_time_spmv(pg_solver* s, int32_t which, int32_t reps, double* avg_ms);
+
+/* host-logic helper (no GPU needed): slab partition of `nplanes` planes with per-plane weights
+   (active rows) into nranks contiguous ranges; bounds has nranks+1 entries. */
+int32_t pg_partition_planes(const int64_t* weight, int64_t nplanes, int32_t nranks, int64_t* bounds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PENGUIN_HIP_H */

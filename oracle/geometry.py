@@ -56,11 +56,9 @@ def seg_overlap(rho: float, a: float, b: float) -> Tuple[float, float]:
 
 def _P(rho: float, u: float) -> float:
     """Antiderivative of sqrt(rho^2-u^2)."""
-    s2 = rho * rho - u * u
+    s2 = (rho - u) * (rho + u)
     s = math.sqrt(s2) if s2 > 0.0 else 0.0
-    q = u / rho
-    q = 1.0 if q > 1.0 else (-1.0 if q < -1.0 else q)
-    return 0.5 * (u * s + rho * rho * math.asin(q))
+    return 0.5 * (u * s + rho * rho * math.atan2(u, s))
 
 
 def _Q(rho: float, a: float, b: float) -> Tuple[float, float, float]:
@@ -108,14 +106,12 @@ def disc_arcs(rho: float, a: float, b: float, t0: float, t1: float) -> Tuple[flo
         return 0.0, 0.0, 0.0
     cand = []
     for xv in (a, b):
-        q = xv / rho
-        if -1.0 < q < 1.0:
-            al = math.acos(q)
+        if -rho < xv < rho:
+            al = math.atan2(math.sqrt((rho - xv) * (rho + xv)), xv)  # acos(xv/rho), well conditioned
             cand += [al, -al]
     for yv in (t0, t1):
-        q = yv / rho
-        if -1.0 < q < 1.0:
-            al = math.asin(q)
+        if -rho < yv < rho:
+            al = math.atan2(yv, math.sqrt((rho - yv) * (rho + yv)))  # asin(yv/rho)
             cand += [al, (math.pi - al) if al >= 0 else (-math.pi - al)]
 
     def inside(phi: float) -> bool:

@@ -1,0 +1,13 @@
+"""penguin.jl_amd -- MI355X (gfx950) implementation of Penguin.jl's cut-cell operator assembly and
+unsteady-diffusion time-step hot path behind the reference's Mesh/Capacity/Phase/DiffusionOps/Solver API.
+
+All arithmetic runs in libpenguin_hip.so (hand-written HIP kernels, C ABI in include/penguin_hip.h).
+There is no CPU fallback: importing works without a GPU (so the ABI can be inspected), any compute
+call without the shared library or a HIP device raises PenguinHipError.
+"""
+from ._lib import PenguinHipError, device_name, finalize, get_unique_id, init, init_distributed, lib  # noqa: F401
+from .api import (  # noqa: F401
+    BorderConditions, Capacity, Circle, DiffusionOps, DiffusionUnsteadyDiph, DiffusionUnsteadyMono, Dirichlet,
+    FluxJump, InterfaceConditions, Mesh, MultiSphere, Neumann, Periodic, Phase, Robin, ScalarJump, Solver, Sphere,
+    check_convergence, div, grad, lp_norm, nC, solve_DiffusionUnsteadyDiph_b, solve_DiffusionUnsteadyMono_b,
+)

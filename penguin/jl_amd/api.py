@@ -1,0 +1,871 @@
+"""Host-side mirror of Penguin.jl's API for the hot path
+    Mesh -> Capacity -> DiffusionOps -> Phase -> DiffusionUnsteadyMono/Diph -> solve_*!
+(src/Penguin.jl:25-75).  Same names, argument order and meaning as the reference; every numeric
+operation is done by libpenguin_hip.so on the GPU through the C ABI (include/penguin_hip.h).
+Closures never cross the ABI: they are evaluated here, at the reference's points and times
+(C_ω for f and D, C_γ for interface values, mesh.centers for border values; t+Δt -- src/solver.jl:230-323,
+441-448, src/solver/diffusion.jl:248-249) and passed as arrays.
+
+Julia spellings that are not Python identifiers:  `∇`->grad, `∇₋`->div, `Wꜝ`->Winv (alias `Wꜝ` works
+as an attribute), `solve_DiffusionUnsteadyMono!`->solve_DiffusionUnsteadyMono_b.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import inspect
+import math
+from dataclasses import dataclass
+from typing import Callable, Dict, Optional, Sequence, Union
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import PenguinHipError
+
+Number = Union[int, float]
+
+# =============================================================================== Mesh
+
+
+class MeshTag:
+    """src/mesh.jl:6-8; border_cells is materialised on first access (1.5 M tuples at 512^3)."""
+
+    def __init__(self, mesh: "Mesh"):
+        self._mesh = mesh
+        self._cells = None
+
+    @property
+    def border_cells(self):
+        if self._cells is None:
+            idx, pos, _ = self._mesh._border_arrays()
+            self._cells = [(tuple(int(v) for v in idx[q]), tuple(float(v) for v in pos[q])) for q in range(len(idx))]
+        return self._cells
+
+
+class Mesh:
+    """Mesh(n, domain_size, x0) -- src/mesh.jl:47-78."""
+
+    def __init__(self, n: Sequence[int], domain_size: Sequence[float], x0: Optional[Sequence[float]] = None):
+        N = len(n)
+        if len(domain_size) != N or (x0 is not None and len(x0) != N):
+            raise ValueError("n, domain_size and x0 must have the same length")
+        if x0 is None:
+            x0 = (0.0,) * N
+        self.N = N
+        self._h = C.c_void_p()
+        n_arr = np.asarray(n, dtype=np.int64)
+        L_arr = np.asarray(domain_size, dtype=np.float64)
+        x_arr = np.asarray(x0, dtype=np.float64)
+        L.check(L.lib().pg_mesh_create(C.c_int32(N), L.iptr(n_arr), L.dptr(L_arr), L.dptr(x_arr), C.byref(self._h)))
+        self.dims = tuple(int(v) for v in n)
+        cen, nod = [], []
+        for d in range(N):
+            c = np.empty(self.dims[d])
+            k = np.empty(self.dims[d] + 1)
+            L.check(L.lib().pg_mesh_get_centers(self._h, d, L.dptr(c), C.c_int64(len(c))))
+            L.check(L.lib().pg_mesh_get_nodes(self._h, d, L.dptr(k), C.c_int64(len(k))))
+            cen.append(c)
+            nod.append(k)
+        self.centers = tuple(cen)
+        self.nodes = tuple(nod)
+        self.tag = MeshTag(self)
+
+    def _border_arrays(self):
+        nb = C.c_int64()
+        L.check(L.lib().pg_mesh_num_border_cells(self._h, C.byref(nb)))
+        nb = nb.value
+        idx = np.empty((nb, self.N), dtype=np.int64)
+        pos = np.empty((nb, self.N), dtype=np.float64)
+        key = np.empty(nb, dtype=np.int32)
+        L.check(L.lib().pg_mesh_get_border_cells(self._h, L.iptr(idx.reshape(-1)), L.dptr(pos.reshape(-1)),
+                                                 key.ctypes.data_as(L.c_i32_p)))
+        return idx, pos, key
+
+    @property
+    def ext(self):
+        return tuple(d + 1 for d in self.dims)
+
+    def __del__(self):
+        try:
+            if self._h:
+                L.lib().pg_mesh_destroy(self._h)
+        except Exception:
+            pass
+
+
+def nC(mesh: Mesh) -> int:
+    """src/mesh.jl:86."""
+    return int(np.prod(mesh.dims))
+
+
+# =============================================================================== bodies
+
+
+class Sphere:
+    """Tagged level set f(x) = |x - c| - r (fluid where f <= 0), evaluated in-kernel.
+    In 2-D a circle, in 1-D an interval.  `complement=True` gives -f (fluid outside)."""
+
+    def __init__(self, center: Sequence[float], radius: float, complement: bool = False):
+        self.center = tuple(float(v) for v in center)
+        self.radius = float(radius)
+        self.complement = bool(complement)
+
+    def __call__(self, *x):
+        s = sum((np.asarray(x[d]) - self.center[d]) ** 2 for d in range(len(self.center)))
+        f = np.sqrt(s) - self.radius
+        return -f if self.complement else f
+
+    def _abi(self, N: int):
+        if len(self.center) != N:
+            raise ValueError("body dimension does not match the mesh")
+        return L.PG_BODY_BALL, np.array(list(self.center) + [self.radius]), (L.PG_FLAG_COMPLEMENT if self.complement else 0)
+
+
+Circle = Sphere
+
+
+class MultiSphere:
+    """Union of pairwise disjoint spheres of equal radius, f = min_s f_s (weak-scaling body)."""
+
+    def __init__(self, centers: Sequence[Sequence[float]], radius: float):
+        self.centers = [tuple(float(v) for v in c) for c in centers]
+        self.radius = float(radius)
+
+    def __call__(self, *x):
+        return np.minimum.reduce([Sphere(c, self.radius)(*x) for c in self.centers])
+
+    def _abi(self, N: int):
+        flat = [self.radius, float(len(self.centers))]
+        for c in self.centers:
+            if len(c) != N:
+                raise ValueError("body dimension does not match the mesh")
+            flat += list(c)
+        return L.PG_BODY_MULTIBALL, np.array(flat), 0
+
+
+# =============================================================================== Capacity
+
+
+class Capacity:
+    """Capacity(body, mesh; method="VOFI", compute_centroids=true) -- src/capacity.jl:51-123.
+
+    Fields A, B, W (N-tuples), V, Γ are the DIAGONALS of the reference's diagonal matrices (length
+    M = prod(n_d+1)); C_ω, C_γ are (M,N) arrays; cell_types is the Float64 vector.  They are fetched
+    from the GPU on first access.  `body` must be a tagged body (Sphere / MultiSphere); an arbitrary
+    callable needs precomputed arrays: Capacity.from_arrays(...)."""
+
+    def __init__(self, body, mesh: Mesh, method: str = "VOFI", compute_centroids: bool = True):
+        if method not in ("VOFI", "ImplicitIntegration"):
+            raise ValueError('method must be "VOFI" or "ImplicitIntegration"')
+        if not hasattr(body, "_abi"):
+            raise PenguinHipError(
+                "Capacity: arbitrary level-set callables cannot be evaluated on the GPU; pass a tagged body "
+                "(Sphere, MultiSphere) or use Capacity.from_arrays with precomputed capacities")
+        L.init()
+        self.mesh = mesh
+        self.body = body
+        self.compute_centroids = compute_centroids
+        kind, params, flags = body._abi(mesh.N)
+        if not compute_centroids:
+            flags |= L.PG_FLAG_NO_CENTROIDS
+        self._h = C.c_void_p()
+        params = np.ascontiguousarray(params, dtype=np.float64)
+        L.check(L.lib().pg_capacity_create_levelset(mesh._h, C.c_int32(kind), L.dptr(params), C.c_int32(len(params)),
+                                                    C.c_int32(flags), C.byref(self._h)))
+        self._cache: Dict = {}
+
+    @classmethod
+    def from_arrays(cls, mesh: Mesh, V, A, B, W, Gamma, C_omega, C_gamma, cell_types, body=None):
+        L.init()
+        self = cls.__new__(cls)
+        self.mesh, self.body, self.compute_centroids = mesh, body, C_gamma is not None
+        N = mesh.N
+        keep = []
+
+        def arr(a):
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            keep.append(a)
+            return a
+
+        def ptrs(seq):
+            p = (L.c_double_p * N)()
+            for d in range(N):
+                p[d] = L.dptr(arr(seq[d]))
+            return p
+
+        cw = [np.ascontiguousarray(np.asarray(C_omega)[:, d]) for d in range(N)]
+        cg = [np.ascontiguousarray(np.asarray(C_gamma)[:, d]) for d in range(N)] if C_gamma is not None and len(C_gamma) else None
+        self._h = C.c_void_p()
+        L.check(L.lib().pg_capacity_create_from_arrays(
+            mesh._h, L.dptr(arr(V)), ptrs(A), ptrs(B), ptrs(W), L.dptr(arr(Gamma)), ptrs(cw),
+            ptrs(cg) if cg is not None else None, L.dptr(arr(cell_types)), C.byref(self._h)))
+        self._cache = {}
+        return self
+
+    # ---- lazy field access -------------------------------------------------------------------
+    def _get(self, field: int, d: int = 0) -> np.ndarray:
+        key = (field, d)
+        if key not in self._cache:
+            M = int(np.prod(self.mesh.ext))
+            out = np.zeros(M)
+            L.check(L.lib().pg_capacity_get(self._h, C.c_int32(field), C.c_int32(d), L.dptr(out), C.c_int64(M)))
+            self._cache[key] = out
+        return self._cache[key]
+
+    @property
+    def N(self):
+        return self.mesh.N
+
+    @property
+    def V(self):
+        return self._get(L.PG_CAP_V)
+
+    @property
+    def Γ(self):
+        return self._get(L.PG_CAP_GAMMA)
+
+    Gamma = Γ
+
+    @property
+    def cell_types(self):
+        return self._get(L.PG_CAP_CELL_TYPES)
+
+    @property
+    def A(self):
+        return tuple(self._get(L.PG_CAP_A, d) for d in range(self.N))
+
+    @property
+    def B(self):
+        return tuple(self._get(L.PG_CAP_B, d) for d in range(self.N))
+
+    @property
+    def W(self):
+        return tuple(self._get(L.PG_CAP_W, d) for d in range(self.N))
+
+    @property
+    def C_ω(self):
+        return np.stack([self._get(L.PG_CAP_C_OMEGA, d) for d in range(self.N)], axis=1)
+
+    C_omega = C_ω
+
+    @property
+    def C_γ(self):
+        if not self.compute_centroids:
+            return np.zeros((0, self.N))  # capacity.jl:119
+        return np.stack([self._get(L.PG_CAP_C_GAMMA, d) for d in range(self.N)], axis=1)
+
+    C_gamma = C_γ
+
+    @property
+    def kernel_ms(self) -> float:
+        ms = C.c_double()
+        L.check(L.lib().pg_capacity_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self._h:
+                L.lib().pg_capacity_destroy(self._h)
+        except Exception:
+            pass
+
+
+# =============================================================================== DiffusionOps
+
+
+class DiffusionOps:
+    """DiffusionOps(capacity) -- src/operators.jl:172-178.  G, H, Wꜝ are exported on demand as scipy CSC
+    matrices (the time loop never forms them); V is the diagonal; size = (n_d+1,...)."""
+
+    def __init__(self, capacity: Capacity):
+        self.capacity = capacity
+        self.size = capacity.mesh.ext
+        self._h = C.c_void_p()
+        L.check(L.lib().pg_diffops_create(capacity._h, C.byref(self._h)))
+        self._mats: Dict[int, object] = {}
+
+    def _export(self, which: int):
+        if which not in self._mats:
+            import scipy.sparse as sp
+
+            N, M = self.capacity.N, int(np.prod(self.size))
+            nnz = C.c_int64()
+            L.check(L.lib().pg_diffops_export_csc(self._h, C.c_int32(which), None, None, None, C.byref(nnz)))
+            ncols = N * M if which == L.PG_OP_WINV else M
+            colptr = np.empty(ncols + 1, dtype=np.int64)
+            rowval = np.empty(nnz.value, dtype=np.int64)
+            nzval = np.empty(nnz.value)
+            L.check(L.lib().pg_diffops_export_csc(self._h, C.c_int32(which), L.iptr(colptr), L.iptr(rowval), L.dptr(nzval),
+                                                  C.byref(nnz)))
+            self._mats[which] = sp.csc_matrix((nzval, rowval, colptr), shape=(N * M, ncols))
+        return self._mats[which]
+
+    @property
+    def G(self):
+        return self._export(L.PG_OP_G)
+
+    @property
+    def H(self):
+        return self._export(L.PG_OP_H)
+
+    @property
+    def Winv(self):
+        return self._export(L.PG_OP_WINV)
+
+    @property
+    def V(self):
+        return self.capacity.V
+
+    def __getattr__(self, name):
+        if name == "Wꜝ":
+            return self.Winv
+        raise AttributeError(name)
+
+    def __del__(self):
+        try:
+            if self._h:
+                L.lib().pg_diffops_destroy(self._h)
+        except Exception:
+            pass
+
+
+def grad(operator: DiffusionOps, p: np.ndarray) -> np.ndarray:
+    """∇(operator, p) -- src/operators.jl:20-23."""
+    M = int(np.prod(operator.size))
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    out = np.empty(operator.capacity.N * M)
+    L.check(L.lib().pg_diffops_grad(operator._h, L.dptr(p), L.dptr(out)))
+    return out
+
+
+def div(operator: DiffusionOps, qω: np.ndarray, qγ: np.ndarray) -> np.ndarray:
+    """∇₋(operator, qω, qγ) -- src/operators.jl:30-34."""
+    M = int(np.prod(operator.size))
+    qω = np.ascontiguousarray(qω, dtype=np.float64)
+    qγ = np.ascontiguousarray(qγ, dtype=np.float64)
+    out = np.empty(M)
+    L.check(L.lib().pg_diffops_div(operator._h, L.dptr(qω), L.dptr(qγ), L.dptr(out)))
+    return out
+
+
+# =============================================================================== boundary / phase
+
+
+@dataclass
+class Dirichlet:
+    """src/boundary.jl:12-14."""
+    value: Union[float, Callable]
+
+
+@dataclass
+class Neumann:
+    """src/boundary.jl:25-27."""
+    value: Union[float, Callable]
+
+
+@dataclass
+class Robin:
+    """src/boundary.jl:38-42."""
+    α: float
+    β: float
+    value: Union[float, Callable]
+
+
+@dataclass
+class Periodic:
+    """src/boundary.jl:49-50."""
+
+
+@dataclass
+class ScalarJump:
+    """src/boundary.jl:96-100."""
+    α1: float
+    α2: float
+    value: Union[float, Callable]
+
+
+@dataclass
+class FluxJump:
+    """src/boundary.jl:111-115."""
+    β1: float
+    β2: float
+    value: Union[float, Callable]
+
+
+class BorderConditions:
+    """BorderConditions(Dict(:left => bc, ...)) -- src/boundary.jl:123-125.  Keys may be written
+    "left" or ":left"; unknown keys (e.g. :front) are kept and silently ignored, as in the reference."""
+
+    def __init__(self, borders: Dict[str, object]):
+        self.borders = {str(k).lstrip(":"): v for k, v in borders.items()}
+
+
+@dataclass
+class InterfaceConditions:
+    """src/boundary.jl:133-136."""
+    scalar: Optional[ScalarJump]
+    flux: Optional[FluxJump]
+
+
+@dataclass
+class Phase:
+    """Phase(capacity, operator, source, Diffusion_coeff) -- src/phase.jl:12-17."""
+    capacity: Capacity
+    operator: DiffusionOps
+    source: Callable
+    Diffusion_coeff: Callable
+
+
+# =============================================================================== closure evaluation
+
+
+def _accepts(fn, nargs: int) -> bool:
+    """Does fn have a method with `nargs` positional arguments?  (Julia: MethodError otherwise.)"""
+    try:
+        inspect.signature(fn).bind(*([0.0] * nargs))
+        return True
+    except TypeError:
+        return False
+    except ValueError:   # builtins without a signature
+        return True
+
+
+def _eval(fn, coords: np.ndarray, t: Optional[float], nargs_space: int):
+    """Evaluate fn at the rows of coords (padded with zero columns up to nargs_space), vectorised when the
+    callable accepts arrays.  Mirrors `try value(x..., t) catch value(x...)` (src/solver.jl:315-319,441-448).
+    Returns a float when the callable returned a scalar for array input (constant data)."""
+    cols = [coords[:, d] if d < coords.shape[1] else np.zeros(coords.shape[0]) for d in range(nargs_space)]
+    if t is not None and _accepts(fn, nargs_space + 1):
+        call = lambda c: fn(*c, t)
+    elif _accepts(fn, nargs_space):
+        call = lambda c: fn(*c)
+    else:
+        raise TypeError(f"{fn!r} accepts neither {nargs_space + 1} nor {nargs_space} positional arguments")
+    try:
+        out = call(cols)
+    except Exception:
+        # not vectorisable (branches, math.* calls): per-point loop with the same signature
+        return np.array([call([c[i] for c in cols]) for i in range(coords.shape[0])], dtype=np.float64)
+    if np.isscalar(out) or (isinstance(out, np.ndarray) and out.ndim == 0):
+        return float(out)
+    out = np.asarray(out, dtype=np.float64)
+    if out.shape != (coords.shape[0],):
+        out = np.broadcast_to(out, (coords.shape[0],)).copy()
+    return np.ascontiguousarray(out)
+
+
+def _padded_field(val, M: int) -> Optional[np.ndarray]:
+    """scalar/array -> M array (None for an exact zero scalar)."""
+    if isinstance(val, float):
+        return None if val == 0.0 else np.full(M, val)
+    return np.ascontiguousarray(val, dtype=np.float64)
+
+
+# =============================================================================== Solver
+
+
+class Solver:
+    """Penguin.Solver -- src/solver.jl:33-42.  `x` is the full 2M (mono) / 4M (diph) vector with zeros at
+    eliminated unknowns (:186-187); `states` holds one such vector per solve when save_states is on."""
+
+    def __init__(self, time_type: str, phase_type: str, equation_type: str):
+        self.time_type, self.phase_type, self.equation_type = time_type, phase_type, equation_type
+        self.x: Optional[np.ndarray] = None
+        self.ch: list = []
+        self.states: list = []
+        self._h = C.c_void_p()
+        self._nunk = 0
+        self._initial_done = False
+        self.last_run: Optional[L.pg_run_info] = None
+
+    # reduced system of the constructor (which=0) or of the loop (which=1): (A_csr, b, idx)
+    def system(self, which: int = 0):
+        import scipy.sparse as sp
+
+        info = self.system_info(which)
+        n, nnz = info.n_own, info.nnz
+        rowptr = np.empty(n + 1, dtype=np.int64)
+        col = np.empty(max(nnz, 1), dtype=np.int64)
+        val = np.empty(max(nnz, 1))
+        b = np.empty(max(n, 1))
+        idx = np.empty(max(n, 1), dtype=np.int64)
+        L.check(L.lib().pg_solver_get_system_csr(self._h, C.c_int32(which), L.iptr(rowptr), L.iptr(col), L.dptr(val),
+                                                 L.dptr(b), L.iptr(idx)))
+        A = sp.csr_matrix((val[:nnz], col[:nnz], rowptr), shape=(n, n + info.n_ghost))
+        return A, b[:n], idx[:n]
+
+    def system_info(self, which: int = 0) -> L.pg_system_info:
+        info = L.pg_system_info()
+        L.check(L.lib().pg_solver_system_info(self._h, C.c_int32(which), C.byref(info)))
+        return info
+
+    @property
+    def A(self):
+        """The reference's s.A restricted to its active rows/cols, embedded in the full (2M x 2M) shape."""
+        import scipy.sparse as sp
+
+        Ar, _, idx = self.system(1 if self._initial_done and self._have_run else 0)
+        n = self._nunk
+        P = sp.csr_matrix((np.ones(len(idx)), (idx, np.arange(len(idx)))), shape=(n, len(idx)))
+        return (P @ Ar[:, : len(idx)] @ P.T).tocsc()
+
+    @property
+    def b(self):
+        _, b, idx = self.system(0)
+        out = np.zeros(self._nunk)
+        out[idx] = b
+        return out
+
+    _have_run = False
+
+    def _fetch_state(self, index: int = -1) -> np.ndarray:
+        out = np.zeros(self._nunk)
+        L.check(L.lib().pg_solver_get_state(self._h, C.c_int64(index), L.dptr(out), C.c_int64(self._nunk)))
+        return out
+
+    def __del__(self):
+        try:
+            if self._h:
+                L.lib().pg_solver_destroy(self._h)
+        except Exception:
+            pass
+
+
+def _border_descs(bc_b: BorderConditions, mesh: Mesh, t: Optional[float]):
+    """-> (ctypes array of pg_border_desc, per-border-cell values or None)."""
+    descs = []
+    need_values = False
+    for name, cond in bc_b.borders.items():
+        if name not in L.PG_KEY:
+            continue  # unknown keys are silently ignored (examples/3D/Diffusion/Heat.jl:26 uses :front/:back)
+        if isinstance(cond, Dirichlet):
+            kind = L.PG_BC_DIRICHLET
+        elif isinstance(cond, Periodic):
+            kind = L.PG_BC_PERIODIC
+        elif isinstance(cond, Neumann):
+            kind = L.PG_BC_NEUMANN
+        elif isinstance(cond, Robin):
+            kind = L.PG_BC_ROBIN
+        else:
+            raise TypeError(f"unsupported border condition {cond!r}")
+        value = 0.0
+        v = getattr(cond, "value", 0.0)
+        if callable(v):
+            need_values = True
+        elif v is not None:
+            value = float(v)
+        descs.append(L.pg_border_desc(L.PG_KEY[name], kind, value))
+    arr = (L.pg_border_desc * max(len(descs), 1))(*descs)
+    values = _border_values(bc_b, mesh, t) if need_values else None
+    return arr, len(descs), values
+
+
+def _border_values(bc_b: BorderConditions, mesh: Mesh, t: Optional[float]) -> np.ndarray:
+    """eval_bc_value at every border cell (src/solver.jl:441-448): value(pos..., t) with the N unpadded
+    coordinates of mesh.centers."""
+    idx, pos, key = mesh._border_arrays()
+    out = np.zeros(len(key))
+    inv = {v: k for k, v in L.PG_KEY.items()}
+    for kval in np.unique(key):
+        cond = bc_b.borders.get(inv[int(kval)])
+        if cond is None:
+            continue
+        sel = key == kval
+        v = getattr(cond, "value", 0.0)
+        if callable(v):
+            out[sel] = _eval(v, pos[sel], t, mesh.N)
+        elif v is not None:
+            out[sel] = float(v)
+    return out
+
+
+def _krylov_opts(method, kwargs) -> L.pg_krylov_opts:
+    """method may be "bicgstab" / "cg" or a callable named like IterativeSolvers' (bicgstabl, cg, gmres...).
+    The reference's default (gmres) and `\\` are served by BiCGStab run to reltol (default 1e-12: the parity
+    target is the direct-solve path)."""
+    name = method if isinstance(method, str) else getattr(method, "__name__", "bicgstab")
+    name = name.lower()
+    m = L.PG_METHOD["cg"] if name == "cg" else L.PG_METHOD["bicgstab"]
+    return L.pg_krylov_opts(m, float(kwargs.get("reltol", 1e-12)), float(kwargs.get("abstol", 0.0)),
+                            int(kwargs.get("maxiter", 0)), int(kwargs.get("check_every", 4)))
+
+
+def DiffusionUnsteadyMono(phase: Phase, bc_b: BorderConditions, bc_i, Δt: float, Tᵢ: np.ndarray, scheme: str,
+                          verbose: bool = False) -> Solver:
+    """DiffusionUnsteadyMono(phase, bc_b, bc_i, Δt, Tᵢ, scheme) -- src/solver/diffusion.jl:192-210."""
+    if verbose:
+        print("Solver creation:\n- Monophasic problem\n- Unsteady problem\n- Diffusion problem")
+    s = Solver("Unsteady", "Monophasic", "Diffusion")
+    cap, mesh = phase.capacity, phase.capacity.mesh
+    M = int(np.prod(mesh.ext))
+    s._nunk = 2 * M
+    Tᵢ = np.ascontiguousarray(Tᵢ, dtype=np.float64)
+    if Tᵢ.shape != (2 * M,):
+        raise ValueError(f"Tᵢ must have length 2*prod(n+1) = {2 * M}")
+    sch = "CN" if scheme == "CN" else "BE"   # diffusion.jl:200-206: anything but "CN" is BE
+    # interface condition
+    if isinstance(bc_i, Dirichlet):
+        kind, a, b = L.PG_BC_DIRICHLET, 0.0, 0.0
+    elif isinstance(bc_i, Neumann):
+        kind, a, b = L.PG_BC_NEUMANN, 0.0, 0.0
+    elif isinstance(bc_i, Robin):
+        kind, a, b = L.PG_BC_ROBIN, float(bc_i.α), float(bc_i.β)
+    else:
+        raise TypeError(f"unsupported interface condition {bc_i!r}")
+    s._ctx = dict(phase=phase, bc_i=bc_i, dt=float(Δt), M=M)
+    g_arr = None
+    gval = 0.0
+    if callable(bc_i.value):
+        g = _eval(bc_i.value, cap.C_γ, float(Δt), 3)      # b(t=0) uses g(0+Δt)  diffusion.jl:249
+        if isinstance(g, float):
+            gval = g
+        else:
+            g_arr = g
+    else:
+        gval = float(bc_i.value)
+    desc = L.pg_bc_desc(kind, a, b, gval, L.dptr(g_arr) if g_arr is not None else None)
+    D = _eval(phase.Diffusion_coeff, cap.C_ω, None, 3) if callable(phase.Diffusion_coeff) else float(phase.Diffusion_coeff)
+    if isinstance(D, float):
+        D_arr = None if D == 1.0 else np.full(M, D)
+    else:
+        D_arr = D
+    f1 = _eval(phase.source, cap.C_ω, float(Δt), 3)        # f(0+Δt)
+    f_arr = _padded_field(f1, M)
+    borders, nb, bvals = _border_descs(bc_b, mesh, 0.0)    # ctor applies borders with t = 0  (:207)
+    L.check(L.lib().pg_solver_create_unsteady_mono(
+        cap._h, phase.operator._h, C.byref(desc), borders, C.c_int32(nb),
+        L.dptr(D_arr) if D_arr is not None else None, L.dptr(f_arr) if f_arr is not None else None,
+        C.c_double(Δt), L.dptr(Tᵢ), C.c_int32(L.PG_SCHEME[sch]), C.byref(s._h)))
+    if sch == "CN":
+        f0 = _padded_field(_eval(phase.source, cap.C_ω, 0.0, 3), M)
+        if f0 is not None:
+            L.check(L.lib().pg_solver_set_source(s._h, 0, L.dptr(f0), None))
+        if callable(bc_i.value):
+            g0 = _eval(bc_i.value, cap.C_γ, 0.0, 3)
+            g0 = np.full(M, g0) if isinstance(g0, float) else g0
+            L.check(L.lib().pg_solver_set_interface_value(s._h, L.dptr(g0), None))
+    if bvals is not None:
+        L.check(L.lib().pg_solver_set_border_values(s._h, L.dptr(bvals)))
+    s._ctor_scheme = sch
+    return s
+
+
+def _time_dependent(fn, coords, t0, t1, nspace) -> bool:
+    """Is data(fn) different at two times?  (constant-in-time data lets the whole loop run on the device)."""
+    if not callable(fn):
+        return False
+    a, b = _eval(fn, coords, t0, nspace), _eval(fn, coords, t1, nspace)
+    if isinstance(a, float) and isinstance(b, float):
+        return a != b
+    return not np.array_equal(np.asarray(a), np.asarray(b))
+
+
+def solve_DiffusionUnsteadyMono_b(s: Solver, phase: Phase, Δt: float, Tₑ: float, bc_b: BorderConditions, bc,
+                                  scheme: str, method="bicgstab", algorithm=None, save_states: bool = True,
+                                  verbose: bool = False, max_steps: Optional[int] = None, **kwargs):
+    """solve_DiffusionUnsteadyMono!(s, phase, Δt, Tₑ, bc_b, bc, scheme; method, algorithm, kwargs...)
+    -- src/solver/diffusion.jl:268-301, quirks kept: the first solve uses the constructor's system and is
+    states[1]; A is rebuilt once with `scheme`; `while t < Tₑ` with fp64 `t += Δt`; data at t+Δt."""
+    if s is None or not s._h:
+        raise PenguinHipError("Solver is not initialized. Call a solver constructor first.")  # :269-271
+    opts = _krylov_opts(method, kwargs)
+    log = bool(kwargs.get("log", False))
+    cap, mesh, M = phase.capacity, phase.capacity.mesh, s._ctx["M"]
+    sch = L.PG_SCHEME[scheme] if scheme in L.PG_SCHEME else L.PG_SCHEME["BE"]
+    t = 0.0
+    info = L.pg_step_info()
+    L.check(L.lib().pg_solver_initial_solve(s._h, C.byref(opts), C.byref(info)))   # :275
+    s._initial_done = True
+    if log:
+        s.ch.append({"iters": info.iters, "resnorm": info.resnorm, "isconverged": bool(info.converged)})
+    s.x = s._fetch_state()
+    if save_states:
+        s.states.append(s.x)
+    if verbose:
+        print("Time: ", t)
+        print("Solver Extremum: ", info.extremum)
+    # is any closure time dependent?  sample t = Δt and 2Δt
+    dyn_f = _time_dependent(phase.source, cap.C_ω, Δt, 2 * Δt, 3)
+    dyn_g = _time_dependent(bc.value, cap.C_γ, Δt, 2 * Δt, 3) if callable(bc.value) else False
+    dyn_b = any(_time_dependent(getattr(c, "value", None), np.zeros((1, mesh.N)), Δt, 2 * Δt, mesh.N)
+                for c in bc_b.borders.values())
+    steps = 0
+    if not (dyn_f or dyn_g or dyn_b):
+        if save_states or verbose or log:
+            while t < Tₑ:
+                if max_steps is not None and steps >= max_steps:
+                    break
+                t += Δt
+                if verbose:
+                    print("Time: ", t)
+                L.check(L.lib().pg_solver_step(s._h, C.c_int32(sch), C.byref(opts), C.byref(info)))
+                s._have_run = True
+                if log:
+                    s.ch.append({"iters": info.iters, "resnorm": info.resnorm, "isconverged": bool(info.converged)})
+                s.x = s._fetch_state()
+                if save_states:
+                    s.states.append(s.x)
+                if verbose:
+                    print("Solver Extremum: ", info.extremum)
+                steps += 1
+        else:
+            run = L.pg_run_info()
+            L.check(L.lib().pg_solver_run(s._h, C.c_double(Tₑ), C.c_int32(sch), C.byref(opts), C.c_int32(0),
+                                          C.c_int64(-1 if max_steps is None else max_steps), C.c_int32(0), C.byref(run)))
+            s._have_run = True
+            s.last_run = run
+            s.x = s._fetch_state()
+        return s
+    # time-dependent data: host-driven loop, closures evaluated at the reference's points and times
+    while t < Tₑ:
+        if max_steps is not None and steps >= max_steps:
+            break
+        t += Δt                                                             # :287
+        if verbose:
+            print("Time: ", t)
+        if dyn_f or scheme == "CN":
+            fn = _padded_field(_eval(phase.source, cap.C_ω, t, 3), M)
+            fn1 = _padded_field(_eval(phase.source, cap.C_ω, t + Δt, 3), M)   # f(t+Δt), t already advanced (:248)
+            zero = np.zeros(M)
+            L.check(L.lib().pg_solver_set_source(s._h, 0, L.dptr(fn if fn is not None else zero),
+                                                 L.dptr(fn1 if fn1 is not None else zero)))
+        if callable(bc.value) and (dyn_g or scheme == "CN"):
+            gn, gn1 = _eval(bc.value, cap.C_γ, t, 3), _eval(bc.value, cap.C_γ, t + Δt, 3)
+            gn = np.full(M, gn) if isinstance(gn, float) else gn
+            gn1 = np.full(M, gn1) if isinstance(gn1, float) else gn1
+            L.check(L.lib().pg_solver_set_interface_value(s._h, L.dptr(gn), L.dptr(gn1)))
+        if dyn_b:
+            L.check(L.lib().pg_solver_set_border_values(s._h, L.dptr(_border_values(bc_b, mesh, t))))   # :292
+        L.check(L.lib().pg_solver_step(s._h, C.c_int32(sch), C.byref(opts), C.byref(info)))            # :294
+        s._have_run = True
+        if log:
+            s.ch.append({"iters": info.iters, "resnorm": info.resnorm, "isconverged": bool(info.converged)})
+        s.x = s._fetch_state()
+        if save_states:
+            s.states.append(s.x)
+        if verbose:
+            print("Solver Extremum: ", info.extremum)
+        steps += 1
+    return s
+
+
+# ---- diphasic twins (config 5) ---------------------------------------------------------------------
+
+
+def DiffusionUnsteadyDiph(phase1: Phase, phase2: Phase, bc_b: BorderConditions, ic: InterfaceConditions, Δt: float,
+                          Tᵢ: np.ndarray, scheme: str, verbose: bool = False) -> Solver:
+    """DiffusionUnsteadyDiph(phase1, phase2, bc_b, ic, Δt, Tᵢ, scheme) -- src/solver/diffusion.jl:319-332."""
+    if verbose:
+        print("Solver creation:\n- Diphasic problem\n- Unsteady problem\n- Diffusion problem")
+    s = Solver("Unsteady", "Diphasic", "Diffusion")
+    mesh = phase1.capacity.mesh
+    M = int(np.prod(mesh.ext))
+    s._nunk = 4 * M
+    Tᵢ = np.ascontiguousarray(Tᵢ, dtype=np.float64)
+    if Tᵢ.shape != (4 * M,):
+        raise ValueError(f"Tᵢ must have length 4*prod(n+1) = {4 * M}")
+    jump, flux = ic.scalar, ic.flux
+    # g, h are built WITHOUT t (diffusion.jl:397)
+    g = _eval(jump.value, phase1.capacity.C_γ, None, 3) if callable(jump.value) else float(jump.value)
+    h = _eval(flux.value, phase2.capacity.C_γ, None, 3) if callable(flux.value) else float(flux.value)
+    g_arr = None if isinstance(g, float) else g
+    h_arr = None if isinstance(h, float) else h
+    desc = L.pg_jump_desc(float(jump.α1), float(jump.α2), g if isinstance(g, float) else 0.0, float(flux.β1),
+                          float(flux.β2), h if isinstance(h, float) else 0.0,
+                          L.dptr(g_arr) if g_arr is not None else None, L.dptr(h_arr) if h_arr is not None else None)
+
+    def dcoef(ph):
+        D = _eval(ph.Diffusion_coeff, ph.capacity.C_ω, None, 3) if callable(ph.Diffusion_coeff) else float(ph.Diffusion_coeff)
+        if isinstance(D, float):
+            return None if D == 1.0 else np.full(M, D)
+        return D
+
+    D1, D2 = dcoef(phase1), dcoef(phase2)
+    f1 = _padded_field(_eval(phase1.source, phase1.capacity.C_ω, float(Δt), 3), M)
+    f2 = _padded_field(_eval(phase2.source, phase2.capacity.C_ω, float(Δt), 3), M)
+    borders, nb, bvals = _border_descs(bc_b, mesh, None)   # BC_border_diph! is called without t (:330)
+    sch = "CN" if scheme == "CN" else "BE"
+    p = lambda a: L.dptr(a) if a is not None else None
+    L.check(L.lib().pg_solver_create_unsteady_diph(
+        phase1.capacity._h, phase1.operator._h, phase2.capacity._h, phase2.operator._h, C.byref(desc), borders,
+        C.c_int32(nb), p(D1), p(D2), p(f1), p(f2), C.c_double(Δt), L.dptr(Tᵢ), C.c_int32(L.PG_SCHEME[sch]), C.byref(s._h)))
+    if sch == "CN":
+        for q, ph in enumerate((phase1, phase2)):
+            f0 = _padded_field(_eval(ph.source, ph.capacity.C_ω, 0.0, 3), M)
+            if f0 is not None:
+                L.check(L.lib().pg_solver_set_source(s._h, q, L.dptr(f0), None))
+    if bvals is not None:
+        L.check(L.lib().pg_solver_set_border_values(s._h, L.dptr(bvals)))
+    s._ctx = dict(M=M, dt=float(Δt))
+    s._ctor_scheme = sch
+    return s
+
+
+def solve_DiffusionUnsteadyDiph_b(s: Solver, phase1: Phase, phase2: Phase, Δt: float, Tₑ: float,
+                                  bc_b: BorderConditions, ic: InterfaceConditions, scheme: str, method="bicgstab",
+                                  algorithm=None, save_states: bool = True, verbose: bool = False,
+                                  max_steps: Optional[int] = None, **kwargs):
+    """solve_DiffusionUnsteadyDiph!(...) -- src/solver/diffusion.jl:422-454 (constant-in-time sources)."""
+    if s is None or not s._h:
+        raise PenguinHipError("Solver is not initialized. Call a solver constructor first.")
+    opts = _krylov_opts(method, kwargs)
+    M = s._ctx["M"]
+    sch = L.PG_SCHEME[scheme] if scheme in L.PG_SCHEME else L.PG_SCHEME["BE"]
+    dyn = any(_time_dependent(ph.source, ph.capacity.C_ω, Δt, 2 * Δt, 3) for ph in (phase1, phase2))
+    t = 0.0
+    info = L.pg_step_info()
+    if verbose:
+        print("Time: ", t)
+    L.check(L.lib().pg_solver_initial_solve(s._h, C.byref(opts), C.byref(info)))
+    s._initial_done = True
+    s.x = s._fetch_state()
+    if save_states:
+        s.states.append(s.x)
+    if verbose:
+        print("Solver Extremum: ", info.extremum)
+    steps = 0
+    while t < Tₑ:
+        if max_steps is not None and steps >= max_steps:
+            break
+        t += Δt
+        if verbose:
+            print("Time: ", t)
+        if dyn or scheme == "CN":
+            for q, ph in enumerate((phase1, phase2)):
+                fn = _padded_field(_eval(ph.source, ph.capacity.C_ω, t, 3), M)
+                fn1 = _padded_field(_eval(ph.source, ph.capacity.C_ω, t + Δt, 3), M)
+                zero = np.zeros(M)
+                L.check(L.lib().pg_solver_set_source(s._h, q, L.dptr(fn if fn is not None else zero),
+                                                     L.dptr(fn1 if fn1 is not None else zero)))
+        L.check(L.lib().pg_solver_step(s._h, C.c_int32(sch), C.byref(opts), C.byref(info)))
+        s._have_run = True
+        s.x = s._fetch_state()
+        if save_states:
+            s.states.append(s.x)
+        if verbose:
+            print("Solver Extremum: ", info.extremum)
+        steps += 1
+    return s
+
+
+# =============================================================================== convergence metric
+
+
+def lp_norm(errors, indices, pval, capacity: Capacity):
+    """src/convergence.jl:4-15."""
+    V = capacity.V
+    if pval == math.inf:
+        return float(np.max(np.abs(errors[indices]), initial=0.0))
+    return float((np.sum(np.abs(errors[indices]) ** pval * V[indices]) / np.sum(V)) ** (1.0 / pval))
+
+
+def check_convergence(u_analytical: Callable, solver: Solver, capacity: Capacity, p=2):
+    """src/convergence.jl:45-93 (absolute norms)."""
+    Cw = capacity.C_ω
+    u_ana = np.array([u_analytical(*c) for c in Cw], dtype=np.float64)
+    u_num = solver.x[: len(solver.x) // 2]
+    err = u_ana - u_num
+    ct = capacity.cell_types
+    sel = lambda m: np.flatnonzero(m)
+    return (u_ana, u_num, lp_norm(err, sel((ct == 1) | (ct == -1)), p, capacity), lp_norm(err, sel(ct == 1), p, capacity),
+            lp_norm(err, sel(ct == -1), p, capacity), lp_norm(err, sel(ct == 0), p, capacity))

@@ -1,0 +1,49 @@
+// pg_capacity.h -- device-resident Capacity (src/capacity.jl:25-36) of one slab.
+#pragma once
+#include "pg_common.h"
+#include "pg_geom.h"
+
+struct pg_capacity {
+  pg_mesh* mesh = nullptr;
+  pg::Slab slab;
+  int N = 0;
+  bool from_body = false;
+  bool has_cg = true;
+  pggeom::BallSet body;
+  // all arrays: slab.Mloc() doubles in the local stored layout (plane-major, dim-0 fastest)
+  pg::DevBuf<double> V, G, ct;
+  pg::DevBuf<double> A[3], B[3], W[3], Cw[3], Cg[3];
+  double kernel_ms = 0.0;
+  pg::i64 n_cut_local = 0;
+};
+
+struct pg_diffops {
+  pg_capacity* cap = nullptr;
+};
+
+namespace pg {
+// pointers handed to kernels
+struct CapView {
+  int N;
+  i64 ext[3], n[3], stride[3];
+  i64 plane, s0, s1, nplanes;   // stored planes [s0,s1) of the slowest dim
+  const double* V;
+  const double* G;
+  const double* A[3];
+  const double* B[3];
+  const double* W[3];
+};
+CapView cap_view(const pg_capacity* c);
+
+// local cell -> 0-based Cartesian index (slowest dim from the plane number)
+__host__ __device__ inline void decode_cell(int N, const i64* ext, i64 plane, i64 s0, i64 lc, i64* idx) {
+  const i64 p = lc / plane + s0;
+  i64 rem = lc % plane;
+  idx[0] = idx[1] = idx[2] = 0;
+  for (int d = 0; d < N - 1; ++d) {
+    idx[d] = rem % ext[d];
+    rem /= ext[d];
+  }
+  idx[N - 1] = p;
+}
+}  // namespace pg

@@ -1,0 +1,492 @@
+// pg_capacity.hip -- K1-K5 of SURVEY.md section 2.3: per-cell cut-cell capacities on the GPU.
+//
+//   reference                                             here
+//   CartesianGeometry.integrate(Tuple{0},...)  capacity.jl:90-92   k_classify + k_cut_cells  (V, C_w, Gamma, type)
+//   computeInterfaceCentroids                  capacity.jl:137-197 k_cut_cells               (C_gamma)
+//   integrate(Tuple{1},...)                    capacity.jl:103     k_sections                (A_d)
+//   integrate(Tuple{1},...,bary)               capacity.jl:105     k_sections                (B_d)
+//   integrate(Tuple{0},...,bary)               capacity.jl:104     k_stagger + k_stagger_cut (W_d)
+//
+// Layout: one thread per padded cell, dim-0 fastest => every store is a coalesced 8-byte-per-lane
+// stream.  Cells whose geometry needs quadrature (cut cells, ~n^(N-1) of n^N) are appended to a
+// compacted work list and processed by a dense second kernel so that no wave idles on a lone cut
+// cell.  Compiled with -ffp-contract=off: classification must match the oracle bit for bit.
+#include "pg_capacity.h"
+
+#include <algorithm>
+#include <memory>
+
+using namespace pg;
+using namespace pggeom;
+
+__constant__ GLTable c_gl;
+
+namespace {
+
+struct GeoView {
+  int N;
+  i64 ext[3], n[3], stride[3];
+  i64 plane, s0, s1;
+  const double* nodes[3];
+};
+
+__device__ inline bool is_real_cell(const GeoView& g, const i64* idx) {
+  for (int d = 0; d < g.N; ++d)
+    if (idx[d] >= g.n[d]) return false;
+  return true;
+}
+
+__device__ inline void cell_box(const GeoView& g, const i64* idx, double* lo, double* hi) {
+  for (int d = 0; d < g.N; ++d) {
+    lo[d] = g.nodes[d][idx[d]];
+    hi[d] = g.nodes[d][idx[d] + 1];
+  }
+}
+
+// K1 (cheap part): classify every stored cell; full/empty cells are finished here.
+__global__ void k_classify(GeoView g, BallSet bs, i64 Mloc, double* V, double* G, double* ct, double* Cw0,
+                           double* Cw1, double* Cw2, double* Cg0, double* Cg1, double* Cg2, int* cut_list,
+                           int* cut_count) {
+  double* Cw[3] = {Cw0, Cw1, Cw2};
+  double* Cg[3] = {Cg0, Cg1, Cg2};
+  for (i64 lc = blockIdx.x * (i64)blockDim.x + threadIdx.x; lc < Mloc; lc += (i64)gridDim.x * blockDim.x) {
+    i64 idx[3];
+    decode_cell(g.N, g.ext, g.plane, g.s0, lc, idx);
+    double v = 0.0, t = 0.0;
+    double cw[3] = {0.0, 0.0, 0.0};
+    if (is_real_cell(g, idx)) {
+      double lo[3], hi[3];
+      cell_box(g, idx, lo, hi);
+      int type;
+      pick_ball(bs, lo, hi, type);
+      if (type != PG_CUT && bs.complement) type = 1 - type;
+      for (int d = 0; d < g.N; ++d) cw[d] = 0.5 * (lo[d] + hi[d]);
+      if (type == PG_FULL) v = prod_ext(lo, hi, g.N, -1);
+      if (type == PG_CUT) {
+        const int slot = atomicAdd(cut_count, 1);
+        cut_list[slot] = (int)lc;
+      }
+      t = (double)type;
+    }
+    V[lc] = v;
+    G[lc] = 0.0;
+    ct[lc] = t;
+    for (int d = 0; d < g.N; ++d) {
+      Cw[d][lc] = cw[d];
+      if (Cg[d]) Cg[d][lc] = 0.0;
+    }
+  }
+}
+
+// K1/K5 (expensive part): one thread per cut cell of the compacted list.
+__global__ void k_cut_cells(GeoView g, BallSet bs, const int* cut_list, int ncut, double* V, double* G,
+                            double* Cw0, double* Cw1, double* Cw2, double* Cg0, double* Cg1, double* Cg2) {
+  double* Cw[3] = {Cw0, Cw1, Cw2};
+  double* Cg[3] = {Cg0, Cg1, Cg2};
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= ncut) return;
+  const i64 lc = cut_list[k];
+  i64 idx[3];
+  decode_cell(g.N, g.ext, g.plane, g.s0, lc, idx);
+  double lo[3], hi[3];
+  cell_box(g, idx, lo, hi);
+  const BoxMeasure m = box_measure(bs, lo, hi, true, c_gl);
+  V[lc] = m.vol;
+  G[lc] = m.gamma;
+  for (int d = 0; d < g.N; ++d) {
+    Cw[d][lc] = m.cen[d];
+    if (Cg[d]) Cg[d][lc] = m.cg[d];
+  }
+}
+
+// K2 + K4: A_d (face x_d = nodes_d[i_d], i_d <= n_d, other dims real) and B_d (section through C_w[d]).
+__global__ void k_sections(GeoView g, BallSet bs, i64 Mloc, const double* Cw0, const double* Cw1,
+                           const double* Cw2, double* A0, double* A1, double* A2, double* B0, double* B1,
+                           double* B2) {
+  const double* Cw[3] = {Cw0, Cw1, Cw2};
+  double* A[3] = {A0, A1, A2};
+  double* B[3] = {B0, B1, B2};
+  for (i64 lc = blockIdx.x * (i64)blockDim.x + threadIdx.x; lc < Mloc; lc += (i64)gridDim.x * blockDim.x) {
+    i64 idx[3];
+    decode_cell(g.N, g.ext, g.plane, g.s0, lc, idx);
+    const bool real = is_real_cell(g, idx);
+    for (int d = 0; d < g.N; ++d) {
+      // A_d: other dims must be real; the section box uses the cell extents of the other dims
+      bool others_real = true;
+      for (int k = 0; k < g.N; ++k)
+        if (k != d && idx[k] >= g.n[k]) others_real = false;
+      double a = 0.0, b = 0.0;
+      if (others_real) {
+        double lo[3], hi[3];
+        for (int k = 0; k < g.N; ++k) {
+          const i64 ik = idx[k] < g.n[k] ? idx[k] : g.n[k] - 1;
+          lo[k] = g.nodes[k][ik];
+          hi[k] = g.nodes[k][ik + 1];
+        }
+        a = section_measure(bs, d, g.nodes[d][idx[d]], lo, hi);
+        if (real) b = section_measure(bs, d, Cw[d][lc], lo, hi);
+      }
+      A[d][lc] = a;
+      B[d][lc] = b;
+    }
+  }
+}
+
+// K3 (cheap part): W_d between the centroids of i-e_d and i; cut boxes go to the work list.
+__global__ void k_stagger(GeoView g, BallSet bs, i64 Mloc, const double* ct, const double* Cw0, const double* Cw1,
+                          const double* Cw2, double* W0, double* W1, double* W2, int* wlist, int* wcount, int wcap) {
+  const double* Cw[3] = {Cw0, Cw1, Cw2};
+  double* W[3] = {W0, W1, W2};
+  for (i64 lc = blockIdx.x * (i64)blockDim.x + threadIdx.x; lc < Mloc; lc += (i64)gridDim.x * blockDim.x) {
+    i64 idx[3];
+    decode_cell(g.N, g.ext, g.plane, g.s0, lc, idx);
+    for (int d = 0; d < g.N; ++d) {
+      double w = 0.0;
+      bool others_real = true;
+      for (int k = 0; k < g.N; ++k)
+        if (k != d && idx[k] >= g.n[k]) others_real = false;
+      // prev = max(i-1, first), next = min(i, last real)      capacity.jl:401-402
+      const i64 ip = idx[d] - 1 < 0 ? 0 : idx[d] - 1;
+      const i64 in = idx[d] < g.n[d] - 1 ? idx[d] : g.n[d] - 1;
+      const i64 lp = lc + (ip - idx[d]) * g.stride[d];
+      const i64 ln = lc + (in - idx[d]) * g.stride[d];
+      // the neighbour in the slowest dim may lie outside the stored planes: leave 0 (never read)
+      const bool have = lp >= 0 && ln >= 0 && lp < Mloc && ln < Mloc;
+      if (others_real && have && ip != in) {
+        const double tp = ct[lp], tn = ct[ln];
+        if (!(tp == 0.0 && tn == 0.0)) {   // capacity.jl:420-427
+          double lo[3], hi[3];
+          for (int k = 0; k < g.N; ++k) {
+            if (k == d) continue;
+            lo[k] = g.nodes[k][idx[k]];
+            hi[k] = g.nodes[k][idx[k] + 1];
+          }
+          lo[d] = Cw[d][lp];
+          hi[d] = Cw[d][ln];
+          int type;
+          pick_ball(bs, lo, hi, type);
+          if (type != PG_CUT && bs.complement) type = 1 - type;
+          bool degenerate = false;
+          for (int k = 0; k < g.N; ++k)
+            if (!(hi[k] - lo[k] > 0.0)) degenerate = true;
+          if (!degenerate) {
+            if (type == PG_FULL) w = prod_ext(lo, hi, g.N, -1);
+            else if (type == PG_CUT) {
+              const int slot = atomicAdd(wcount, 1);
+              if (slot < wcap) {
+                wlist[2 * slot] = (int)lc;
+                wlist[2 * slot + 1] = d;
+              }
+            }
+          }
+        }
+      }
+      W[d][lc] = w;
+    }
+  }
+}
+
+__global__ void k_stagger_cut(GeoView g, BallSet bs, const int* wlist, int nw, const double* Cw0,
+                              const double* Cw1, const double* Cw2, double* W0, double* W1, double* W2) {
+  const double* Cw[3] = {Cw0, Cw1, Cw2};
+  double* W[3] = {W0, W1, W2};
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nw) return;
+  const i64 lc = wlist[2 * k];
+  const int d = wlist[2 * k + 1];
+  i64 idx[3];
+  decode_cell(g.N, g.ext, g.plane, g.s0, lc, idx);
+  const i64 ip = idx[d] - 1 < 0 ? 0 : idx[d] - 1;
+  const i64 in = idx[d] < g.n[d] - 1 ? idx[d] : g.n[d] - 1;
+  const i64 lp = lc + (ip - idx[d]) * g.stride[d];
+  const i64 ln = lc + (in - idx[d]) * g.stride[d];
+  double lo[3], hi[3];
+  for (int q = 0; q < g.N; ++q) {
+    if (q == d) continue;
+    lo[q] = g.nodes[q][idx[q]];
+    hi[q] = g.nodes[q][idx[q] + 1];
+  }
+  lo[d] = Cw[d][lp];
+  hi[d] = Cw[d][ln];
+  W[d][lc] = box_measure(bs, lo, hi, false, c_gl).vol;
+}
+
+// per-plane count of non-empty cells (slab balancing weights)
+__global__ void k_plane_weights(GeoView g, BallSet bs, i64 plane_lo, i64 plane_hi, unsigned long long* weight) {
+  const i64 total = (plane_hi - plane_lo) * g.plane;
+  for (i64 q = blockIdx.x * (i64)blockDim.x + threadIdx.x; q < total; q += (i64)gridDim.x * blockDim.x) {
+    const i64 p = q / g.plane + plane_lo;
+    i64 rem = q % g.plane;
+    i64 idx[3] = {0, 0, 0};
+    for (int d = 0; d < g.N - 1; ++d) { idx[d] = rem % g.ext[d]; rem /= g.ext[d]; }
+    idx[g.N - 1] = p;
+    if (!is_real_cell(g, idx)) continue;
+    double lo[3], hi[3];
+    cell_box(g, idx, lo, hi);
+    int type;
+    pick_ball(bs, lo, hi, type);
+    if (type != PG_CUT && bs.complement) type = 1 - type;
+    if (type != PG_EMPTY) atomicAdd(&weight[p], type == PG_CUT ? 2ull : 1ull);
+  }
+}
+
+GeoView geo_view(pg_mesh* m, const Slab& s) {
+  GeoView g;
+  g.N = s.N;
+  for (int d = 0; d < 3; ++d) {
+    g.ext[d] = s.ext[d];
+    g.n[d] = s.n[d];
+    g.stride[d] = s.stride[d];
+    g.nodes[d] = nullptr;
+  }
+  g.plane = s.plane;
+  g.s0 = s.s0;
+  g.s1 = s.s1;
+  for (int d = 0; d < s.N; ++d) {
+    if (!m->d_nodes[d].p) {
+      m->d_nodes[d].alloc(m->n[d] + 1);
+      m->d_nodes[d].upload(m->nodes[d].data(), m->n[d] + 1);
+    }
+    g.nodes[d] = m->d_nodes[d].p;
+  }
+  return g;
+}
+
+void alloc_fields(pg_capacity* c) {
+  const i64 Ml = c->slab.Mloc();
+  PG_REQUIRE(Ml < (i64)2147483647, "capacity: local slab exceeds 2^31 cells");
+  c->V.alloc(Ml); c->G.alloc(Ml); c->ct.alloc(Ml);
+  for (int d = 0; d < c->N; ++d) {
+    c->A[d].alloc(Ml); c->B[d].alloc(Ml); c->W[d].alloc(Ml); c->Cw[d].alloc(Ml);
+    if (c->has_cg) c->Cg[d].alloc(Ml);
+  }
+}
+
+bool g_gl_uploaded = false;
+void ensure_gl() {
+  if (g_gl_uploaded) return;
+  GLTable t;
+  gl_init(t);
+  PG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_gl), &t, sizeof(t)));
+  g_gl_uploaded = true;
+}
+
+}  // namespace
+
+namespace pg {
+CapView cap_view(const pg_capacity* c) {
+  CapView v;
+  v.N = c->N;
+  for (int d = 0; d < 3; ++d) {
+    v.ext[d] = c->slab.ext[d];
+    v.n[d] = c->slab.n[d];
+    v.stride[d] = c->slab.stride[d];
+    v.A[d] = c->A[d].p;
+    v.B[d] = c->B[d].p;
+    v.W[d] = c->W[d].p;
+  }
+  v.plane = c->slab.plane;
+  v.s0 = c->slab.s0;
+  v.s1 = c->slab.s1;
+  v.nplanes = c->slab.nplanes;
+  v.V = c->V.p;
+  v.G = c->G.p;
+  return v;
+}
+}  // namespace pg
+
+extern "C" {
+
+int32_t pg_capacity_create_levelset(pg_mesh* m, int32_t body_kind, const double* params, int32_t nparams,
+                                    int32_t flags, pg_capacity** out) {
+  PG_API_BEGIN
+  require_init();
+  PG_REQUIRE(m && params && out, "pg_capacity_create_levelset: NULL argument");
+  Context& cx = ctx();
+  const int N = m->N;
+  BallSet bs;
+  std::memset(&bs, 0, sizeof(bs));
+  bs.N = N;
+  bs.complement = (flags & PG_FLAG_COMPLEMENT) ? 1 : 0;
+  if (body_kind == PG_BODY_BALL) {
+    PG_REQUIRE(nparams == N + 1, "PG_BODY_BALL expects params = {c_1..c_N, r}");
+    bs.nballs = 1;
+    for (int d = 0; d < N; ++d) bs.c[0][d] = params[d];
+    bs.r = params[N];
+  } else if (body_kind == PG_BODY_MULTIBALL) {
+    PG_REQUIRE(nparams >= 2, "PG_BODY_MULTIBALL expects params = {r, nballs, centres...}");
+    bs.r = params[0];
+    bs.nballs = (int)params[1];
+    PG_REQUIRE(bs.nballs >= 1 && bs.nballs <= MAX_BALLS, "PG_BODY_MULTIBALL: 1..16 balls");
+    PG_REQUIRE(nparams == 2 + bs.nballs * N, "PG_BODY_MULTIBALL: wrong parameter count");
+    PG_REQUIRE(!bs.complement, "PG_BODY_MULTIBALL: complement not supported");
+    for (int s = 0; s < bs.nballs; ++s)
+      for (int d = 0; d < N; ++d) bs.c[s][d] = params[2 + s * N + d];
+  } else {
+    throw Error("pg_capacity_create_levelset: unknown body kind (arbitrary bodies: use pg_capacity_create_from_arrays)");
+  }
+  PG_REQUIRE(bs.r > 0.0, "ball radius must be positive");
+
+  auto* c = new pg_capacity();
+  std::unique_ptr<pg_capacity> guard(c);
+  c->mesh = m;
+  c->N = N;
+  c->from_body = true;
+  c->has_cg = !(flags & PG_FLAG_NO_CENTROIDS);
+  c->body = bs;
+  c->slab = m->base_slab();
+  ensure_gl();
+  hipStream_t st = cx.stream;
+
+  // ---- slab partition balanced by non-empty cells per plane ----------------
+  if (cx.nranks > 1) {
+    const Slab& s = c->slab;
+    PG_REQUIRE(s.nplanes >= cx.nranks, "fewer planes than ranks");
+    GeoView g = geo_view(m, s);
+    DevBuf<unsigned long long> w(s.nplanes);
+    w.zero();
+    const i64 lo = s.nplanes * cx.rank / cx.nranks, hi = s.nplanes * (cx.rank + 1) / cx.nranks;
+    if (hi > lo)
+      hipLaunchKernelGGL(k_plane_weights, dim3(grid_for((hi - lo) * s.plane, 256)), dim3(256), 0, st, g, bs, lo, hi, w.p);
+    PG_HIP(hipGetLastError());
+    PG_NCCL(ncclAllReduce(w.p, w.p, s.nplanes, ncclUint64, ncclSum, cx.comm, st));
+    std::vector<unsigned long long> hw(s.nplanes);
+    w.download(hw.data(), s.nplanes);
+    std::vector<i64> wt(hw.begin(), hw.end()), bounds(cx.nranks + 1);
+    PG_REQUIRE(pg_partition_planes(wt.data(), s.nplanes, cx.nranks, bounds.data()) == 0, "partition failed");
+    c->slab.set_own(bounds[cx.rank], bounds[cx.rank + 1]);
+  }
+
+  alloc_fields(c);
+  const Slab& s = c->slab;
+  const i64 Ml = s.Mloc();
+  GeoView g = geo_view(m, s);
+  DevBuf<int> cut_list(Ml), counters(2);
+  DevBuf<int> wlist;
+  counters.zero();
+  hipEvent_t e0, e1;
+  PG_HIP(hipEventCreate(&e0));
+  PG_HIP(hipEventCreate(&e1));
+  PG_HIP(hipEventRecord(e0, st));
+  const int gr = grid_for(Ml, 256, 256 * 16);
+  hipLaunchKernelGGL(k_classify, dim3(gr), dim3(256), 0, st, g, bs, Ml, c->V.p, c->G.p, c->ct.p, c->Cw[0].p,
+                     c->Cw[1].p, c->Cw[2].p, c->Cg[0].p, c->Cg[1].p, c->Cg[2].p, cut_list.p, counters.p);
+  PG_HIP(hipGetLastError());
+  int hc[2];
+  counters.download(hc, 2);
+  const int ncut = hc[0];
+  c->n_cut_local = ncut;
+  if (ncut > 0) {
+    hipLaunchKernelGGL(k_cut_cells, dim3((ncut + 63) / 64), dim3(64), 0, st, g, bs, cut_list.p, ncut, c->V.p, c->G.p,
+                       c->Cw[0].p, c->Cw[1].p, c->Cw[2].p, c->Cg[0].p, c->Cg[1].p, c->Cg[2].p);
+    PG_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_sections, dim3(gr), dim3(256), 0, st, g, bs, Ml, c->Cw[0].p, c->Cw[1].p, c->Cw[2].p, c->A[0].p,
+                     c->A[1].p, c->A[2].p, c->B[0].p, c->B[1].p, c->B[2].p);
+  PG_HIP(hipGetLastError());
+  // W work list: at most N entries per cut-adjacent cell; bound by 2*N*ncut + slack
+  const i64 wcap = std::min<i64>((i64)N * Ml, (i64)4 * N * (i64)ncut + 1024);
+  wlist.alloc(2 * wcap);
+  hipLaunchKernelGGL(k_stagger, dim3(gr), dim3(256), 0, st, g, bs, Ml, c->ct.p, c->Cw[0].p, c->Cw[1].p, c->Cw[2].p,
+                     c->W[0].p, c->W[1].p, c->W[2].p, wlist.p, counters.p + 1, (int)wcap);
+  PG_HIP(hipGetLastError());
+  counters.download(hc, 2);
+  const int nw = hc[1];
+  PG_REQUIRE(nw <= wcap, "internal: staggered-volume work list overflow");
+  if (nw > 0) {
+    hipLaunchKernelGGL(k_stagger_cut, dim3((nw + 63) / 64), dim3(64), 0, st, g, bs, wlist.p, nw, c->Cw[0].p, c->Cw[1].p,
+                       c->Cw[2].p, c->W[0].p, c->W[1].p, c->W[2].p);
+    PG_HIP(hipGetLastError());
+  }
+  PG_HIP(hipEventRecord(e1, st));
+  PG_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  PG_HIP(hipEventElapsedTime(&ms, e0, e1));
+  c->kernel_ms = ms;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *out = guard.release();
+  PG_API_END
+}
+
+int32_t pg_capacity_create_from_arrays(pg_mesh* m, const double* V, const double* const* A, const double* const* B,
+                                       const double* const* W, const double* Gamma, const double* const* C_omega,
+                                       const double* const* C_gamma, const double* cell_types, pg_capacity** out) {
+  PG_API_BEGIN
+  require_init();
+  PG_REQUIRE(m && V && A && B && W && Gamma && C_omega && cell_types && out, "pg_capacity_create_from_arrays: NULL argument");
+  PG_REQUIRE(ctx().nranks == 1, "pg_capacity_create_from_arrays: single rank only");
+  auto* c = new pg_capacity();
+  std::unique_ptr<pg_capacity> guard(c);
+  c->mesh = m;
+  c->N = m->N;
+  c->from_body = false;
+  c->has_cg = C_gamma != nullptr;
+  c->slab = m->base_slab();
+  alloc_fields(c);
+  const i64 M = c->slab.M;
+  c->V.upload(V, M);
+  c->G.upload(Gamma, M);
+  c->ct.upload(cell_types, M);
+  for (int d = 0; d < c->N; ++d) {
+    c->A[d].upload(A[d], M);
+    c->B[d].upload(B[d], M);
+    c->W[d].upload(W[d], M);
+    c->Cw[d].upload(C_omega[d], M);
+    if (c->has_cg) c->Cg[d].upload(C_gamma[d], M);
+  }
+  *out = guard.release();
+  PG_API_END
+}
+
+int32_t pg_capacity_destroy(pg_capacity* c) {
+  PG_API_BEGIN
+  delete c;
+  PG_API_END
+}
+
+int32_t pg_capacity_get(const pg_capacity* c, int32_t field, int32_t d, double* out, int64_t len) {
+  PG_API_BEGIN
+  require_init();
+  PG_REQUIRE(c && out, "pg_capacity_get: NULL argument");
+  PG_REQUIRE(len == c->slab.M, "pg_capacity_get: len must be prod(n_d+1)");
+  const DevBuf<double>* src = nullptr;
+  switch (field) {
+    case PG_CAP_V: src = &c->V; break;
+    case PG_CAP_GAMMA: src = &c->G; break;
+    case PG_CAP_CELL_TYPES: src = &c->ct; break;
+    case PG_CAP_A: case PG_CAP_B: case PG_CAP_W: case PG_CAP_C_OMEGA: case PG_CAP_C_GAMMA:
+      PG_REQUIRE(d >= 0 && d < c->N, "pg_capacity_get: bad dimension");
+      src = field == PG_CAP_A ? &c->A[d] : field == PG_CAP_B ? &c->B[d] : field == PG_CAP_W ? &c->W[d]
+          : field == PG_CAP_C_OMEGA ? &c->Cw[d] : &c->Cg[d];
+      break;
+    default: throw Error("pg_capacity_get: unknown field");
+  }
+  PG_REQUIRE(src->p != nullptr, "pg_capacity_get: field not available (centroids disabled?)");
+  src->download(out + c->slab.first_cell(), c->slab.Mloc());
+  PG_API_END
+}
+
+int32_t pg_capacity_kernel_ms(const pg_capacity* c, double* ms) {
+  PG_API_BEGIN
+  PG_REQUIRE(c && ms, "pg_capacity_kernel_ms: NULL argument");
+  *ms = c->kernel_ms;
+  PG_API_END
+}
+
+int32_t pg_diffops_create(pg_capacity* c, pg_diffops** out) {
+  PG_API_BEGIN
+  PG_REQUIRE(c && out, "pg_diffops_create: NULL argument");
+  auto* o = new pg_diffops();
+  o->cap = c;
+  *out = o;
+  PG_API_END
+}
+
+int32_t pg_diffops_destroy(pg_diffops* o) {
+  PG_API_BEGIN
+  delete o;
+  PG_API_END
+}
+
+}  // extern "C"

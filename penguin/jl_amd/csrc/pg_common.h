@@ -1,0 +1,184 @@
+// pg_common.h -- shared internals of libpenguin_hip.so (gfx950 only; no CUDA paths, no shims).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/penguin_hip.h"
+
+namespace pg {
+
+using i64 = int64_t;
+using i32 = int32_t;
+
+struct Error : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+void set_last_error(const std::string& msg);
+
+#define PG_HIP(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess)                                                                         \
+      throw pg::Error(std::string("HIP error: ") + hipGetErrorString(_e) + " at " + __FILE__ + ":" + \
+                      std::to_string(__LINE__) + " (" #expr ")");                                 \
+  } while (0)
+
+#define PG_NCCL(expr)                                                                             \
+  do {                                                                                            \
+    ncclResult_t _e = (expr);                                                                     \
+    if (_e != ncclSuccess)                                                                        \
+      throw pg::Error(std::string("RCCL error: ") + ncclGetErrorString(_e) + " at " + __FILE__ + ":" + \
+                      std::to_string(__LINE__) + " (" #expr ")");                                 \
+  } while (0)
+
+#define PG_REQUIRE(cond, msg)                                   \
+  do {                                                          \
+    if (!(cond)) throw pg::Error(std::string(msg));             \
+  } while (0)
+
+// every extern "C" entry point is wrapped:  PG_API_BEGIN ... PG_API_END
+#define PG_API_BEGIN try {
+#define PG_API_END                                  \
+  return 0;                                         \
+  }                                                 \
+  catch (const std::exception& e) {                 \
+    pg::set_last_error(e.what());                   \
+    return 1;                                       \
+  }                                                 \
+  catch (...) {                                     \
+    pg::set_last_error("unknown exception");        \
+    return 2;                                       \
+  }
+
+struct Context {
+  bool inited = false;
+  int device = 0;
+  hipStream_t stream = nullptr;      // compute stream: every kernel of the path runs here
+  hipStream_t comm_stream = nullptr; // halo exchange stream (overlaps interior SpMV rows)
+  int rank = 0, nranks = 1;
+  ncclComm_t comm = nullptr;
+  bool profiling = false;
+  std::string device_name;
+};
+Context& ctx();
+void require_init();
+
+// ---- device buffer -------------------------------------------------------------------------
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  i64 n = 0;
+  DevBuf() = default;
+  explicit DevBuf(i64 n_) { alloc(n_); }
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept {
+    if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+    return *this;
+  }
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr; n = 0;
+  }
+  void alloc(i64 n_) {
+    release();
+    n = n_;
+    if (n > 0) PG_HIP(hipMalloc(reinterpret_cast<void**>(&p), sizeof(T) * static_cast<size_t>(n)));
+  }
+  void zero() {
+    if (n > 0) PG_HIP(hipMemsetAsync(p, 0, sizeof(T) * static_cast<size_t>(n), ctx().stream));
+  }
+  void upload(const T* h, i64 count, i64 offset = 0) {
+    if (count > 0) {
+      PG_HIP(hipMemcpyAsync(p + offset, h, sizeof(T) * static_cast<size_t>(count), hipMemcpyHostToDevice, ctx().stream));
+      PG_HIP(hipStreamSynchronize(ctx().stream));
+    }
+  }
+  void download(T* h, i64 count, i64 offset = 0) const {
+    if (count > 0) {
+      PG_HIP(hipMemcpyAsync(h, p + offset, sizeof(T) * static_cast<size_t>(count), hipMemcpyDeviceToHost, ctx().stream));
+      PG_HIP(hipStreamSynchronize(ctx().stream));
+    }
+  }
+};
+
+inline int grid_for(i64 n, int block, int cap = 256 * 8) {
+  i64 g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return static_cast<int>(g);
+}
+
+// ---- slab of the padded grid owned / stored by this rank --------------------------------------
+// The padded grid has ext[d] = n_d + 1 nodes per dimension (d < N), linear index dim-0 fastest.
+// The slowest dimension (N-1) is cut into planes; a rank owns planes [p0,p1) and stores planes
+// [s0,s1) = [p0-HALO, p1+HALO) ∩ [0,nplanes) so that every stencil / active-set decision for its
+// owned rows and its one ghost plane each side can be taken locally (capacities are pure functions
+// of position: ghost planes are recomputed, never communicated).
+constexpr int CAP_HALO = 3;
+
+struct Slab {
+  int N = 0;
+  i64 n[3] = {1, 1, 1};     // cells per dim
+  i64 ext[3] = {1, 1, 1};   // n+1 for d<N, 1 otherwise
+  i64 stride[3] = {1, 1, 1};
+  i64 plane = 1;            // cells per plane of the slowest dim
+  i64 nplanes = 1;          // ext[N-1]
+  i64 M = 1;                // global padded size
+  i64 p0 = 0, p1 = 1;       // owned planes
+  i64 s0 = 0, s1 = 1;       // stored planes
+  i64 Mloc() const { return (s1 - s0) * plane; }
+  i64 first_cell() const { return s0 * plane; }  // global linear index of local cell 0
+  void set_own(i64 a, i64 b) {
+    p0 = a; p1 = b;
+    s0 = p0 - CAP_HALO; if (s0 < 0) s0 = 0;
+    s1 = p1 + CAP_HALO; if (s1 > nplanes) s1 = nplanes;
+  }
+};
+
+}  // namespace pg
+
+// ---- opaque handle definitions -------------------------------------------------------------
+struct pg_mesh {
+  int N = 0;
+  pg::i64 n[3] = {1, 1, 1};
+  double L[3] = {0, 0, 0};
+  double x0[3] = {0, 0, 0};
+  std::vector<double> centers[3];
+  std::vector<double> nodes[3];
+  // border cells, reference order (src/mesh.jl:57-74 + unique!): built lazily
+  bool border_built = false;
+  std::vector<pg::i64> border_idx;   // nb*N, 1-based
+  std::vector<double> border_pos;    // nb*N
+  std::vector<pg::i32> border_key;   // nb
+  pg::DevBuf<double> d_nodes[3];     // device copies of the node coordinates
+  pg::Slab base_slab() const;
+};
+
+namespace pg {
+void mesh_build_border(pg_mesh* m);
+// classify_boundary_cell_fast, src/solver.jl:379-409, 0-based cell indices, returns PG_KEY_* or -1
+__host__ __device__ inline int border_key_of(int N, const i64* n, i64 i0, i64 i1, i64 i2) {
+  if (N >= 2) {
+    if (i1 == 0) return PG_KEY_LEFT;
+    if (i1 == n[1] - 1) return PG_KEY_RIGHT;
+  }
+  if (i0 == 0) return PG_KEY_BOTTOM;
+  if (i0 == n[0] - 1) return PG_KEY_TOP;
+  if (N >= 3) {
+    if (i2 == 0) return PG_KEY_BACKWARD;
+    if (i2 == n[2] - 1) return PG_KEY_FORWARD;
+  }
+  return -1;
+}
+}  // namespace pg

@@ -1,0 +1,34 @@
+// pg_krylov.h -- K11: Krylov solve of the reduced system on one slab (BiCGStab / CG).
+#pragma once
+#include "pg_system.h"
+
+namespace pg {
+
+struct KrylovWork {
+  i64 n = 0, nvec = 0;
+  DevBuf<double> r, rhat, p, v, s, t;   // n_vec each (p and s carry ghost entries)
+  DevBuf<double> partials;              // per-block partial sums, 4 slots x grid
+  DevBuf<double> sc;                    // device scalars (see pg_krylov.hip)
+  double* h_sc = nullptr;               // pinned host mirror of sc
+  int grid = 1;
+  void init(i64 n_own, i64 n_vec);
+  ~KrylovWork();
+};
+
+struct SolveStats {
+  int iters = 0;
+  int converged = 0;
+  double resnorm = 0.0, bnorm = 0.0;
+  double spmv_ms = 0.0;
+  i64 spmv_launches = 0;
+};
+
+// halo exchange of the ghost segments of `vec` (no-op on one rank)
+void halo_exchange(const Numbering& nb, const Slab& slab, double* vec, hipStream_t st);
+// y[0..n) = A * x   (x must hold valid ghosts)
+void spmv(const CsrMatrix& A, const double* x, double* y, hipStream_t st);
+// x (n_vec, overwritten; zero initial guess) = A^{-1} b
+void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, const double* b, double* x,
+                  KrylovWork& w, const pg_krylov_opts& opts, SolveStats& stats);
+
+}  // namespace pg

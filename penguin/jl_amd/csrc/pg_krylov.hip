@@ -1,0 +1,439 @@
+// pg_krylov.hip -- K11 of SURVEY.md section 2.3: the Krylov inner loop of solve_system! (src/solver.jl:158-188)
+//
+//   reference (IterativeSolvers 0.9.4, single thread)          here
+//   CSC mul!                                                   k_spmv: CSR row blocks staged through LDS
+//   dot / axpy! / norm (OpenBLAS BLAS-1)                       fused update+dot kernels, wave64 reductions
+//   method(A_reduced, b_reduced; kwargs...)                    device-resident BiCGStab / CG: all scalars stay
+//                                                              on the GPU, the host polls a done flag every
+//                                                              `check_every` iterations (no per-iteration sync)
+//
+// SpMV design (CDNA4): a 256-thread block owns 256 consecutive rows.  Their val/col entries are one
+// contiguous range of the CSR arrays, streamed into LDS with fully coalesced loads (the matrix is read
+// exactly once: 12 B/nnz); then thread t walks row t out of LDS and gathers x[col].  Because rows are in
+// box order, for a fixed stencil slot consecutive threads read consecutive x entries, so the gathers
+// coalesce and hit L2 / Infinity Cache (x = 8 B x n fits the 256 MB MALL at 512^3).  The dots that follow
+// an SpMV in BiCGStab / CG are fused into its epilogue.
+#include "pg_krylov.h"
+
+using namespace pg;
+
+namespace {
+
+enum { S_RHO = 0, S_RHO_OLD, S_ALPHA, S_OMEGA, S_BETA, S_RR, S_BB, S_TOL2, S_DONE, S_ITERS, S_RELTOL2, S_ABSTOL2,
+       S_RED0, S_RED1, S_RED2, S_RED3, S_COUNT };
+enum { PH_INIT = 0, PH_BICG_1, PH_BICG_2, PH_BICG_3, PH_CG_INIT, PH_CG_1, PH_CG_2 };
+
+constexpr int BLOCK = 256;
+constexpr int SPMV_ROWS = 256;          // rows per block iteration
+constexpr int SPMV_LDS_ENTRIES = 3584;  // 256 rows x 14 entries (max row: 2*(2N+1) in 3-D)
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// sum over the block; result valid in thread 0
+__device__ inline double block_sum(double v, double* sh /*BLOCK/64*/) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  double s = 0.0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) s += sh[w];
+  }
+  return s;
+}
+
+// ---- SpMV ---------------------------------------------------------------------------------------
+// MODE 0: y = A x.  MODE 1: + partial[0] = aux . y.  MODE 2: + partial[0] = y . x, partial[1] = y . y
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_spmv(i64 n, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                const double* __restrict__ val, const double* __restrict__ x,
+                                                double* __restrict__ y, const double* __restrict__ aux,
+                                                double* __restrict__ partials, const double* __restrict__ sc) {
+  __shared__ double s_val[SPMV_LDS_ENTRIES];
+  __shared__ int s_col[SPMV_LDS_ENTRIES];
+  __shared__ double s_red[BLOCK / 64];
+  if (sc && sc[S_DONE] != 0.0) return;
+  double acc0 = 0.0, acc1 = 0.0;
+  const i64 nchunks = (n + SPMV_ROWS - 1) / SPMV_ROWS;
+  for (i64 chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const i64 r0 = chunk * SPMV_ROWS;
+    const i64 r1 = r0 + SPMV_ROWS < n ? r0 + SPMV_ROWS : n;
+    const int base = rowptr[r0];
+    const int cnt = rowptr[r1] - base;
+    const i64 r = r0 + threadIdx.x;
+    int a = 0, b = 0;
+    if (r < r1) {
+      a = rowptr[r] - base;
+      b = rowptr[r + 1] - base;
+    }
+    double sum = 0.0;
+    if (cnt <= SPMV_LDS_ENTRIES) {
+      for (int k = threadIdx.x; k < cnt; k += BLOCK) {
+        s_val[k] = val[base + k];
+        s_col[k] = col[base + k];
+      }
+      __syncthreads();
+      for (int k = a; k < b; ++k) sum += s_val[k] * x[s_col[k]];
+      __syncthreads();
+    } else {
+      // rows longer than the stencil bound (never for this path's systems): direct CSR walk
+      for (int k = a; k < b; ++k) sum += val[base + k] * x[col[base + k]];
+    }
+    if (r < r1) {
+      y[r] = sum;
+      if (MODE == 1) acc0 += aux[r] * sum;
+      if (MODE == 2) {
+        acc0 += sum * x[r];
+        acc1 += sum * sum;
+      }
+    }
+  }
+  if (MODE >= 1) {
+    const double t0 = block_sum(acc0, s_red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t0;
+  }
+  if (MODE == 2) {
+    const double t1 = block_sum(acc1, s_red);
+    if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = t1;
+  }
+}
+
+// ---- fused vector kernels ---------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_bicg_init(i64 n, i64 nvec, const double* __restrict__ b, double* __restrict__ x,
+                                                     double* __restrict__ r, double* __restrict__ rhat,
+                                                     double* __restrict__ p, double* __restrict__ v,
+                                                     double* __restrict__ partials) {
+  __shared__ double s_red[BLOCK / 64];
+  double acc = 0.0;
+  for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < nvec; i += (i64)gridDim.x * BLOCK) {
+    if (i < n) {
+      const double bi = b[i];
+      x[i] = 0.0; r[i] = bi; rhat[i] = bi; p[i] = 0.0; v[i] = 0.0;
+      acc += bi * bi;
+    } else {
+      x[i] = 0.0; p[i] = 0.0;
+    }
+  }
+  const double t = block_sum(acc, s_red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_bicg_p(i64 n, const double* __restrict__ sc, const double* __restrict__ r,
+                                                  const double* __restrict__ v, double* __restrict__ p) {
+  if (sc[S_DONE] != 0.0) return;
+  const double beta = sc[S_BETA], omega = sc[S_OMEGA];
+  for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK)
+    p[i] = r[i] + beta * (p[i] - omega * v[i]);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_bicg_s(i64 n, const double* __restrict__ sc, const double* __restrict__ r,
+                                                  const double* __restrict__ v, double* __restrict__ s) {
+  if (sc[S_DONE] != 0.0) return;
+  const double alpha = sc[S_ALPHA];
+  for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) s[i] = r[i] - alpha * v[i];
+}
+
+__global__ __launch_bounds__(BLOCK) void k_bicg_xr(i64 n, const double* __restrict__ sc, const double* __restrict__ p,
+                                                   const double* __restrict__ s, const double* __restrict__ t,
+                                                   const double* __restrict__ rhat, double* __restrict__ x,
+                                                   double* __restrict__ r, double* __restrict__ partials) {
+  __shared__ double s_red[BLOCK / 64];
+  if (sc[S_DONE] != 0.0) return;
+  const double alpha = sc[S_ALPHA], omega = sc[S_OMEGA];
+  double a0 = 0.0, a1 = 0.0;
+  for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) {
+    const double si = s[i];
+    x[i] = x[i] + alpha * p[i] + omega * si;
+    const double ri = si - omega * t[i];
+    r[i] = ri;
+    a0 += rhat[i] * ri;
+    a1 += ri * ri;
+  }
+  const double t0 = block_sum(a0, s_red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t0;
+  const double t1 = block_sum(a1, s_red);
+  if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = t1;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_cg_init(i64 n, i64 nvec, const double* __restrict__ b, double* __restrict__ x,
+                                                   double* __restrict__ r, double* __restrict__ p,
+                                                   double* __restrict__ partials) {
+  __shared__ double s_red[BLOCK / 64];
+  double acc = 0.0;
+  for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < nvec; i += (i64)gridDim.x * BLOCK) {
+    if (i < n) {
+      const double bi = b[i];
+      x[i] = 0.0; r[i] = bi; p[i] = bi;
+      acc += bi * bi;
+    } else {
+      x[i] = 0.0; p[i] = 0.0;
+    }
+  }
+  const double t = block_sum(acc, s_red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_cg_xr(i64 n, const double* __restrict__ sc, const double* __restrict__ p,
+                                                 const double* __restrict__ q, double* __restrict__ x,
+                                                 double* __restrict__ r, double* __restrict__ partials) {
+  __shared__ double s_red[BLOCK / 64];
+  if (sc[S_DONE] != 0.0) return;
+  const double alpha = sc[S_ALPHA];
+  double a0 = 0.0;
+  for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) {
+    x[i] += alpha * p[i];
+    const double ri = r[i] - alpha * q[i];
+    r[i] = ri;
+    a0 += ri * ri;
+  }
+  const double t0 = block_sum(a0, s_red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t0;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_cg_p(i64 n, const double* __restrict__ sc, const double* __restrict__ r,
+                                                double* __restrict__ p) {
+  if (sc[S_DONE] != 0.0) return;
+  const double beta = sc[S_BETA];
+  for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) p[i] = r[i] + beta * p[i];
+}
+
+// ---- scalar phase: sum block partials (deterministic order), then derive the iteration scalars ----
+__device__ inline void derive(int phase, double* sc) {
+  const double r0 = sc[S_RED0], r1 = sc[S_RED1];
+  switch (phase) {
+    case PH_INIT:
+    case PH_CG_INIT: {
+      sc[S_BB] = r0; sc[S_RR] = r0; sc[S_RHO] = r0; sc[S_RHO_OLD] = 1.0;
+      sc[S_ALPHA] = 1.0; sc[S_OMEGA] = 1.0; sc[S_BETA] = 0.0; sc[S_ITERS] = 0.0;
+      const double t2 = sc[S_RELTOL2] * r0;
+      sc[S_TOL2] = t2 > sc[S_ABSTOL2] ? t2 : sc[S_ABSTOL2];
+      sc[S_DONE] = (r0 <= sc[S_TOL2]) ? 1.0 : 0.0;
+      break;
+    }
+    case PH_BICG_1:
+      if (r0 == 0.0) sc[S_DONE] = 2.0; else sc[S_ALPHA] = sc[S_RHO] / r0;
+      break;
+    case PH_BICG_2:
+      sc[S_OMEGA] = r1 != 0.0 ? r0 / r1 : 0.0;
+      break;
+    case PH_BICG_3: {
+      const double rho_old = sc[S_RHO];
+      sc[S_RHO_OLD] = rho_old;
+      sc[S_RHO] = r0;
+      sc[S_RR] = r1;
+      sc[S_ITERS] += 1.0;
+      if (r1 <= sc[S_TOL2]) sc[S_DONE] = 1.0;
+      else if (sc[S_OMEGA] == 0.0 || r0 == 0.0) sc[S_DONE] = 2.0;
+      else sc[S_BETA] = (r0 / rho_old) * (sc[S_ALPHA] / sc[S_OMEGA]);
+      break;
+    }
+    case PH_CG_1:
+      if (r0 == 0.0) sc[S_DONE] = 2.0; else sc[S_ALPHA] = sc[S_RR] / r0;
+      break;
+    case PH_CG_2: {
+      const double rr_old = sc[S_RR];
+      sc[S_RR] = r0;
+      sc[S_ITERS] += 1.0;
+      if (r0 <= sc[S_TOL2]) sc[S_DONE] = 1.0;
+      else sc[S_BETA] = r0 / rr_old;
+      break;
+    }
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_finalize(int phase, int nslots, int grid, const double* __restrict__ partials,
+                                                    double* __restrict__ sc, int do_derive, int check_done) {
+  __shared__ double s_red[BLOCK / 64];
+  if (check_done && sc[S_DONE] != 0.0) return;
+  for (int s = 0; s < nslots; ++s) {
+    double a = 0.0;
+    for (int i = threadIdx.x; i < grid; i += BLOCK) a += partials[s * grid + i];
+    const double t = block_sum(a, s_red);
+    if (threadIdx.x == 0) sc[S_RED0 + s] = t;
+  }
+  if (do_derive && threadIdx.x == 0) derive(phase, sc);
+}
+
+__global__ void k_derive(int phase, double* sc, int check_done) {
+  if (check_done && sc[S_DONE] != 0.0) return;
+  derive(phase, sc);
+}
+
+void finalize(int phase, int nslots, KrylovWork& w, hipStream_t st, bool check_done) {
+  Context& cx = ctx();
+  if (cx.nranks == 1) {
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, st, phase, nslots, w.grid, w.partials.p, w.sc.p, 1,
+                       check_done ? 1 : 0);
+  } else {
+    // local sums -> RCCL all-reduce of <=2 doubles over xGMI -> identical scalars on every rank
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, st, phase, nslots, w.grid, w.partials.p, w.sc.p, 0,
+                       check_done ? 1 : 0);
+    PG_NCCL(ncclAllReduce(w.sc.p + S_RED0, w.sc.p + S_RED0, nslots, ncclDouble, ncclSum, cx.comm, st));
+    hipLaunchKernelGGL(k_derive, dim3(1), dim3(1), 0, st, phase, w.sc.p, check_done ? 1 : 0);
+  }
+}
+
+template <int MODE>
+void launch_spmv(const CsrMatrix& A, const double* x, double* y, const double* aux, double* partials, const double* sc,
+                 int grid, hipStream_t st) {
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv<MODE>), dim3(grid), dim3(BLOCK), 0, st, A.n, A.rowptr.p, A.col.p, A.val.p, x, y,
+                     aux, partials, sc);
+}
+
+struct SpmvTimer {
+  bool on;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs;
+  explicit SpmvTimer(bool on_) : on(on_) {}
+  void begin(hipStream_t st) {
+    if (!on) return;
+    PG_HIP(hipEventCreate(&e0));
+    PG_HIP(hipEventCreate(&e1));
+    PG_HIP(hipEventRecord(e0, st));
+  }
+  void end(hipStream_t st) {
+    if (!on) return;
+    PG_HIP(hipEventRecord(e1, st));
+    pairs.emplace_back(e0, e1);
+  }
+  void collect(SolveStats& s) {
+    for (auto& pr : pairs) {
+      float ms = 0.f;
+      (void)hipEventSynchronize(pr.second);
+      if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) s.spmv_ms += ms;
+      s.spmv_launches += 1;
+      (void)hipEventDestroy(pr.first);
+      (void)hipEventDestroy(pr.second);
+    }
+    pairs.clear();
+  }
+};
+
+}  // namespace
+
+namespace pg {
+
+void KrylovWork::init(i64 n_own, i64 n_vec) {
+  n = n_own;
+  nvec = n_vec;
+  const i64 a = n_vec > 0 ? n_vec : 1;
+  r.alloc(a); rhat.alloc(a); p.alloc(a); v.alloc(a); s.alloc(a); t.alloc(a);
+  grid = grid_for(n_own, BLOCK, 256 * 8);
+  partials.alloc(4 * (i64)grid);
+  sc.alloc(S_COUNT);
+  sc.zero();
+  if (!h_sc) PG_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_sc), sizeof(double) * S_COUNT));
+}
+
+KrylovWork::~KrylovWork() {
+  if (h_sc) (void)hipHostFree(h_sc);
+}
+
+void halo_exchange(const Numbering& nb, const Slab& slab, double* vec, hipStream_t st) {
+  Context& cx = ctx();
+  if (cx.nranks == 1) return;
+  const bool has_lo = slab.p0 > 0, has_hi = slab.p1 < slab.nplanes;
+  // neighbours in rank order: ranks own increasing plane ranges
+  PG_NCCL(ncclGroupStart());
+  for (int k = 0; k < nb.K; ++k) {
+    if (has_lo) {
+      if (nb.sendL_cnt[k] > 0) PG_NCCL(ncclSend(vec + nb.sendL_off[k], nb.sendL_cnt[k], ncclDouble, cx.rank - 1, cx.comm, st));
+      if (nb.cntL[k] > 0) PG_NCCL(ncclRecv(vec + nb.offL[k], nb.cntL[k], ncclDouble, cx.rank - 1, cx.comm, st));
+    }
+    if (has_hi) {
+      if (nb.sendU_cnt[k] > 0) PG_NCCL(ncclSend(vec + nb.sendU_off[k], nb.sendU_cnt[k], ncclDouble, cx.rank + 1, cx.comm, st));
+      if (nb.cntU[k] > 0) PG_NCCL(ncclRecv(vec + nb.offU[k], nb.cntU[k], ncclDouble, cx.rank + 1, cx.comm, st));
+    }
+  }
+  PG_NCCL(ncclGroupEnd());
+}
+
+void spmv(const CsrMatrix& A, const double* x, double* y, hipStream_t st) {
+  if (A.n == 0) return;
+  launch_spmv<0>(A, x, y, nullptr, nullptr, nullptr, grid_for(A.n, BLOCK, 256 * 8), st);
+  PG_HIP(hipGetLastError());
+}
+
+void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, const double* b, double* x, KrylovWork& w,
+                  const pg_krylov_opts& opts, SolveStats& stats) {
+  Context& cx = ctx();
+  hipStream_t st = cx.stream;
+  const i64 n = A.n, nvec = nb.n_vec();
+  PG_REQUIRE(w.n == n && w.nvec == nvec, "krylov workspace size mismatch");
+  const int G = w.grid;
+  const int check_every = opts.check_every > 0 ? opts.check_every : 4;
+  int maxiter = opts.maxiter;
+  if (maxiter <= 0) {
+    // IterativeSolvers default: size of the system (global)
+    maxiter = 100000;
+  }
+  // tolerances -> device scalars
+  double hs[S_COUNT];
+  std::memset(hs, 0, sizeof(hs));
+  hs[S_RELTOL2] = opts.reltol * opts.reltol;
+  hs[S_ABSTOL2] = opts.abstol * opts.abstol;
+  PG_HIP(hipMemcpyAsync(w.sc.p, hs, sizeof(hs), hipMemcpyHostToDevice, st));
+  SpmvTimer timer(cx.profiling);
+
+  const bool cg = opts.method == PG_METHOD_CG;
+  if (!cg) {
+    hipLaunchKernelGGL(k_bicg_init, dim3(G), dim3(BLOCK), 0, st, n, nvec, b, x, w.r.p, w.rhat.p, w.p.p, w.v.p, w.partials.p);
+    finalize(PH_INIT, 1, w, st, false);
+  } else {
+    hipLaunchKernelGGL(k_cg_init, dim3(G), dim3(BLOCK), 0, st, n, nvec, b, x, w.r.p, w.p.p, w.partials.p);
+    finalize(PH_CG_INIT, 1, w, st, false);
+  }
+  PG_HIP(hipGetLastError());
+
+  int launched = 0;
+  bool done = false;
+  while (!done) {
+    const int batch = std::min(check_every, maxiter - launched);
+    for (int it = 0; it < batch; ++it) {
+      if (!cg) {
+        hipLaunchKernelGGL(k_bicg_p, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.r.p, w.v.p, w.p.p);
+        halo_exchange(nb, slab, w.p.p, st);
+        timer.begin(st);
+        launch_spmv<1>(A, w.p.p, w.v.p, w.rhat.p, w.partials.p, w.sc.p, G, st);
+        timer.end(st);
+        finalize(PH_BICG_1, 1, w, st, true);
+        hipLaunchKernelGGL(k_bicg_s, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.r.p, w.v.p, w.s.p);
+        halo_exchange(nb, slab, w.s.p, st);
+        timer.begin(st);
+        launch_spmv<2>(A, w.s.p, w.t.p, nullptr, w.partials.p, w.sc.p, G, st);
+        timer.end(st);
+        finalize(PH_BICG_2, 2, w, st, true);
+        hipLaunchKernelGGL(k_bicg_xr, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.p.p, w.s.p, w.t.p, w.rhat.p, x, w.r.p,
+                           w.partials.p);
+        finalize(PH_BICG_3, 2, w, st, true);
+      } else {
+        halo_exchange(nb, slab, w.p.p, st);
+        timer.begin(st);
+        launch_spmv<2>(A, w.p.p, w.v.p, nullptr, w.partials.p, w.sc.p, G, st);   // v = A p ; (v.p), (v.v)
+        timer.end(st);
+        finalize(PH_CG_1, 1, w, st, true);
+        hipLaunchKernelGGL(k_cg_xr, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.p.p, w.v.p, x, w.r.p, w.partials.p);
+        finalize(PH_CG_2, 1, w, st, true);
+        hipLaunchKernelGGL(k_cg_p, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.r.p, w.p.p);
+      }
+    }
+    PG_HIP(hipGetLastError());
+    launched += batch;
+    PG_HIP(hipMemcpyAsync(w.h_sc, w.sc.p, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, st));
+    PG_HIP(hipStreamSynchronize(st));
+    if (w.h_sc[S_DONE] != 0.0 || launched >= maxiter) done = true;
+  }
+  stats.iters = (int)w.h_sc[S_ITERS];
+  stats.converged = w.h_sc[S_DONE] == 1.0 ? 1 : 0;
+  stats.resnorm = std::sqrt(w.h_sc[S_RR]);
+  stats.bnorm = std::sqrt(w.h_sc[S_BB]);
+  timer.collect(stats);
+}
+
+}  // namespace pg

@@ -1,0 +1,736 @@
+// pg_solver.hip -- Solver / DiffusionUnsteadyMono / DiffusionUnsteadyDiph and their time loops
+//
+//   reference                                                        here
+//   DiffusionUnsteadyMono ctor               diffusion.jl:192-210     pg_solver_create_unsteady_mono
+//   DiffusionUnsteadyDiph ctor               diffusion.jl:319-332     pg_solver_create_unsteady_diph
+//   b_mono_unstead_diff / b_diph_unstead_diff diffusion.jl:243-265,391-420   k_row_static + k_bconst + k_rhs (K8)
+//   solve_DiffusionUnsteadyMono!/Diph!       diffusion.jl:268-301,422-454    pg_solver_initial_solve / _step / _run
+//   s.x = zeros(n); s.x[cols_idx] = x_reduced solver.jl:186-187       k_scatter_active (K12)
+//
+// Everything the loop touches stays in HBM in the reduced (active-set) layout; the padded 2M/4M vector is
+// only materialised when the host asks for a state.
+#include <algorithm>
+#include <cmath>
+#include <memory>
+
+#include "pg_krylov.h"
+
+using namespace pg;
+
+struct pg_solver {
+  int nphase = 1;
+  pg_capacity* cap[2] = {nullptr, nullptr};
+  Slab slab;
+  int K = 2;
+  i64 Mloc = 0, M = 0;
+  double dt = 0.0, t = 0.0;
+  int scheme_ctor = PG_SCHEME_BE;
+  // problem description
+  pg_bc_desc bc_i{};          // mono interface condition
+  pg_jump_desc ic{};          // diph jumps
+  int border_kind[6] = {0, 0, 0, 0, 0, 0};
+  double border_value[6] = {0, 0, 0, 0, 0, 0};
+  double inv_dx = 0.0;
+  DevBuf<double> Id[2];       // D(C_ω), optional
+  DevBuf<double> f_n[2], f_np1[2];   // source at t and t+Δt (padded local), optional (NULL = 0)
+  DevBuf<double> g_n, g_np1;  // mono interface value arrays, optional
+  DevBuf<double> g_arr, h_arr;  // diph jump arrays, optional
+  // numbering + matrices
+  Numbering nb;
+  CsrMatrix A_ctor, A_run;
+  bool have_run = false;
+  int scheme_run = -1;
+  // per-row data
+  DevBuf<double> mass, bconst, bcv;
+  DevBuf<unsigned char> fixed;
+  int bconst_scheme = -1;
+  bool bconst_dirty = true;
+  // vectors
+  DevBuf<double> x, b, y;     // n_vec
+  DevBuf<double> T0pad;       // K*Mloc, ctor initial condition
+  KrylovWork work;
+  bool initial_done = false;
+  std::vector<DevBuf<double>> states;
+  i64 steps_done = 0;
+  DevBuf<double> red_scratch;  // max-abs partials
+  DevBuf<i64> border_cells_lin;  // global linear index of each border cell (mesh order), lazily uploaded
+};
+
+namespace {
+
+constexpr int BLOCK = 256;
+
+struct RowSegs {
+  int K;
+  i64 off_own[MAX_KINDS];
+};
+
+__device__ inline int seg_kind(const RowSegs& s, i64 r) {
+  int k = 0;
+  while (k + 1 < s.K && r >= s.off_own[k + 1]) ++k;
+  return k;
+}
+
+RowSegs make_segs(const Numbering& nb) {
+  RowSegs s;
+  s.K = nb.K;
+  for (int k = 0; k < MAX_KINDS; ++k) s.off_own[k] = nb.off_own[k];
+  return s;
+}
+
+struct KeyVals {
+  double v[6];
+};
+
+// static per-row data: mass (V for bulk rows that are not overwritten), fixed (b = bconst), border constant
+__global__ void k_row_static(SysParams P, RowSegs seg, i64 n_own, const int* row_cell, KeyVals kv, double* mass,
+                             unsigned char* fixed, double* bcv) {
+  const CapView& c = P.cap[0];
+  for (i64 r = blockIdx.x * (i64)blockDim.x + threadIdx.x; r < n_own; r += (i64)gridDim.x * blockDim.x) {
+    const int k = seg_kind(seg, r);
+    const i64 lc = row_cell[r];
+    i64 idx[3];
+    decode_cell(c.N, c.ext, c.plane, c.s0, lc, idx);
+    double m = 0.0, bv = 0.0;
+    unsigned char fx = 0;
+    if ((k & 1) == 0) {
+      const int ph = k >> 1;
+      int key = -1;
+      const int bk = border_row_kind(P, ph, lc, idx, &key);
+      if (bk != PG_BC_NONE) {
+        fx = 1;
+        bv = (bk == PG_BC_PERIODIC) ? 0.0 : kv.v[key];
+      } else {
+        m = P.cap[ph].V[lc];
+      }
+    } else if (P.nphase == 2) {
+      fx = 1;   // jump rows: b2 = g, b4 = Γ₂h for both schemes (diffusion.jl:415-416)
+    }
+    mass[r] = m;
+    fixed[r] = fx;
+    bcv[r] = bv;
+  }
+}
+
+struct SrcView {
+  const double* f_n[2];
+  const double* f_np1[2];
+  const double* g_n;     // mono: g(t)      diph: g array
+  const double* g_np1;   // mono: g(t+Δt)   diph: h array
+  double g_const, h_const;
+};
+
+// time-data part of the right-hand side                 diffusion.jl:257-261, 409-416
+__global__ void k_bconst(SysParams P, RowSegs seg, i64 n_own, const int* row_cell, SrcView s, int scheme, double dt,
+                         const unsigned char* fixed, const double* bcv, double* bconst) {
+  for (i64 r = blockIdx.x * (i64)blockDim.x + threadIdx.x; r < n_own; r += (i64)gridDim.x * blockDim.x) {
+    const int k = seg_kind(seg, r);
+    const i64 lc = row_cell[r];
+    const int ph = k >> 1;
+    double v;
+    if ((k & 1) == 0) {
+      if (fixed[r]) v = bcv[r];
+      else {
+        const double V = P.cap[ph].V[lc];
+        const double f1 = s.f_np1[ph] ? s.f_np1[ph][lc] : 0.0;
+        if (scheme == PG_SCHEME_CN) {
+          const double f0 = s.f_n[ph] ? s.f_n[ph][lc] : 0.0;
+          v = dt / 2 * V * (f0 + f1);
+        } else {
+          v = dt * V * f1;
+        }
+      }
+    } else if (P.nphase == 1) {
+      const double G = P.cap[0].G[lc];
+      const double g1 = s.g_np1 ? s.g_np1[lc] : s.g_const;
+      if (scheme == PG_SCHEME_CN) {
+        const double g0 = s.g_n ? s.g_n[lc] : s.g_const;
+        v = dt / 2 * G * (g0 + g1);
+      } else {
+        v = G * g1;
+      }
+    } else if (k == 1) {
+      v = s.g_n ? s.g_n[lc] : s.g_const;                          // b2 = gᵧ
+    } else {
+      v = P.cap[1].G[lc] * (s.g_np1 ? s.g_np1[lc] : s.h_const);   // b4 = Γ₂ hᵧ
+    }
+    bconst[r] = v;
+  }
+}
+
+// K8, loop form: T is the previous reduced state; y = A*T (CN only)
+__global__ void k_rhs(i64 n, int scheme, const double* __restrict__ T, const double* __restrict__ y,
+                      const double* __restrict__ mass, const double* __restrict__ bconst,
+                      const unsigned char* __restrict__ fixed, double* __restrict__ b) {
+  for (i64 r = blockIdx.x * (i64)blockDim.x + threadIdx.x; r < n; r += (i64)gridDim.x * blockDim.x) {
+    double v;
+    if (fixed[r]) v = bconst[r];
+    else if (scheme == PG_SCHEME_CN) v = 2.0 * (mass[r] * T[r]) - y[r] + bconst[r];
+    else v = mass[r] * T[r] + bconst[r];
+    b[r] = v;
+  }
+}
+
+// K8, constructor form: T0 and K*T0 live in the padded layout (T0 may be non-zero at eliminated unknowns)
+__global__ void k_rhs_first(RowSegs seg, i64 n, i64 Mloc, int scheme, const int* row_cell, const double* T0pad,
+                            const double* ypad, const double* mass, const double* bconst, const unsigned char* fixed,
+                            double* b, double* x0) {
+  for (i64 r = blockIdx.x * (i64)blockDim.x + threadIdx.x; r < n; r += (i64)gridDim.x * blockDim.x) {
+    const int k = seg_kind(seg, r);
+    const i64 q = (i64)k * Mloc + row_cell[r];
+    const double T = T0pad[q];
+    double v;
+    if (fixed[r]) v = bconst[r];
+    else if (scheme == PG_SCHEME_CN) v = 2.0 * (mass[r] * T) - ypad[q] + bconst[r];
+    else v = mass[r] * T + bconst[r];
+    b[r] = v;
+    x0[r] = T;
+  }
+}
+
+// K12: padded[k*Mloc + cell] = x[r]
+__global__ void k_scatter_active(RowSegs seg, i64 n, i64 Mloc, const int* row_cell, const double* x, double* padded) {
+  for (i64 r = blockIdx.x * (i64)blockDim.x + threadIdx.x; r < n; r += (i64)gridDim.x * blockDim.x) {
+    const int k = seg_kind(seg, r);
+    padded[(i64)k * Mloc + row_cell[r]] = x[r];
+  }
+}
+
+__global__ void k_maxabs(i64 n, const double* x, double* partials) {
+  __shared__ double sh[BLOCK];
+  double m = 0.0;
+  for (i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+    const double a = fabs(x[i]);
+    m = a > m ? a : m;
+  }
+  sh[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = BLOCK / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sh[threadIdx.x] = sh[threadIdx.x] > sh[threadIdx.x + s] ? sh[threadIdx.x] : sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[blockIdx.x] = sh[0];
+}
+
+__global__ void k_set_border_values(i64 nb, const i64* cells_global, const double* values, i64 first_cell, i64 Mloc,
+                                    int nbulk, const int* red, i64 n_own, double* bcv) {
+  for (i64 q = blockIdx.x * (i64)blockDim.x + threadIdx.x; q < nb; q += (i64)gridDim.x * blockDim.x) {
+    const i64 lc = cells_global[q] - first_cell;
+    if (lc < 0 || lc >= Mloc) continue;
+    for (int ph = 0; ph < nbulk; ++ph) {
+      const int r = red[(i64)(2 * ph) * Mloc + lc];
+      if (r >= 0 && r < n_own) bcv[r] = values[q];
+    }
+  }
+}
+
+SysParams make_params(const pg_solver* s, int scheme) {
+  SysParams P;
+  std::memset(&P, 0, sizeof(P));
+  P.nphase = s->nphase;
+  for (int q = 0; q < s->nphase; ++q) {
+    P.cap[q] = cap_view(s->cap[q]);
+    P.ct[q] = s->cap[q]->ct.p;
+    P.Id[q] = s->Id[q].p;
+  }
+  if (s->nphase == 1) { P.cap[1] = P.cap[0]; P.ct[1] = P.ct[0]; P.Id[1] = nullptr; }
+  const double th = scheme == PG_SCHEME_CN ? s->dt / 2 : s->dt;
+  P.theta = th;
+  P.gscale = scheme == PG_SCHEME_CN ? s->dt / 2 : 1.0;
+  if (s->nphase == 1) {
+    switch (s->bc_i.kind) {     // build_I_bc, solver.jl:203-223
+      case PG_BC_DIRICHLET: P.Ia = 1.0; P.Ib = 0.0; break;
+      case PG_BC_NEUMANN: P.Ia = 0.0; P.Ib = 1.0; break;
+      case PG_BC_ROBIN: P.Ia = s->bc_i.alpha; P.Ib = s->bc_i.beta; break;
+      default: P.Ia = 0.0; P.Ib = 0.0; break;
+    }
+  } else {
+    P.a1 = s->ic.alpha1; P.a2 = s->ic.alpha2; P.b1 = s->ic.beta1; P.b2 = s->ic.beta2;
+  }
+  for (int k = 0; k < 6; ++k) P.border_kind[k] = s->border_kind[k];
+  P.inv_dx = s->inv_dx;
+  return P;
+}
+
+void upload_local(DevBuf<double>& dst, const double* host_global, const Slab& slab) {
+  dst.alloc(slab.Mloc());
+  dst.upload(host_global + slab.first_cell(), slab.Mloc());
+}
+
+SrcView src_view(const pg_solver* s) {
+  SrcView v;
+  for (int q = 0; q < 2; ++q) { v.f_n[q] = s->f_n[q].p; v.f_np1[q] = s->f_np1[q].p; }
+  if (s->nphase == 1) {
+    v.g_n = s->g_n.p; v.g_np1 = s->g_np1.p;
+    v.g_const = s->bc_i.value; v.h_const = 0.0;
+  } else {
+    v.g_n = s->g_arr.p; v.g_np1 = s->h_arr.p;
+    v.g_const = s->ic.g; v.h_const = s->ic.h;
+  }
+  return v;
+}
+
+void ensure_bconst(pg_solver* s, int scheme) {
+  if (!s->bconst_dirty && s->bconst_scheme == scheme) return;
+  hipStream_t st = ctx().stream;
+  const i64 n = s->nb.n_own;
+  if (n > 0) {
+    const SysParams P = make_params(s, scheme);
+    hipLaunchKernelGGL(k_bconst, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, st, P, make_segs(s->nb), n, s->nb.row_cell.p,
+                       src_view(s), scheme, s->dt, s->fixed.p, s->bcv.p, s->bconst.p);
+    PG_HIP(hipGetLastError());
+  }
+  s->bconst_scheme = scheme;
+  s->bconst_dirty = false;
+}
+
+void setup_common(pg_solver* s, const pg_border_desc* borders, int nborders, const double* T0) {
+  hipStream_t st = ctx().stream;
+  const Slab& slab = s->slab;
+  s->K = s->nphase == 1 ? 2 : 4;
+  s->Mloc = slab.Mloc();
+  s->M = slab.M;
+  for (int i = 0; i < nborders; ++i) {
+    const int key = borders[i].key;
+    PG_REQUIRE(key >= 0 && key < 6, "border key out of range");
+    const int kind = borders[i].kind;
+    PG_REQUIRE(kind == PG_BC_DIRICHLET || kind == PG_BC_PERIODIC || kind == PG_BC_NEUMANN || kind == PG_BC_NONE ||
+               kind == PG_BC_ROBIN, "border kind not supported");
+    // Robin (and Neumann in >1-D) borders are silently ignored by the reference (solver.jl:450-499)
+    s->border_kind[key] = (kind == PG_BC_ROBIN) ? PG_BC_NONE : kind;
+    s->border_value[key] = borders[i].value;
+  }
+  if (slab.N == 1) {
+    const auto& nd = s->cap[0]->mesh->nodes[0];
+    double dx = 1e300;
+    for (size_t i = 1; i < nd.size(); ++i) dx = std::min(dx, nd[i] - nd[i - 1]);
+    s->inv_dx = 1.0 / dx;   // solver.jl:476
+  }
+  if (ctx().nranks > 1)
+    for (int k = 0; k < 6; ++k)
+      PG_REQUIRE(s->border_kind[k] != PG_BC_PERIODIC, "periodic borders are single-rank only");
+
+  // initial condition, padded local layout
+  s->T0pad.alloc((i64)s->K * s->Mloc);
+  for (int k = 0; k < s->K; ++k) s->T0pad.upload(T0 + (i64)k * s->M + slab.first_cell(), s->Mloc, (i64)k * s->Mloc);
+
+  // K10 once, K7/K9 for the constructor scheme
+  const SysParams P = make_params(s, s->scheme_ctor);
+  build_numbering(P, slab, s->nb);
+  assemble_csr(P, slab, s->nb, s->A_ctor);
+  s->A_ctor.scheme = s->scheme_ctor;
+
+  const i64 n = s->nb.n_own, nv = s->nb.n_vec();
+  const i64 na = n > 0 ? n : 1, nva = nv > 0 ? nv : 1;
+  s->mass.alloc(na); s->bconst.alloc(na); s->bcv.alloc(na); s->fixed.alloc(na);
+  s->x.alloc(nva); s->b.alloc(nva); s->y.alloc(nva);
+  s->x.zero(); s->b.zero(); s->y.zero();
+  s->work.init(n, nv);
+  s->red_scratch.alloc(2048);
+  if (n > 0) {
+    KeyVals kv;
+    for (int k = 0; k < 6; ++k) kv.v[k] = s->border_value[k];
+    hipLaunchKernelGGL(k_row_static, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, st, P, make_segs(s->nb), n, s->nb.row_cell.p,
+                       kv, s->mass.p, s->fixed.p, s->bcv.p);
+    PG_HIP(hipGetLastError());
+  }
+  // first right-hand side: b(t = 0) with the constructor scheme (diffusion.jl:202/205, 328)
+  ensure_bconst(s, s->scheme_ctor);
+  DevBuf<double> ypad;
+  if (s->scheme_ctor == PG_SCHEME_CN) {
+    ypad.alloc((i64)s->K * s->Mloc);
+    ypad.zero();
+    apply_rows_padded(P, slab, s->T0pad.p, ypad.p);
+  }
+  if (n > 0) {
+    hipLaunchKernelGGL(k_rhs_first, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, st, make_segs(s->nb), n, s->Mloc,
+                       s->scheme_ctor, s->nb.row_cell.p, s->T0pad.p, ypad.p, s->mass.p, s->bconst.p, s->fixed.p, s->b.p,
+                       s->x.p);
+    PG_HIP(hipGetLastError());
+  }
+  PG_HIP(hipStreamSynchronize(st));
+  s->t = 0.0;
+}
+
+double max_abs(pg_solver* s) {
+  hipStream_t st = ctx().stream;
+  const i64 n = s->nb.n_own;
+  double m = 0.0;
+  if (n > 0) {
+    const int g = grid_for(n, BLOCK, 2048);
+    hipLaunchKernelGGL(k_maxabs, dim3(g), dim3(BLOCK), 0, st, n, s->x.p, s->red_scratch.p);
+    PG_HIP(hipGetLastError());
+    std::vector<double> h(g);
+    s->red_scratch.download(h.data(), g);
+    for (double v : h) m = std::max(m, v);
+  }
+  if (ctx().nranks > 1) {
+    DevBuf<double> d(1);
+    d.upload(&m, 1);
+    PG_NCCL(ncclAllReduce(d.p, d.p, 1, ncclDouble, ncclMax, ctx().comm, st));
+    d.download(&m, 1);
+  }
+  return m;
+}
+
+void ensure_run_matrix(pg_solver* s, int scheme) {
+  if (s->have_run && s->scheme_run == scheme) return;
+  if (scheme == s->scheme_ctor && s->A_ctor.n == s->nb.n_own && s->A_ctor.rowptr.p) {
+    // same scheme: the loop matrix equals the constructor matrix (border rows are re-applied identically)
+    s->scheme_run = scheme;
+    s->have_run = true;
+    return;
+  }
+  const SysParams P = make_params(s, scheme);
+  assemble_csr(P, s->slab, s->nb, s->A_run);
+  s->A_run.scheme = scheme;
+  s->scheme_run = scheme;
+  s->have_run = true;
+}
+
+const CsrMatrix& run_matrix(const pg_solver* s) {
+  return (s->scheme_run == s->scheme_ctor) ? s->A_ctor : s->A_run;
+}
+
+void fill_info(pg_solver* s, const SolveStats& st, pg_step_info* info) {
+  if (!info) return;
+  info->iters = st.iters;
+  info->converged = st.converged;
+  info->resnorm = st.resnorm;
+  info->bnorm = st.bnorm;
+  info->extremum = max_abs(s);
+  info->time = s->t;
+}
+
+void keep_state(pg_solver* s) {
+  DevBuf<double> cp(s->nb.n_own > 0 ? s->nb.n_own : 1);
+  if (s->nb.n_own > 0)
+    PG_HIP(hipMemcpyAsync(cp.p, s->x.p, sizeof(double) * s->nb.n_own, hipMemcpyDeviceToDevice, ctx().stream));
+  s->states.emplace_back(std::move(cp));
+}
+
+pg_krylov_opts default_opts() {
+  pg_krylov_opts o;
+  o.method = PG_METHOD_BICGSTAB;
+  o.reltol = 1e-12;
+  o.abstol = 0.0;
+  o.maxiter = 0;
+  o.check_every = 4;
+  return o;
+}
+
+void do_initial(pg_solver* s, const pg_krylov_opts* opts, SolveStats& st) {
+  const pg_krylov_opts o = opts ? *opts : default_opts();
+  // solve_system!(s) with the constructor's A and b (diffusion.jl:275)
+  krylov_solve(s->A_ctor, s->nb, s->slab, s->b.p, s->x.p, s->work, o, st);
+  s->initial_done = true;
+}
+
+void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& st) {
+  PG_REQUIRE(s->initial_done, "Solver is not initialized. Call pg_solver_initial_solve first.");
+  const pg_krylov_opts o = opts ? *opts : default_opts();
+  hipStream_t stream = ctx().stream;
+  ensure_run_matrix(s, scheme);
+  const CsrMatrix& A = run_matrix(s);
+  const i64 n = s->nb.n_own;
+  s->t += s->dt;                     // diffusion.jl:287
+  ensure_bconst(s, scheme);
+  if (n > 0) {
+    if (scheme == PG_SCHEME_CN) {
+      halo_exchange(s->nb, s->slab, s->x.p, stream);
+      spmv(A, s->x.p, s->y.p, stream);
+    }
+    hipLaunchKernelGGL(k_rhs, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, stream, n, scheme, s->x.p, s->y.p, s->mass.p,
+                       s->bconst.p, s->fixed.p, s->b.p);
+    PG_HIP(hipGetLastError());
+  }
+  krylov_solve(A, s->nb, s->slab, s->b.p, s->x.p, s->work, o, st);
+  s->steps_done += 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t pg_solver_create_unsteady_mono(pg_capacity* c, pg_diffops* o, const pg_bc_desc* bc_interface,
+                                       const pg_border_desc* borders, int32_t nborders, const double* Dcoef,
+                                       const double* source, double dt, const double* T0, int32_t scheme,
+                                       pg_solver** out) {
+  PG_API_BEGIN
+  require_init();
+  PG_REQUIRE(c && o && bc_interface && T0 && out, "pg_solver_create_unsteady_mono: NULL argument");
+  PG_REQUIRE(o->cap == c, "operators were built from a different capacity");
+  PG_REQUIRE(scheme == PG_SCHEME_BE || scheme == PG_SCHEME_CN, "scheme must be BE or CN");
+  PG_REQUIRE(dt > 0.0, "dt must be positive");
+  auto* s = new pg_solver();
+  std::unique_ptr<pg_solver> guard(s);
+  s->nphase = 1;
+  s->cap[0] = c;
+  s->slab = c->slab;
+  s->dt = dt;
+  s->scheme_ctor = scheme;
+  s->bc_i = *bc_interface;
+  if (Dcoef) upload_local(s->Id[0], Dcoef, s->slab);
+  if (source) upload_local(s->f_np1[0], source, s->slab);
+  if (bc_interface->value_array) {
+    upload_local(s->g_np1, bc_interface->value_array, s->slab);
+    upload_local(s->g_n, bc_interface->value_array, s->slab);
+  }
+  s->bc_i.value_array = nullptr;
+  setup_common(s, borders, nborders, T0);
+  *out = guard.release();
+  PG_API_END
+}
+
+int32_t pg_solver_create_unsteady_diph(pg_capacity* c1, pg_diffops* o1, pg_capacity* c2, pg_diffops* o2,
+                                       const pg_jump_desc* ic, const pg_border_desc* borders, int32_t nborders,
+                                       const double* D1, const double* D2, const double* f1, const double* f2, double dt,
+                                       const double* T0, int32_t scheme, pg_solver** out) {
+  PG_API_BEGIN
+  require_init();
+  PG_REQUIRE(c1 && c2 && o1 && o2 && ic && T0 && out, "pg_solver_create_unsteady_diph: NULL argument");
+  PG_REQUIRE(c1->mesh == c2->mesh, "Phase capacities must share the same mesh.");
+  PG_REQUIRE(c1->slab.p0 == c2->slab.p0 && c1->slab.p1 == c2->slab.p1, "phase capacities must share the slab partition");
+  PG_REQUIRE(scheme == PG_SCHEME_BE || scheme == PG_SCHEME_CN, "scheme must be BE or CN");
+  auto* s = new pg_solver();
+  std::unique_ptr<pg_solver> guard(s);
+  s->nphase = 2;
+  s->cap[0] = c1;
+  s->cap[1] = c2;
+  s->slab = c1->slab;
+  s->dt = dt;
+  s->scheme_ctor = scheme;
+  s->ic = *ic;
+  if (D1) upload_local(s->Id[0], D1, s->slab);
+  if (D2) upload_local(s->Id[1], D2, s->slab);
+  if (f1) upload_local(s->f_np1[0], f1, s->slab);
+  if (f2) upload_local(s->f_np1[1], f2, s->slab);
+  if (ic->g_array) upload_local(s->g_arr, ic->g_array, s->slab);
+  if (ic->h_array) upload_local(s->h_arr, ic->h_array, s->slab);
+  s->ic.g_array = s->ic.h_array = nullptr;
+  setup_common(s, borders, nborders, T0);
+  *out = guard.release();
+  PG_API_END
+}
+
+int32_t pg_solver_destroy(pg_solver* s) {
+  PG_API_BEGIN
+  delete s;
+  PG_API_END
+}
+
+int32_t pg_solver_set_source(pg_solver* s, int32_t phase, const double* f_n, const double* f_np1) {
+  PG_API_BEGIN
+  require_init();
+  PG_REQUIRE(s && phase >= 0 && phase < s->nphase, "pg_solver_set_source: bad arguments");
+  if (f_n) upload_local(s->f_n[phase], f_n, s->slab);
+  if (f_np1) upload_local(s->f_np1[phase], f_np1, s->slab);
+  s->bconst_dirty = true;
+  PG_API_END
+}
+
+int32_t pg_solver_set_interface_value(pg_solver* s, const double* g_n, const double* g_np1) {
+  PG_API_BEGIN
+  require_init();
+  PG_REQUIRE(s && s->nphase == 1, "pg_solver_set_interface_value: monophasic solver expected");
+  if (g_n) upload_local(s->g_n, g_n, s->slab);
+  if (g_np1) upload_local(s->g_np1, g_np1, s->slab);
+  s->bconst_dirty = true;
+  PG_API_END
+}
+
+int32_t pg_solver_set_border_values(pg_solver* s, const double* values) {
+  PG_API_BEGIN
+  require_init();
+  PG_REQUIRE(s && values, "pg_solver_set_border_values: NULL argument");
+  pg_mesh* m = s->cap[0]->mesh;
+  mesh_build_border(m);
+  const i64 nb = (i64)m->border_key.size();
+  if (!s->border_cells_lin.p) {
+    std::vector<i64> lin(nb);
+    for (i64 q = 0; q < nb; ++q) {
+      i64 li = 0;
+      for (int d = 0; d < m->N; ++d) li += (m->border_idx[q * m->N + d] - 1) * s->slab.stride[d];
+      lin[q] = li;
+    }
+    s->border_cells_lin.alloc(nb);
+    s->border_cells_lin.upload(lin.data(), nb);
+  }
+  DevBuf<double> dv(nb);
+  dv.upload(values, nb);
+  hipLaunchKernelGGL(k_set_border_values, dim3(grid_for(nb, BLOCK)), dim3(BLOCK), 0, ctx().stream, nb, s->border_cells_lin.p,
+                     dv.p, s->slab.first_cell(), s->Mloc, s->nphase, s->nb.red.p, s->nb.n_own, s->bcv.p);
+  PG_HIP(hipGetLastError());
+  PG_HIP(hipStreamSynchronize(ctx().stream));
+  s->bconst_dirty = true;
+  PG_API_END
+}
+
+int32_t pg_solver_initial_solve(pg_solver* s, const pg_krylov_opts* opts, pg_step_info* info) {
+  PG_API_BEGIN
+  require_init();
+  PG_REQUIRE(s, "Solver is not initialized. Call a solver constructor first.");
+  SolveStats st;
+  do_initial(s, opts, st);
+  fill_info(s, st, info);
+  PG_API_END
+}
+
+int32_t pg_solver_step(pg_solver* s, int32_t scheme, const pg_krylov_opts* opts, pg_step_info* info) {
+  PG_API_BEGIN
+  require_init();
+  PG_REQUIRE(s, "Solver is not initialized. Call a solver constructor first.");
+  PG_REQUIRE(scheme == PG_SCHEME_BE || scheme == PG_SCHEME_CN, "scheme must be BE or CN");
+  SolveStats st;
+  do_step(s, scheme, opts, st);
+  fill_info(s, st, info);
+  PG_API_END
+}
+
+int32_t pg_solver_run(pg_solver* s, double Tend, int32_t scheme, const pg_krylov_opts* opts, int32_t do_initial_flag,
+                      int64_t max_steps, int32_t save_every, pg_run_info* info) {
+  PG_API_BEGIN
+  require_init();
+  PG_REQUIRE(s, "Solver is not initialized. Call a solver constructor first.");
+  PG_REQUIRE(scheme == PG_SCHEME_BE || scheme == PG_SCHEME_CN, "scheme must be BE or CN");
+  hipStream_t stream = ctx().stream;
+  hipEvent_t e0, e1;
+  PG_HIP(hipEventCreate(&e0));
+  PG_HIP(hipEventCreate(&e1));
+  PG_HIP(hipEventRecord(e0, stream));
+  SolveStats tot;
+  i64 steps = 0, iters = 0;
+  if (do_initial_flag) {
+    SolveStats st;
+    do_initial(s, opts, st);
+    iters += st.iters; tot.spmv_ms += st.spmv_ms; tot.spmv_launches += st.spmv_launches;
+    if (save_every > 0) keep_state(s);
+  }
+  while (s->t < Tend) {             // diffusion.jl:286
+    if (max_steps >= 0 && steps >= max_steps) break;
+    SolveStats st;
+    do_step(s, scheme, opts, st);
+    iters += st.iters; tot.spmv_ms += st.spmv_ms; tot.spmv_launches += st.spmv_launches;
+    ++steps;
+    if (save_every > 0 && steps % save_every == 0) keep_state(s);
+  }
+  PG_HIP(hipEventRecord(e1, stream));
+  PG_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  PG_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (info) {
+    info->steps = steps;
+    info->total_iters = iters;
+    info->t_final = s->t;
+    info->extremum = max_abs(s);
+    info->solve_ms = ms;
+    info->spmv_ms_total = tot.spmv_ms;
+    info->spmv_launches = tot.spmv_launches;
+  }
+  PG_API_END
+}
+
+int32_t pg_solver_num_states(const pg_solver* s, int64_t* out) {
+  PG_API_BEGIN
+  PG_REQUIRE(s && out, "pg_solver_num_states: NULL argument");
+  *out = (int64_t)s->states.size();
+  PG_API_END
+}
+
+int32_t pg_solver_get_state(const pg_solver* s, int64_t state_index, double* x, int64_t len) {
+  PG_API_BEGIN
+  require_init();
+  PG_REQUIRE(s && x, "pg_solver_get_state: NULL argument");
+  PG_REQUIRE(len == (i64)s->K * s->M, "pg_solver_get_state: len must be 2M (mono) or 4M (diph)");
+  const double* src = s->x.p;
+  if (state_index >= 0) {
+    PG_REQUIRE(state_index < (i64)s->states.size(), "pg_solver_get_state: state index out of range");
+    src = s->states[state_index].p;
+  }
+  hipStream_t st = ctx().stream;
+  DevBuf<double> pad((i64)s->K * s->Mloc);
+  pad.zero();                                            // s.x = zeros(n)          solver.jl:186
+  if (s->nb.n_own > 0) {
+    hipLaunchKernelGGL(k_scatter_active, dim3(grid_for(s->nb.n_own, BLOCK)), dim3(BLOCK), 0, st, make_segs(s->nb),
+                       s->nb.n_own, s->Mloc, s->nb.row_cell.p, src, pad.p);   // s.x[cols_idx] = x_reduced   :187
+    PG_HIP(hipGetLastError());
+  }
+  // only the owned planes are authoritative on this rank
+  const i64 own_lo = (s->slab.p0 - s->slab.s0) * s->slab.plane, own_n = (s->slab.p1 - s->slab.p0) * s->slab.plane;
+  for (int k = 0; k < s->K; ++k)
+    pad.download(x + (i64)k * s->M + s->slab.p0 * s->slab.plane, own_n, (i64)k * s->Mloc + own_lo);
+  PG_API_END
+}
+
+int32_t pg_solver_system_info(const pg_solver* s, int32_t which, pg_system_info* out) {
+  PG_API_BEGIN
+  PG_REQUIRE(s && out, "pg_solver_system_info: NULL argument");
+  const CsrMatrix& A = (which == 0 || !s->have_run) ? s->A_ctor : run_matrix(s);
+  out->n_own = s->nb.n_own;
+  out->nnz = A.nnz;
+  out->n_ghost = s->nb.n_ghost;
+  i64 nw = 0, ng = 0;
+  for (int k = 0; k < s->K; ++k) ((k & 1) ? ng : nw) += s->nb.cnt_own[k];
+  out->n_omega = nw;
+  out->n_gamma = ng;
+  out->M_global = s->M;
+  PG_API_END
+}
+
+int32_t pg_solver_get_system_csr(const pg_solver* s, int32_t which, int64_t* rowptr, int64_t* col, double* val, double* b,
+                                 int64_t* idx) {
+  PG_API_BEGIN
+  require_init();
+  PG_REQUIRE(s, "pg_solver_get_system_csr: NULL argument");
+  if (which == 1) PG_REQUIRE(s->have_run, "run matrix not assembled yet");
+  const CsrMatrix& A = which == 0 ? s->A_ctor : run_matrix(s);
+  const i64 n = s->nb.n_own;
+  if (rowptr) {
+    std::vector<int> h(n + 1);
+    A.rowptr.download(h.data(), n + 1);
+    for (i64 i = 0; i <= n; ++i) rowptr[i] = h[i];
+  }
+  if (col && A.nnz > 0) {
+    std::vector<int> h(A.nnz);
+    A.col.download(h.data(), A.nnz);
+    for (i64 i = 0; i < A.nnz; ++i) col[i] = h[i];
+  }
+  if (val && A.nnz > 0) A.val.download(val, A.nnz);
+  if (b && n > 0) s->b.download(b, n);
+  if (idx && n > 0) {
+    std::vector<int> h(n);
+    s->nb.row_cell.download(h.data(), n);
+    for (i64 r = 0; r < n; ++r) {
+      const int k = s->nb.kind_of_row(r);
+      idx[r] = (i64)k * s->M + s->slab.first_cell() + h[r];
+    }
+  }
+  PG_API_END
+}
+
+int32_t pg_solver_time_spmv(pg_solver* s, int32_t which, int32_t reps, double* avg_ms) {
+  PG_API_BEGIN
+  require_init();
+  PG_REQUIRE(s && avg_ms && reps > 0, "pg_solver_time_spmv: bad arguments");
+  if (which == 1) PG_REQUIRE(s->have_run, "run matrix not assembled yet");
+  const CsrMatrix& A = which == 0 ? s->A_ctor : run_matrix(s);
+  hipStream_t st = ctx().stream;
+  hipEvent_t e0, e1;
+  PG_HIP(hipEventCreate(&e0));
+  PG_HIP(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) spmv(A, s->x.p, s->y.p, st);
+  PG_HIP(hipEventRecord(e0, st));
+  for (int i = 0; i < reps; ++i) spmv(A, s->x.p, s->y.p, st);
+  PG_HIP(hipEventRecord(e1, st));
+  PG_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  PG_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *avg_ms = ms / reps;
+  PG_API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,47 @@
+// pg_system.h -- reduced (active-set) linear system of one slab: numbering (K10) + CSR matrix (K7/K9).
+#pragma once
+#include "pg_stencil.h"
+
+namespace pg {
+
+// Local vector layout (length n_own + n_ghost):
+//   [ kind0 owned | kind1 owned | ... | lower ghost: kind0.. | upper ghost: kind0.. ]
+// Owned unknowns of a kind are ordered by padded cell index (the reference's common_idx order,
+// src/solver.jl:65-71), so the actives of the first / last owned plane are contiguous chunks at the
+// start / end of each kind segment: halo exchange needs no pack/unpack kernels.
+struct Numbering {
+  int K = 2;
+  i64 Mloc = 0;
+  i64 n_own = 0, n_ghost = 0;
+  i64 cnt_own[MAX_KINDS] = {0, 0, 0, 0}, off_own[MAX_KINDS] = {0, 0, 0, 0};
+  i64 cntL[MAX_KINDS] = {0, 0, 0, 0}, offL[MAX_KINDS] = {0, 0, 0, 0};   // lower ghost segments (absolute offsets)
+  i64 cntU[MAX_KINDS] = {0, 0, 0, 0}, offU[MAX_KINDS] = {0, 0, 0, 0};   // upper ghost segments
+  // chunks of OWNED unknowns sent to the lower / upper neighbour (absolute offsets into the owned part)
+  i64 sendL_off[MAX_KINDS] = {0, 0, 0, 0}, sendL_cnt[MAX_KINDS] = {0, 0, 0, 0};
+  i64 sendU_off[MAX_KINDS] = {0, 0, 0, 0}, sendU_cnt[MAX_KINDS] = {0, 0, 0, 0};
+  // rows that touch no ghost column: [interior_lo, interior_hi) per kind is NOT contiguous across kinds,
+  // so the overlap split is expressed per kind
+  DevBuf<int> red;        // K*Mloc: local vector index of (kind, local cell) or -1
+  DevBuf<int> row_cell;   // n_own: local cell of each owned row
+  i64 n_vec() const { return n_own + n_ghost; }
+  int kind_of_row(i64 r) const {
+    int k = 0;
+    while (k + 1 < K && r >= off_own[k + 1]) ++k;
+    return k;
+  }
+};
+
+struct CsrMatrix {
+  i64 n = 0, nnz = 0;
+  int scheme = -1;
+  DevBuf<int> rowptr, col;
+  DevBuf<double> val;
+};
+
+void build_numbering(const SysParams& P, const Slab& slab, Numbering& nb);
+void assemble_csr(const SysParams& P, const Slab& slab, const Numbering& nb, CsrMatrix& A);
+// y (padded, K*Mloc) = K_full * x (padded, K*Mloc): matrix-free application of the un-reduced operator rows
+// `rows` of the planes owned by this rank (used for the constructor's first right-hand side under CN).
+void apply_rows_padded(const SysParams& P, const Slab& slab, const double* x, double* y);
+
+}  // namespace pg

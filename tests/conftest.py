@@ -1,0 +1,22 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pj():
+    """The product package, initialised on cuda:0.  Fails loudly without the HIP library / a GPU."""
+    import penguin.jl_amd as pj
+
+    pj.init(0)
+    return pj
