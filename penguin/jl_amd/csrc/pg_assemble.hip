@@ -131,6 +131,34 @@ __global__ void k_fill(SysParams P, RowSegs seg, i64 Mloc, i64 n_own, const int*
   }
 }
 
+// ds[red] = |a_ii|^-1/2 for every numbered unknown (owned and ghost: ghost rows are evaluable locally)
+__global__ void k_diag_scale(SysParams P, int K, i64 Mloc, const int* red, double* ds) {
+  const CapView& c = P.cap[0];
+  const i64 total = (i64)K * Mloc;
+  for (i64 q = blockIdx.x * (i64)blockDim.x + threadIdx.x; q < total; q += (i64)gridDim.x * blockDim.x) {
+    const int r = red[q];
+    if (r < 0) continue;
+    const int k = (int)(q / Mloc);
+    const i64 lc = q % Mloc;
+    i64 idx[3];
+    decode_cell(c.N, c.ext, c.plane, c.s0, lc, idx);
+    double diag = 0.0;
+    eval_row(P, k, lc, idx, [&](int ck, i64 cl, double v) {
+      if (ck == k && cl == lc) diag = v;
+    });
+    const double a = fabs(diag);
+    ds[r] = (a > 0.0 && a < 1e300) ? 1.0 / sqrt(a) : 1.0;
+  }
+}
+
+__global__ void k_scale_vals(i64 n, const int* __restrict__ rowptr, const int* __restrict__ col,
+                             const double* __restrict__ ds, double* __restrict__ val) {
+  for (i64 r = blockIdx.x * (i64)blockDim.x + threadIdx.x; r < n; r += (i64)gridDim.x * blockDim.x) {
+    const double sr = ds[r];
+    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) val[k] = sr * val[k] * ds[col[k]];
+  }
+}
+
 // y[k*Mloc+lc] = sum_entries v * x[ck*Mloc+cl] for rows of planes [lc_begin,lc_end)
 __global__ void k_apply_padded(SysParams P, i64 Mloc, i64 lc_begin, i64 lc_end, const double* x, double* y) {
   const int K = nkinds(P);
@@ -241,6 +269,7 @@ void assemble_csr(const SysParams& P, const Slab& s, const Numbering& nb, CsrMat
   if (n == 0) {
     A.rowptr.zero();
     A.nnz = 0;
+    A.ds.alloc(nb.n_vec() > 0 ? nb.n_vec() : 1);
     return;
   }
   DevBuf<int> cnt(n);
@@ -256,6 +285,13 @@ void assemble_csr(const SysParams& P, const Slab& s, const Numbering& nb, CsrMat
   A.val.alloc(nnz > 0 ? nnz : 1);
   hipLaunchKernelGGL(k_fill, dim3(gr), dim3(256), 0, st, P, seg, nb.Mloc, n, nb.row_cell.p, nb.red.p, A.rowptr.p, A.col.p,
                      A.val.p);
+  PG_HIP(hipGetLastError());
+  // symmetric diagonal equilibration folded into the values (see CsrMatrix)
+  A.ds.alloc(nb.n_vec());
+  hipLaunchKernelGGL(k_diag_scale, dim3(grid_for((i64)nb.K * nb.Mloc, 256, 256 * 16)), dim3(256), 0, st, P, nb.K, nb.Mloc,
+                     nb.red.p, A.ds.p);
+  PG_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_scale_vals, dim3(gr), dim3(256), 0, st, n, A.rowptr.p, A.col.p, A.ds.p, A.val.p);
   PG_HIP(hipGetLastError());
   PG_HIP(hipStreamSynchronize(st));
 }

@@ -46,7 +46,8 @@ struct pg_solver {
   int bconst_scheme = -1;
   bool bconst_dirty = true;
   // vectors
-  DevBuf<double> x, b, y;     // n_vec
+  DevBuf<double> x, b, y;     // n_vec: unscaled state, scaled right-hand side, Â z
+  DevBuf<double> z, ysol;     // n_vec: scaled state S⁻¹x (SpMV input), Krylov solution y (x = S y)
   DevBuf<double> T0pad;       // K*Mloc, ctor initial condition
   KrylovWork work;
   bool initial_done = false;
@@ -158,23 +159,29 @@ __global__ void k_bconst(SysParams P, RowSegs seg, i64 n_own, const int* row_cel
   }
 }
 
-// K8, loop form: T is the previous reduced state; y = A*T (CN only)
-__global__ void k_rhs(i64 n, int scheme, const double* __restrict__ T, const double* __restrict__ y,
-                      const double* __restrict__ mass, const double* __restrict__ bconst,
+// K8, loop form: x is the previous (unscaled) reduced state; yhat = Â (S⁻¹x) (CN only); output is S b
+__global__ void k_rhs(i64 n, int scheme, const double* __restrict__ x, const double* __restrict__ yhat,
+                      const double* __restrict__ ds, const double* __restrict__ mass, const double* __restrict__ bconst,
                       const unsigned char* __restrict__ fixed, double* __restrict__ b) {
   for (i64 r = blockIdx.x * (i64)blockDim.x + threadIdx.x; r < n; r += (i64)gridDim.x * blockDim.x) {
     double v;
-    if (fixed[r]) v = bconst[r];
-    else if (scheme == PG_SCHEME_CN) v = 2.0 * (mass[r] * T[r]) - y[r] + bconst[r];
-    else v = mass[r] * T[r] + bconst[r];
+    if (fixed[r]) v = ds[r] * bconst[r];
+    else if (scheme == PG_SCHEME_CN) v = ds[r] * (2.0 * (mass[r] * x[r]) + bconst[r]) - yhat[r];
+    else v = ds[r] * (mass[r] * x[r] + bconst[r]);
     b[r] = v;
   }
 }
 
+__global__ void k_scale_state(i64 n, const double* __restrict__ ds, const double* __restrict__ in, double* __restrict__ out,
+                              int divide) {
+  for (i64 r = blockIdx.x * (i64)blockDim.x + threadIdx.x; r < n; r += (i64)gridDim.x * blockDim.x)
+    out[r] = divide ? in[r] / ds[r] : in[r] * ds[r];
+}
+
 // K8, constructor form: T0 and K*T0 live in the padded layout (T0 may be non-zero at eliminated unknowns)
 __global__ void k_rhs_first(RowSegs seg, i64 n, i64 Mloc, int scheme, const int* row_cell, const double* T0pad,
-                            const double* ypad, const double* mass, const double* bconst, const unsigned char* fixed,
-                            double* b, double* x0) {
+                            const double* ypad, const double* ds, const double* mass, const double* bconst,
+                            const unsigned char* fixed, double* b, double* x0) {
   for (i64 r = blockIdx.x * (i64)blockDim.x + threadIdx.x; r < n; r += (i64)gridDim.x * blockDim.x) {
     const int k = seg_kind(seg, r);
     const i64 q = (i64)k * Mloc + row_cell[r];
@@ -183,7 +190,7 @@ __global__ void k_rhs_first(RowSegs seg, i64 n, i64 Mloc, int scheme, const int*
     if (fixed[r]) v = bconst[r];
     else if (scheme == PG_SCHEME_CN) v = 2.0 * (mass[r] * T) - ypad[q] + bconst[r];
     else v = mass[r] * T + bconst[r];
-    b[r] = v;
+    b[r] = ds[r] * v;
     x0[r] = T;
   }
 }
@@ -323,8 +330,8 @@ void setup_common(pg_solver* s, const pg_border_desc* borders, int nborders, con
   const i64 n = s->nb.n_own, nv = s->nb.n_vec();
   const i64 na = n > 0 ? n : 1, nva = nv > 0 ? nv : 1;
   s->mass.alloc(na); s->bconst.alloc(na); s->bcv.alloc(na); s->fixed.alloc(na);
-  s->x.alloc(nva); s->b.alloc(nva); s->y.alloc(nva);
-  s->x.zero(); s->b.zero(); s->y.zero();
+  s->x.alloc(nva); s->b.alloc(nva); s->y.alloc(nva); s->z.alloc(nva); s->ysol.alloc(nva);
+  s->x.zero(); s->b.zero(); s->y.zero(); s->z.zero(); s->ysol.zero();
   s->work.init(n, nv);
   s->red_scratch.alloc(2048);
   if (n > 0) {
@@ -344,8 +351,8 @@ void setup_common(pg_solver* s, const pg_border_desc* borders, int nborders, con
   }
   if (n > 0) {
     hipLaunchKernelGGL(k_rhs_first, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, st, make_segs(s->nb), n, s->Mloc,
-                       s->scheme_ctor, s->nb.row_cell.p, s->T0pad.p, ypad.p, s->mass.p, s->bconst.p, s->fixed.p, s->b.p,
-                       s->x.p);
+                       s->scheme_ctor, s->nb.row_cell.p, s->T0pad.p, ypad.p, s->A_ctor.ds.p, s->mass.p, s->bconst.p, s->fixed.p,
+                       s->b.p, s->x.p);
     PG_HIP(hipGetLastError());
   }
   PG_HIP(hipStreamSynchronize(st));
@@ -422,7 +429,13 @@ pg_krylov_opts default_opts() {
 void do_initial(pg_solver* s, const pg_krylov_opts* opts, SolveStats& st) {
   const pg_krylov_opts o = opts ? *opts : default_opts();
   // solve_system!(s) with the constructor's A and b (diffusion.jl:275)
-  krylov_solve(s->A_ctor, s->nb, s->slab, s->b.p, s->x.p, s->work, o, st);
+  krylov_solve(s->A_ctor, s->nb, s->slab, s->b.p, s->ysol.p, s->work, o, st);
+  const i64 n = s->nb.n_own;
+  if (n > 0) {
+    hipLaunchKernelGGL(k_scale_state, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx().stream, n, s->A_ctor.ds.p, s->ysol.p,
+                       s->x.p, 0);   // x = S y
+    PG_HIP(hipGetLastError());
+  }
   s->initial_done = true;
 }
 
@@ -437,14 +450,19 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
   ensure_bconst(s, scheme);
   if (n > 0) {
     if (scheme == PG_SCHEME_CN) {
-      halo_exchange(s->nb, s->slab, s->x.p, stream);
-      spmv(A, s->x.p, s->y.p, stream);
+      hipLaunchKernelGGL(k_scale_state, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, stream, n, A.ds.p, s->x.p, s->z.p, 1);
+      halo_exchange(s->nb, s->slab, s->z.p, stream);
+      spmv(A, s->z.p, s->y.p, stream);   // Â S⁻¹ x = S A x
     }
-    hipLaunchKernelGGL(k_rhs, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, stream, n, scheme, s->x.p, s->y.p, s->mass.p,
+    hipLaunchKernelGGL(k_rhs, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, stream, n, scheme, s->x.p, s->y.p, A.ds.p, s->mass.p,
                        s->bconst.p, s->fixed.p, s->b.p);
     PG_HIP(hipGetLastError());
   }
-  krylov_solve(A, s->nb, s->slab, s->b.p, s->x.p, s->work, o, st);
+  krylov_solve(A, s->nb, s->slab, s->b.p, s->ysol.p, s->work, o, st);
+  if (n > 0) {
+    hipLaunchKernelGGL(k_scale_state, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, stream, n, A.ds.p, s->ysol.p, s->x.p, 0);
+    PG_HIP(hipGetLastError());
+  }
   s->steps_done += 1;
 }
 
@@ -697,8 +715,21 @@ int32_t pg_solver_get_system_csr(const pg_solver* s, int32_t which, int64_t* row
     A.col.download(h.data(), A.nnz);
     for (i64 i = 0; i < A.nnz; ++i) col[i] = h[i];
   }
-  if (val && A.nnz > 0) A.val.download(val, A.nnz);
-  if (b && n > 0) s->b.download(b, n);
+  // undo the equilibration: a_rc = â_rc / (s_r s_c), b_r = b̂_r / s_r
+  std::vector<double> hds(s->nb.n_vec() > 0 ? s->nb.n_vec() : 1);
+  if (s->nb.n_vec() > 0) A.ds.download(hds.data(), s->nb.n_vec());
+  if (val && A.nnz > 0) {
+    A.val.download(val, A.nnz);
+    std::vector<int> hr(n + 1), hc(A.nnz);
+    A.rowptr.download(hr.data(), n + 1);
+    A.col.download(hc.data(), A.nnz);
+    for (i64 r = 0; r < n; ++r)
+      for (int k = hr[r]; k < hr[r + 1]; ++k) val[k] = val[k] / (hds[r] * hds[hc[k]]);
+  }
+  if (b && n > 0) {
+    s->b.download(b, n);
+    for (i64 r = 0; r < n; ++r) b[r] /= hds[r];
+  }
   if (idx && n > 0) {
     std::vector<int> h(n);
     s->nb.row_cell.download(h.data(), n);

@@ -31,11 +31,17 @@ struct Numbering {
   }
 };
 
+// The stored matrix is the symmetrically equilibrated  Â = S A S,  S = diag(|a_ii|^-1/2)  (S = 1 where
+// a_ii = 0).  The reference solves A x = b with a direct solver (or an unpreconditioned Krylov method that
+// needs O(10^3) iterations on cut-cell systems: tiny staggered volumes give rows 10^5 apart in scale).
+// Solving  Â y = S b,  x = S y  is the same linear system; folding S into the CSR values costs nothing per
+// SpMV and brings BiCGStab to ~20 iterations per step.  `ds` holds S for owned AND ghost unknowns.
 struct CsrMatrix {
   i64 n = 0, nnz = 0;
   int scheme = -1;
   DevBuf<int> rowptr, col;
   DevBuf<double> val;
+  DevBuf<double> ds;   // n_vec
 };
 
 void build_numbering(const SysParams& P, const Slab& slab, Numbering& nb);
