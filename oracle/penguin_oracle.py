@@ -402,18 +402,21 @@ def bicgstab_ref(A: sp.csr_matrix, b: np.ndarray, reltol: float = 1e-12, abstol:
     v = np.zeros(n)
     p = np.zeros(n)
     it = 0
+    rho = rhat @ r
+    rhat2 = rhat @ rhat
+    restart = False
     while it < maxiter:
         it += 1
-        rho = rhat @ r
-        if rho == 0.0:
-            break
-        beta = (rho / rho_old) * (alpha / omega)
-        p = r + beta * (p - omega * v)
+        if restart:
+            p = r.copy()
+            restart = False
+        else:
+            beta = (rho / rho_old) * (alpha / omega)
+            p = r + beta * (p - omega * v)
         v = A @ p
         den = rhat @ v
-        if den == 0.0:
-            break
-        alpha = rho / den
+        force = den == 0.0
+        alpha = 0.0 if force else rho / den      # (r̂,Ap) == 0: minimal-residual half step, then restart
         s = r - alpha * v
         t = A @ s
         tt = t @ t
@@ -421,9 +424,17 @@ def bicgstab_ref(A: sp.csr_matrix, b: np.ndarray, reltol: float = 1e-12, abstol:
         x = x + alpha * p + omega * s
         r = s - omega * t
         rho_old = rho
-        rnorm = np.linalg.norm(r)
-        if rnorm <= tol or omega == 0.0:
+        rho = rhat @ r
+        rr = r @ r
+        rnorm = math.sqrt(rr)
+        if rnorm <= tol:
             break
+        if omega == 0.0 or force or rho * rho < 1e-20 * rhat2 * rr:
+            # (r̂,r) collapsed (cos < 1e-10): restart with r̂ := r -- same rule as pg_krylov.hip
+            rhat = r.copy()
+            rho = rhat2 = rr
+            alpha = omega = 1.0
+            restart = True
     return x, it, rnorm
 
 

@@ -20,6 +20,7 @@ using namespace pg;
 namespace {
 
 enum { S_RHO = 0, S_RHO_OLD, S_ALPHA, S_OMEGA, S_BETA, S_RR, S_BB, S_TOL2, S_DONE, S_ITERS, S_RELTOL2, S_ABSTOL2,
+       S_RESTART, S_RHAT2, S_FORCE,
        S_RED0, S_RED1, S_RED2, S_RED3, S_COUNT };
 enum { PH_INIT = 0, PH_BICG_1, PH_BICG_2, PH_BICG_3, PH_CG_INIT, PH_CG_1, PH_CG_2 };
 
@@ -125,9 +126,18 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_init(i64 n, i64 nvec, const doub
 }
 
 __global__ __launch_bounds__(BLOCK) void k_bicg_p(i64 n, const double* __restrict__ sc, const double* __restrict__ r,
-                                                  const double* __restrict__ v, double* __restrict__ p) {
+                                                  const double* __restrict__ v, double* __restrict__ p,
+                                                  double* __restrict__ rhat) {
   if (sc[S_DONE] != 0.0) return;
   const double beta = sc[S_BETA], omega = sc[S_OMEGA];
+  if (sc[S_RESTART] != 0.0) {
+    for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) {
+      const double ri = r[i];
+      rhat[i] = ri;
+      p[i] = ri;
+    }
+    return;
+  }
   for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK)
     p[i] = r[i] + beta * (p[i] - omega * v[i]);
 }
@@ -211,13 +221,16 @@ __device__ inline void derive(int phase, double* sc) {
     case PH_CG_INIT: {
       sc[S_BB] = r0; sc[S_RR] = r0; sc[S_RHO] = r0; sc[S_RHO_OLD] = 1.0;
       sc[S_ALPHA] = 1.0; sc[S_OMEGA] = 1.0; sc[S_BETA] = 0.0; sc[S_ITERS] = 0.0;
+      sc[S_RESTART] = 0.0; sc[S_RHAT2] = r0; sc[S_FORCE] = 0.0;
       const double t2 = sc[S_RELTOL2] * r0;
       sc[S_TOL2] = t2 > sc[S_ABSTOL2] ? t2 : sc[S_ABSTOL2];
       sc[S_DONE] = (r0 <= sc[S_TOL2]) ? 1.0 : 0.0;
       break;
     }
     case PH_BICG_1:
-      if (r0 == 0.0) sc[S_DONE] = 2.0; else sc[S_ALPHA] = sc[S_RHO] / r0;
+      sc[S_RESTART] = 0.0;
+      // (r̂, A p) == 0: take a pure minimal-residual half step (alpha = 0) and restart afterwards
+      if (r0 == 0.0) { sc[S_ALPHA] = 0.0; sc[S_FORCE] = 1.0; } else sc[S_ALPHA] = sc[S_RHO] / r0;
       break;
     case PH_BICG_2:
       sc[S_OMEGA] = r1 != 0.0 ? r0 / r1 : 0.0;
@@ -229,8 +242,14 @@ __device__ inline void derive(int phase, double* sc) {
       sc[S_RR] = r1;
       sc[S_ITERS] += 1.0;
       if (r1 <= sc[S_TOL2]) sc[S_DONE] = 1.0;
-      else if (sc[S_OMEGA] == 0.0 || r0 == 0.0) sc[S_DONE] = 2.0;
-      else sc[S_BETA] = (r0 / rho_old) * (sc[S_ALPHA] / sc[S_OMEGA]);
+      else if (sc[S_OMEGA] == 0.0 || sc[S_FORCE] != 0.0 || r0 * r0 < 1e-20 * sc[S_RHAT2] * r1) {
+        // (r̂,r) collapsed -- r̂ = b is often supported on a few identity rows (T⁰ = 0) and r leaves that
+        // support: restart with r̂ := r (the remedy Eigen's BiCGSTAB uses, with a relative threshold:
+        // cos(r̂,r) < 1e-10).  k_bicg_p copies r into r̂ and p.
+        sc[S_FORCE] = 0.0;
+        sc[S_RESTART] = 1.0;
+        sc[S_RHO] = r1; sc[S_RHAT2] = r1; sc[S_BETA] = 0.0; sc[S_OMEGA] = 1.0; sc[S_ALPHA] = 1.0;
+      } else sc[S_BETA] = (r0 / rho_old) * (sc[S_ALPHA] / sc[S_OMEGA]);
       break;
     }
     case PH_CG_1:
@@ -397,7 +416,7 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
     const int batch = std::min(check_every, maxiter - launched);
     for (int it = 0; it < batch; ++it) {
       if (!cg) {
-        hipLaunchKernelGGL(k_bicg_p, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.r.p, w.v.p, w.p.p);
+        hipLaunchKernelGGL(k_bicg_p, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.r.p, w.v.p, w.p.p, w.rhat.p);
         halo_exchange(nb, slab, w.p.p, st);
         timer.begin(st);
         launch_spmv<1>(A, w.p.p, w.v.p, w.rhat.p, w.partials.p, w.sc.p, G, st);
@@ -429,6 +448,10 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
     PG_HIP(hipStreamSynchronize(st));
     if (w.h_sc[S_DONE] != 0.0 || launched >= maxiter) done = true;
   }
+  if (getenv("PG_DEBUG"))
+    fprintf(stderr, "[pg_krylov] done=%g iters=%g rr=%g tol2=%g rho=%g rho_old=%g alpha=%g omega=%g beta=%g red0=%g red1=%g\n",
+            w.h_sc[S_DONE], w.h_sc[S_ITERS], w.h_sc[S_RR], w.h_sc[S_TOL2], w.h_sc[S_RHO], w.h_sc[S_RHO_OLD], w.h_sc[S_ALPHA],
+            w.h_sc[S_OMEGA], w.h_sc[S_BETA], w.h_sc[S_RED0], w.h_sc[S_RED1]);
   stats.iters = (int)w.h_sc[S_ITERS];
   stats.converged = w.h_sc[S_DONE] == 1.0 ? 1 : 0;
   stats.resnorm = std::sqrt(w.h_sc[S_RR]);

@@ -291,6 +291,28 @@ void ensure_bconst(pg_solver* s, int scheme) {
   s->bconst_dirty = false;
 }
 
+// first right-hand side: b(t = 0) with the constructor scheme (diffusion.jl:202/205, 328); re-run when the host
+// supplies per-cell data after construction but before the first solve
+void build_first_rhs(pg_solver* s) {
+  hipStream_t st = ctx().stream;
+  const i64 n = s->nb.n_own;
+  const SysParams P = make_params(s, s->scheme_ctor);
+  ensure_bconst(s, s->scheme_ctor);
+  DevBuf<double> ypad;
+  if (s->scheme_ctor == PG_SCHEME_CN) {
+    ypad.alloc((i64)s->K * s->Mloc);
+    ypad.zero();
+    apply_rows_padded(P, s->slab, s->T0pad.p, ypad.p);
+  }
+  if (n > 0) {
+    hipLaunchKernelGGL(k_rhs_first, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, st, make_segs(s->nb), n, s->Mloc,
+                       s->scheme_ctor, s->nb.row_cell.p, s->T0pad.p, ypad.p, s->A_ctor.ds.p, s->mass.p, s->bconst.p, s->fixed.p,
+                       s->b.p, s->x.p);
+    PG_HIP(hipGetLastError());
+  }
+  PG_HIP(hipStreamSynchronize(st));
+}
+
 void setup_common(pg_solver* s, const pg_border_desc* borders, int nborders, const double* T0) {
   hipStream_t st = ctx().stream;
   const Slab& slab = s->slab;
@@ -341,21 +363,7 @@ void setup_common(pg_solver* s, const pg_border_desc* borders, int nborders, con
                        kv, s->mass.p, s->fixed.p, s->bcv.p);
     PG_HIP(hipGetLastError());
   }
-  // first right-hand side: b(t = 0) with the constructor scheme (diffusion.jl:202/205, 328)
-  ensure_bconst(s, s->scheme_ctor);
-  DevBuf<double> ypad;
-  if (s->scheme_ctor == PG_SCHEME_CN) {
-    ypad.alloc((i64)s->K * s->Mloc);
-    ypad.zero();
-    apply_rows_padded(P, slab, s->T0pad.p, ypad.p);
-  }
-  if (n > 0) {
-    hipLaunchKernelGGL(k_rhs_first, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, st, make_segs(s->nb), n, s->Mloc,
-                       s->scheme_ctor, s->nb.row_cell.p, s->T0pad.p, ypad.p, s->A_ctor.ds.p, s->mass.p, s->bconst.p, s->fixed.p,
-                       s->b.p, s->x.p);
-    PG_HIP(hipGetLastError());
-  }
-  PG_HIP(hipStreamSynchronize(st));
+  build_first_rhs(s);
   s->t = 0.0;
 }
 
@@ -544,6 +552,7 @@ int32_t pg_solver_set_source(pg_solver* s, int32_t phase, const double* f_n, con
   if (f_n) upload_local(s->f_n[phase], f_n, s->slab);
   if (f_np1) upload_local(s->f_np1[phase], f_np1, s->slab);
   s->bconst_dirty = true;
+  if (!s->initial_done) build_first_rhs(s);
   PG_API_END
 }
 
@@ -554,6 +563,7 @@ int32_t pg_solver_set_interface_value(pg_solver* s, const double* g_n, const dou
   if (g_n) upload_local(s->g_n, g_n, s->slab);
   if (g_np1) upload_local(s->g_np1, g_np1, s->slab);
   s->bconst_dirty = true;
+  if (!s->initial_done) build_first_rhs(s);
   PG_API_END
 }
 
@@ -581,6 +591,7 @@ int32_t pg_solver_set_border_values(pg_solver* s, const double* values) {
   PG_HIP(hipGetLastError());
   PG_HIP(hipStreamSynchronize(ctx().stream));
   s->bconst_dirty = true;
+  if (!s->initial_done) build_first_rhs(s);
   PG_API_END
 }
 

@@ -1,0 +1,114 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/penguin_hip.h declares, its host-only entry points (Mesh, slab partition) reproduce the
+reference's golden vectors, and compute calls fail loudly without a GPU (no CPU fallback)."""
+import ctypes as C
+import json
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+GOLD = json.loads((ROOT / "tests" / "golden" / "reference_pins.json").read_text())
+
+
+@pytest.fixture(scope="module")
+def L():
+    from penguin.jl_amd import _lib
+
+    if not _lib.LIB_PATH.exists():
+        from penguin.jl_amd.build import build_library
+
+        build_library()
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(L):
+    syms = L.declared_symbols()
+    assert len(syms) >= 35
+    out = subprocess.run(["nm", "-D", "--defined-only", str(L.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    missing = [s for s in syms if s not in exported]
+    assert not missing, f"declared in include/penguin_hip.h but not exported: {missing}"
+    lib = L.lib()
+    for s in syms:
+        assert hasattr(lib, s)
+
+
+def test_product_does_not_import_oracle():
+    for p in (ROOT / "penguin").rglob("*.py"):
+        txt = p.read_text()
+        assert "import oracle" not in txt and "from oracle" not in txt, f"{p} must not use the oracle"
+    for p in (ROOT / "penguin").rglob("*.hip"):
+        assert "oracle/" not in p.read_text().replace("oracle/geometry.py", "").replace("the oracle", "")
+
+
+@pytest.mark.parametrize("N", [1, 2, 3])
+def test_mesh_through_abi_matches_reference_vectors(L, N):
+    import penguin.jl_amd as pj
+
+    g = GOLD["mesh"][str(N)]
+    mesh = pj.Mesh((5,) * N, (1.0,) * N, (0.0,) * N)
+    for d in range(N):
+        assert mesh.centers[d].tolist() == g["centers"]
+    assert mesh.nodes[0].tolist() == GOLD["mesh"]["nodes_1d"]
+    assert pj.nC(mesh) == g["nC"]
+    b = mesh.tag.border_cells
+    assert len(b) == g["n_border"]
+    assert [list(b[0][0]), list(b[0][1])] == g["border0"]
+    assert [list(b[1][0]), list(b[1][1])] == g["border1"]
+
+
+def test_mesh_border_order_equals_oracle(L):
+    import penguin.jl_amd as pj
+    from oracle import penguin_oracle as po
+
+    for dims in [(7,), (4, 6), (3, 5, 4), (2, 2, 2), (1, 3)]:
+        N = len(dims)
+        a = pj.Mesh(dims, (1.0,) * N, (0.25,) * N)
+        b = po.Mesh(dims, (1.0,) * N, (0.25,) * N)
+        assert a.tag.border_cells == b.border_cells
+        _, _, key = a._border_arrays()
+        inv = {v: k for k, v in L.PG_KEY.items()}
+        assert [inv[int(k)] for k in key] == [po.classify_boundary_cell_fast(ci, b) for ci, _ in b.border_cells]
+
+
+def test_partition_planes_balances_weights(L):
+    lib = L.lib()
+    w = np.zeros(513, dtype=np.int64)
+    w[128:385] = 1000           # a sphere occupying the middle planes
+    for nr in (1, 2, 4, 8):
+        bounds = np.zeros(nr + 1, dtype=np.int64)
+        L.check(lib.pg_partition_planes(L.iptr(w), C.c_int64(513), C.c_int32(nr), L.iptr(bounds)))
+        assert bounds[0] == 0 and bounds[-1] == 513 and np.all(np.diff(bounds) >= 1)
+        loads = [w[bounds[r]:bounds[r + 1]].sum() for r in range(nr)]
+        assert max(loads) <= 1.25 * (w.sum() / nr) + 1000
+    # more ranks than planes is an error with a message, not a crash
+    bounds = np.zeros(9, dtype=np.int64)
+    assert lib.pg_partition_planes(L.iptr(w), C.c_int64(4), C.c_int32(8), L.iptr(bounds)) != 0
+    buf = C.create_string_buffer(256)
+    lib.pg_last_error(buf, 256)
+    assert b"fewer planes" in buf.value
+
+
+def test_compute_fails_loudly_without_gpu(L):
+    """No CPU fallback: on a box without a HIP device every compute entry point raises."""
+    import penguin.jl_amd as pj
+
+    lib = L.lib()
+    ndev = 0
+    try:
+        hip = C.CDLL("libamdhip64.so")
+        n = C.c_int(0)
+        if hip.hipGetDeviceCount(C.byref(n)) == 0:
+            ndev = n.value
+    except OSError:
+        pass
+    if ndev > 0:
+        pytest.skip("a GPU is visible: the loud-failure path is exercised on CPU-only boxes")
+    mesh = pj.Mesh((4, 4), (1.0, 1.0))
+    with pytest.raises(pj.PenguinHipError, match="no HIP device|not initialised"):
+        pj.Capacity(pj.Sphere((0.5, 0.5), 0.3), mesh)
+    with pytest.raises(pj.PenguinHipError):
+        pj.Capacity(lambda x, y: x + y, mesh)    # arbitrary callables are refused, never evaluated on the CPU

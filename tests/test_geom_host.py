@@ -1,0 +1,113 @@
+"""CPU unit test of the geometry DEVICE functions (penguin/jl_amd/csrc/pg_geom.h) compiled for the host
+with g++ (tests/geom_host.cpp -> tests/_build/libgeom_host.so; test-only build, never loaded by the
+product) against the oracle's independent formulation (oracle/geometry.py)."""
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle.geometry import Ball, MultiBall
+
+ROOT = Path(__file__).resolve().parent.parent
+P = C.POINTER(C.c_double)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    out = ROOT / "tests" / "_build" / "libgeom_host.so"
+    out.parent.mkdir(exist_ok=True)
+    src = ROOT / "tests" / "geom_host.cpp"
+    hdr = ROOT / "penguin" / "jl_amd" / "csrc" / "pg_geom.h"
+    if not out.exists() or out.stat().st_mtime < max(src.stat().st_mtime, hdr.stat().st_mtime):
+        subprocess.run(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", str(out), str(src)], check=True)
+    l = C.CDLL(str(out))
+    l.geom_section.restype = C.c_double
+    return l
+
+
+def cbox(lib, N, centers, r, lo, hi, comp=0, surf=1):
+    out = np.zeros(9)
+    cc = np.ascontiguousarray(centers, dtype=float).reshape(-1)
+    lo = np.ascontiguousarray(lo, dtype=float)
+    hi = np.ascontiguousarray(hi, dtype=float)
+    lib.geom_box(N, len(cc) // N, comp, C.c_double(r), cc.ctypes.data_as(P), lo.ctypes.data_as(P), hi.ctypes.data_as(P), surf,
+                 out.ctypes.data_as(P))
+    return out
+
+
+def csec(lib, N, centers, r, d, s, lo, hi, comp=0):
+    cc = np.ascontiguousarray(centers, dtype=float).reshape(-1)
+    lo = np.ascontiguousarray(lo, dtype=float)
+    hi = np.ascontiguousarray(hi, dtype=float)
+    return lib.geom_section(N, len(cc) // N, comp, C.c_double(r), cc.ctypes.data_as(P), d, C.c_double(s), lo.ctypes.data_as(P),
+                            hi.ctypes.data_as(P))
+
+
+@pytest.mark.parametrize("N,trials", [(1, 300), (2, 1500), (3, 150)])
+def test_box_and_section_measures_match_oracle(lib, N, trials):
+    rng = np.random.default_rng(10 + N)
+    ncut = 0
+    for _ in range(trials):
+        c = rng.uniform(-0.2, 0.2, N)
+        r = rng.uniform(0.5, 1.5)
+        h = rng.choice([0.05, 0.2, 0.01])
+        dirv = rng.normal(size=N)
+        dirv /= np.linalg.norm(dirv)
+        p = c + dirv * r + rng.uniform(-h, h, N) * 0.7
+        lo, hi = p - h / 2, p + h / 2
+        for comp in (0, 1):
+            m = Ball(c, r, complement=bool(comp)).box(list(lo), list(hi))
+            o = cbox(lib, N, c, r, lo, hi, comp)
+            assert int(o[0]) == m.type                                  # bit-exact classification
+            full = h ** N
+            if m.type == -1:
+                ncut += 1
+                assert abs(o[1] - m.vol) <= 2e-11 * full
+                assert abs(o[5] - m.gamma) <= 2e-11 * max(h ** (N - 1), 1.0)
+                # centroids are moment / measure: the absolute moment error (cancellation ~1e-11 full*h) is
+                # amplified by full/vol in nearly empty cells
+                R = r + 0.2
+                if m.vol > 1e-3 * full:
+                    assert np.max(np.abs(o[2:2 + N] - np.array(m.centroid))) <= 2e-15 * R ** (N + 1) / m.vol + 1e-14
+                if m.gamma > 1e-3 * h ** (N - 1):
+                    assert np.max(np.abs(o[6:6 + N] - np.array(m.cgamma))) <= 2e-15 * R ** N / m.gamma + 1e-14
+            else:
+                assert o[1] == m.vol                                    # full/empty: identical expression
+            for d in range(N):
+                s = rng.uniform(lo[d], hi[d])
+                ref = Ball(c, r, complement=bool(comp)).section(d, s, list(lo), list(hi))
+                assert abs(csec(lib, N, c, r, d, s, lo, hi, comp) - ref) <= 1e-11 * max(h ** (N - 1), 1e-300)
+    assert ncut > trials // 4
+
+
+def test_faces_of_full_cells_are_full_bit_for_bit(lib):
+    """H = A D⁻ − D⁻ B vanishes exactly away from the interface only if A == B bitwise there."""
+    rng = np.random.default_rng(3)
+    c, r = np.array([2.01, 2.01, 2.01]), 1.0
+    nodes = 0.0 + (np.arange(33) + 0.5) * (4.0 / 32)
+    for _ in range(300):
+        i = rng.integers(0, 32, 3)
+        lo = nodes[i]
+        hi = nodes[i + 1]
+        o = cbox(lib, 3, c, r, lo, hi)
+        if int(o[0]) != 1:
+            continue
+        for d in range(3):
+            others = [k for k in range(3) if k != d]
+            full = (hi[others[0]] - lo[others[0]]) * (hi[others[1]] - lo[others[1]])
+            assert csec(lib, 3, c, r, d, lo[d], lo, hi) == full
+            assert csec(lib, 3, c, r, d, hi[d], lo, hi) == full
+            assert csec(lib, 3, c, r, d, o[2 + d], lo, hi) == full
+
+
+def test_multiball_picks_the_right_ball(lib):
+    centers = np.array([[2.01, 2.01, 2.01], [2.01, 2.01, 6.01]])
+    mb = MultiBall(centers, 1.0)
+    for z in (1.2, 2.9, 5.1, 6.9, 4.0):
+        lo, hi = [2.0, 2.0, z], [2.1, 2.1, z + 0.1]
+        m = mb.box(lo, hi)
+        o = cbox(lib, 3, centers, 1.0, lo, hi)
+        assert int(o[0]) == m.type
+        assert abs(o[1] - m.vol) <= 1e-14

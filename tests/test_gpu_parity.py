@@ -1,0 +1,420 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Bars (BASELINE.json north_star): bit-exact cut-cell classification and indices; <= 1e-10 relative L2 on
+the temperature field.  Per-cell capacities agree to quadrature / cancellation accuracy (oracle/geometry.py).
+"""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import penguin_oracle as po
+from oracle.geometry import Ball, MultiBall
+from tests.common import oracle_capacity_from_product, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL_T = 1e-10   # north_star tolerance on the temperature field (relative L2)
+
+
+def _caps_close(cap, ocap, N, h):
+    assert np.array_equal(cap.cell_types, ocap.cell_types)                      # bit-exact classification
+    assert np.array_equal(np.flatnonzero(cap.Γ > 0), np.flatnonzero(ocap.G > 0))
+    full = h ** N
+    assert np.max(np.abs(cap.V - ocap.V)) <= 1e-10 * full
+    assert np.max(np.abs(cap.Γ - ocap.G)) <= 1e-10 * max(h ** (N - 1), 1.0)
+    for d in range(N):
+        assert np.max(np.abs(cap.A[d] - ocap.A[d])) <= 1e-10 * max(h ** (N - 1), 1e-300)
+        assert np.max(np.abs(cap.B[d] - ocap.B[d])) <= 1e-7 * max(h ** (N - 1), 1e-300)   # via C_ω of tiny cells
+        assert np.max(np.abs(cap.W[d] - ocap.W[d])) <= 1e-7 * full
+    big = ocap.V > 1e-3 * full
+    assert np.max(np.abs(cap.C_ω[big] - ocap.C_w[big])) <= 1e-8 * h
+
+
+# ------------------------------------------------------------------------------------ K1-K5
+@pytest.mark.parametrize("N,n,L,c,r", [
+    (1, 20, 1.0, (0.5,), 0.3),                    # test/capacity_test.jl:192-226
+    (2, 20, 1.0, (0.5, 0.5), 0.3),                # test/capacity_test.jl:6-84
+    (2, 30, 1.0, (0.51, 0.51), 0.3),              # test/capacity_test.jl:228-258
+    (2, 20, 1.0, (0.0, 0.0), 0.5),                # fluid touching the border (test/operators_test.jl:4-17)
+    (3, 10, 1.0, (0.5, 0.5, 0.5), 0.3),           # test/capacity_test.jl:86-145
+    (3, 12, 4.0, (2.01, 2.01, 2.01), 1.0),        # config 3 shape
+])
+def test_capacity_kernels_match_oracle(pj, N, n, L, c, r):
+    mesh = pj.Mesh((n,) * N, (L,) * N, (0.0,) * N)
+    omesh = po.Mesh((n,) * N, (L,) * N, (0.0,) * N)
+    for comp in (False, True):
+        cap = pj.Capacity(pj.Sphere(c, r, complement=comp), mesh)
+        ocap = po.make_capacity(Ball(c, r, complement=comp), omesh)
+        _caps_close(cap, ocap, N, L / n)
+        cut = np.flatnonzero(cap.cell_types == -1)
+        assert np.array_equal(cut, np.flatnonzero(cap.Γ > 0))                   # reference's own invariant
+        if N > 1:
+            big = ocap.G > 1e-3 * (L / n) ** (N - 1)
+            assert np.max(np.abs(cap.C_γ[big] - ocap.C_g[big])) <= 1e-8 * (L / n)
+
+
+def test_capacity_without_centroids(pj):
+    mesh = pj.Mesh((20,), (1.0,), (0.0,))
+    cap = pj.Capacity(pj.Sphere((0.5,), 0.3), mesh, compute_centroids=False)
+    assert cap.C_γ.shape[0] == 0                                                # isempty(C_γ)
+    assert np.count_nonzero(cap.Γ > 0) == 2
+
+
+def test_capacity_from_arrays_roundtrip(pj):
+    omesh = po.Mesh((16, 16), (4.0, 4.0), (0.0, 0.0))
+    ocap = po.make_capacity(Ball((2.01, 2.01), 1.0), omesh)
+    mesh = pj.Mesh((16, 16), (4.0, 4.0), (0.0, 0.0))
+    cap = pj.Capacity.from_arrays(mesh, ocap.V, ocap.A, ocap.B, ocap.W, ocap.G, ocap.C_w, ocap.C_g, ocap.cell_types)
+    assert np.array_equal(cap.V, ocap.V) and np.array_equal(cap.W[1], ocap.W[1]) and np.array_equal(cap.C_ω, ocap.C_w)
+
+
+# ------------------------------------------------------------------------------------ operators (API)
+def test_operators_match_oracle(pj):
+    n = 20
+    mesh = pj.Mesh((n, n), (1.0, 1.0), (0.0, 0.0))
+    cap = pj.Capacity(pj.Sphere((0.0, 0.0), 0.5), mesh)
+    op = pj.DiffusionOps(cap)
+    M = (n + 1) ** 2
+    assert op.size == (n + 1, n + 1)
+    assert (op.G.T @ op.Winv @ op.G).shape == (M, M)                            # test/operators_test.jl:41
+    ones = np.ones(2 * M)
+    assert pj.grad(op, ones)[1] == 0.0                                          # test/operators_test.jl:14
+    assert pj.div(op, np.ones(2 * M), np.ones(2 * M))[1] == 0.0                 # :16
+    # against the Kronecker construction of the oracle, from the SAME capacities
+    ocap = oracle_capacity_from_product(cap, po.Mesh((n, n), (1.0, 1.0), (0.0, 0.0)))
+    oop = po.make_diffusion_ops(ocap)
+    assert abs(op.G - oop.G.tocsc()).max() == 0.0
+    assert abs(op.H - oop.H.tocsc()).max() == 0.0
+    assert abs(op.Winv - oop.Winv.tocsc()).max() == 0.0
+    rng = np.random.default_rng(0)
+    p = rng.normal(size=2 * M)
+    assert np.allclose(pj.grad(op, p), po.grad(oop, p), rtol=1e-12, atol=1e-12 * np.abs(po.grad(oop, p)).max())
+    qw, qg = rng.normal(size=2 * M), rng.normal(size=2 * M)
+    assert np.allclose(pj.div(op, qw, qg), po.div(oop, qw, qg), rtol=1e-12, atol=1e-12 * np.abs(po.div(oop, qw, qg)).max())
+
+
+# ------------------------------------------------------------------------------------ K7/K9/K10 + time loop
+def _mono_pair(pj, N, n, L, c, r, bc_i, bc_i_o, borders, borders_o, dt, u0, scheme0, f=None, D=None, comp=False):
+    mesh = pj.Mesh((n,) * N, (L,) * N, (0.0,) * N)
+    omesh = po.Mesh((n,) * N, (L,) * N, (0.0,) * N)
+    cap = pj.Capacity(pj.Sphere(c, r, complement=comp), mesh)
+    ocap = oracle_capacity_from_product(cap, omesh)          # same capacities => isolates the solve path
+    op, oop = pj.DiffusionOps(cap), po.make_diffusion_ops(ocap)
+    f = f or (lambda x, y, z, t: 0.0)
+    D = D or (lambda x, y, z: 1.0)
+    ph, oph = pj.Phase(cap, op, f, D), po.Phase(ocap, oop, f, D)
+    s = pj.DiffusionUnsteadyMono(ph, pj.BorderConditions(borders), bc_i, dt, u0, scheme0)
+    so = po.DiffusionUnsteadyMono(oph, po.BorderConditions(borders_o), bc_i_o, dt, u0, scheme0)
+    return (s, ph, pj.BorderConditions(borders), bc_i), (so, oph, po.BorderConditions(borders_o), bc_i_o)
+
+
+def _check_system(s, so):
+    """Reduced system of the constructor: same active index set (bit-exact), same matrix, same rhs."""
+    A, b, idx = s.system(0)
+    Ar, br, oidx = po.remove_zero_rows_cols(so.A, so.b)
+    assert np.array_equal(idx, oidx)                                            # bit-exact indices
+    A = A[:, : len(idx)]
+    scale = abs(Ar).max()
+    assert abs(A - Ar).max() <= 1e-12 * scale
+    assert np.max(np.abs(b - br)) <= 1e-12 * max(np.max(np.abs(br)), 1e-300)
+    return idx
+
+
+HEAT_BORDERS = ("left", "right", "top", "bottom")
+
+
+@pytest.mark.parametrize("scheme0,scheme", [("BE", "BE"), ("BE", "CN"), ("CN", "CN")])
+def test_heat_monophasic_reference_test(pj, scheme0, scheme):
+    """test/solver/diffusion_test.jl:57-80 (20^2, circle r=1, Dirichlet(1) interface) on both schemes."""
+    n = 20
+    M = (n + 1) ** 2
+    u0 = np.concatenate([np.zeros(M), np.ones(M)])
+    dt = 0.25 * (4.0 / n) ** 2
+    (s, ph, bcb, bci), (so, oph, obcb, obci) = _mono_pair(
+        pj, 2, n, 4.0, (2.0, 2.0), 1.0, pj.Dirichlet(1.0), po.Dirichlet(1.0),
+        {k: pj.Dirichlet(0.0) for k in HEAT_BORDERS}, {k: po.Dirichlet(0.0) for k in HEAT_BORDERS}, dt, u0, scheme0)
+    _check_system(s, so)
+    pj.solve_DiffusionUnsteadyMono_b(s, ph, dt, 0.05, bcb, bci, scheme, reltol=1e-13)
+    po.solve_DiffusionUnsteadyMono(so, oph, dt, 0.05, obcb, obci, scheme, method="\\")
+    assert len(s.states) == len(so.states)                                     # same `while t < Tend` step count
+    for a, b in zip(s.states, so.states):
+        assert rel_l2(a, b) <= TOL_T
+    if scheme == "BE":
+        assert s.x[M:].max() == pytest.approx(1.0, abs=1e-2)                   # the reference's assertion
+
+
+def test_config1_function_valued_interface(pj):
+    """examples/2D/Diffusion/Heat.jl (config 1): 80^2, centre (2.01,2.01), Dirichlet((x,y,z,t)->sin(pi x)sin(pi y))."""
+    n = 80
+    M = (n + 1) ** 2
+    g = lambda x, y, z, t: np.sin(np.pi * x) * np.sin(np.pi * y)
+    u0 = np.concatenate([np.zeros(M), np.ones(M)])
+    dt = 0.25 * (4.0 / n) ** 2
+    (s, ph, bcb, bci), (so, oph, obcb, obci) = _mono_pair(
+        pj, 2, n, 4.0, (2.01, 2.01), 1.0, pj.Dirichlet(g), po.Dirichlet(g),
+        {k: pj.Dirichlet(0.0) for k in HEAT_BORDERS}, {k: po.Dirichlet(0.0) for k in HEAT_BORDERS}, dt, u0, "BE")
+    idx = _check_system(s, so)
+    assert 1000 < len(idx) < 2500
+    pj.solve_DiffusionUnsteadyMono_b(s, ph, dt, 0.01, bcb, bci, "BE", reltol=1e-13)
+    po.solve_DiffusionUnsteadyMono(so, oph, dt, 0.01, obcb, obci, "BE", method="\\")
+    assert len(s.states) == len(so.states) == 17
+    assert rel_l2(s.x, so.x) <= TOL_T
+    assert rel_l2(s.states[0], so.states[0]) <= TOL_T
+
+
+def test_time_dependent_data_and_variable_coefficient(pj):
+    """f(x,y,z,t), g(x,y,z,t), border value(x,y,t) all time dependent + D(x,y,z): host-driven loop (a11, a14)."""
+    n = 24
+    M = (n + 1) ** 2
+    f = lambda x, y, z, t: 1.0 + t * x
+    D = lambda x, y, z: 1.0 + 0.3 * x + 0.1 * y
+    g = lambda x, y, z, t: np.cos(x) * (1.0 + t)
+    bv = lambda x, y, t: 0.5 * x + t
+    u0 = np.concatenate([0.2 * np.ones(M), np.ones(M)])
+    dt = 0.4 * (4.0 / n) ** 2
+    for scheme in ("BE", "CN"):
+        (s, ph, bcb, bci), (so, oph, obcb, obci) = _mono_pair(
+            pj, 2, n, 4.0, (2.01, 2.01), 1.7, pj.Dirichlet(g), po.Dirichlet(g),
+            {k: pj.Dirichlet(bv) for k in HEAT_BORDERS}, {k: po.Dirichlet(bv) for k in HEAT_BORDERS}, dt, u0, scheme,
+            f=f, D=D)
+        _check_system(s, so)
+        pj.solve_DiffusionUnsteadyMono_b(s, ph, dt, 6 * dt, bcb, bci, scheme, reltol=1e-13)
+        po.solve_DiffusionUnsteadyMono(so, oph, dt, 6 * dt, obcb, obci, scheme, method="\\")
+        assert len(s.states) == len(so.states)
+        assert rel_l2(s.x, so.x) <= TOL_T
+
+
+@pytest.mark.parametrize("bc_kind", ["robin", "neumann"])
+def test_robin_and_neumann_interface(pj, bc_kind):
+    """Iᵦ != 0: blocks 3-4 live, genuinely 2x2 non-symmetric system."""
+    n = 24
+    M = (n + 1) ** 2
+    u0 = np.concatenate([np.ones(M), np.ones(M)])
+    dt = 0.25 * (4.0 / n) ** 2
+    if bc_kind == "robin":
+        bi, boi = pj.Robin(1.0, 0.5, 2.0), po.Robin(1.0, 0.5, 2.0)
+    else:
+        bi, boi = pj.Neumann(0.3), po.Neumann(0.3)
+    (s, ph, bcb, bci), (so, oph, obcb, obci) = _mono_pair(
+        pj, 2, n, 4.0, (2.01, 2.01), 1.0, bi, boi, {k: pj.Dirichlet(0.0) for k in HEAT_BORDERS},
+        {k: po.Dirichlet(0.0) for k in HEAT_BORDERS}, dt, u0, "BE")
+    _check_system(s, so)
+    pj.solve_DiffusionUnsteadyMono_b(s, ph, dt, 5 * dt, bcb, bci, "CN", reltol=1e-13)
+    po.solve_DiffusionUnsteadyMono(so, oph, dt, 5 * dt, obcb, obci, "CN", method="\\")
+    assert rel_l2(s.x, so.x) <= 1e-9
+
+
+def test_fluid_touching_border_and_unknown_keys(pj):
+    """Heat_Nobody-like: fluid reaches the border cells; :front/:back keys are silently ignored."""
+    n = 16
+    M = (n + 1) ** 2
+    u0 = np.concatenate([np.zeros(M), np.zeros(M)])
+    dt = 0.25 * (4.0 / n) ** 2
+    borders = {"left": pj.Dirichlet(1.0), "right": pj.Dirichlet(0.0), "front": pj.Dirichlet(5.0)}
+    oborders = {"left": po.Dirichlet(1.0), "right": po.Dirichlet(0.0), "front": po.Dirichlet(5.0)}
+    (s, ph, bcb, bci), (so, oph, obcb, obci) = _mono_pair(
+        pj, 2, n, 4.0, (2.0, 2.0), 3.5, pj.Dirichlet(0.5), po.Dirichlet(0.5), borders, oborders, dt, u0, "BE")
+    _check_system(s, so)
+    pj.solve_DiffusionUnsteadyMono_b(s, ph, dt, 4 * dt, bcb, bci, "BE", reltol=1e-13)
+    po.solve_DiffusionUnsteadyMono(so, oph, dt, 4 * dt, obcb, obci, "BE", method="\\")
+    assert rel_l2(s.x, so.x) <= TOL_T
+
+
+def test_periodic_border_2d(pj):
+    """test/solver_test.jl:78-171 shape: Periodic left/right."""
+    n = 16
+    M = (n + 1) ** 2
+    u0 = np.concatenate([np.zeros(M), np.zeros(M)])
+    dt = 0.25 * (4.0 / n) ** 2
+    borders = {"left": pj.Periodic(), "right": pj.Periodic(), "top": pj.Dirichlet(1.0), "bottom": pj.Dirichlet(0.0)}
+    oborders = {"left": po.Periodic(), "right": po.Periodic(), "top": po.Dirichlet(1.0), "bottom": po.Dirichlet(0.0)}
+    (s, ph, bcb, bci), (so, oph, obcb, obci) = _mono_pair(
+        pj, 2, n, 4.0, (2.0, 2.0), 3.5, pj.Dirichlet(0.5), po.Dirichlet(0.5), borders, oborders, dt, u0, "BE")
+    _check_system(s, so)
+    pj.solve_DiffusionUnsteadyMono_b(s, ph, dt, 3 * dt, bcb, bci, "BE", reltol=1e-13)
+    po.solve_DiffusionUnsteadyMono(so, oph, dt, 3 * dt, obcb, obci, "BE", method="\\")
+    assert rel_l2(s.x, so.x) <= 1e-9
+
+
+def test_unsteady_1d_with_neumann_border(pj):
+    """1-D: only :bottom/:top exist; Neumann border rows are 1-D only (solver.jl:471-496)."""
+    n = 40
+    u0 = np.concatenate([np.ones(n + 1), np.ones(n + 1)])
+    dt = 0.5 * (1.0 / n) ** 2
+    borders = {"bottom": pj.Neumann(0.0), "top": pj.Dirichlet(2.0)}
+    oborders = {"bottom": po.Neumann(0.0), "top": po.Dirichlet(2.0)}
+    (s, ph, bcb, bci), (so, oph, obcb, obci) = _mono_pair(
+        pj, 1, n, 1.0, (0.5,), 0.9, pj.Dirichlet(0.0), po.Dirichlet(0.0), borders, oborders, dt, u0, "BE")
+    _check_system(s, so)
+    pj.solve_DiffusionUnsteadyMono_b(s, ph, dt, 5 * dt, bcb, bci, "BE", reltol=1e-13)
+    po.solve_DiffusionUnsteadyMono(so, oph, dt, 5 * dt, obcb, obci, "BE", method="\\")
+    assert rel_l2(s.x, so.x) <= TOL_T
+
+
+def test_unsteady_1d_zero_stays_zero(pj):
+    """test/convergence_test.jl:72-98."""
+    n = 40
+    dt = 0.5 * (1.0 / n) ** 2
+    (s, ph, bcb, bci), _ = _mono_pair(
+        pj, 1, n, 1.0, (0.5,), 0.25, pj.Dirichlet(0.0), po.Dirichlet(0.0), {"top": pj.Dirichlet(0.0), "bottom": pj.Dirichlet(0.0)},
+        {"top": po.Dirichlet(0.0), "bottom": po.Dirichlet(0.0)}, dt, np.zeros(2 * (n + 1)), "BE")
+    pj.solve_DiffusionUnsteadyMono_b(s, ph, dt, 5 * dt, bcb, bci, "BE")
+    assert np.max(np.abs(s.x)) < 1e-8
+
+
+def test_heat3d_config3_shape(pj):
+    """benchmark/Heat3D.jl shape (config 3/4) at 16^3: BE first solve then CN, 4 border keys."""
+    n = 16
+    M = (n + 1) ** 3
+    u0 = np.zeros(2 * M)
+    dt = 0.75 * (4.0 / n) ** 2
+    keys = ("left", "right", "top", "bottom")
+    (s, ph, bcb, bci), (so, oph, obcb, obci) = _mono_pair(
+        pj, 3, n, 4.0, (2.01, 2.01, 2.01), 1.0, pj.Dirichlet(1.0), po.Dirichlet(1.0),
+        {k: pj.Dirichlet(1.0) for k in keys}, {k: po.Dirichlet(1.0) for k in keys}, dt, u0, "BE")
+    idx = _check_system(s, so)
+    pj.solve_DiffusionUnsteadyMono_b(s, ph, dt, 4 * dt, bcb, bci, "CN", reltol=1e-13)
+    po.solve_DiffusionUnsteadyMono(so, oph, dt, 4 * dt, obcb, obci, "CN", method="\\")
+    assert len(s.states) == len(so.states)
+    for a, b in zip(s.states, so.states):
+        assert rel_l2(a, b) <= TOL_T
+    # eliminated unknowns come back as exact zeros (solver.jl:186-187)
+    mask = np.ones(2 * M, dtype=bool)
+    mask[idx] = False
+    assert np.all(s.x[mask] == 0.0)
+
+
+def test_cg_method_on_symmetric_problem(pj):
+    """IterativeSolvers.cg path (method=cg): a body covering the whole box and no border rows give the SPD
+    system V + dt GᵀWꜝG, the case CG is admissible for."""
+    n = 20
+    M = (n + 1) ** 2
+    rng = np.random.default_rng(5)
+    u0 = np.concatenate([rng.uniform(0.0, 1.0, M), np.zeros(M)])
+    dt = 0.25 * (4.0 / n) ** 2
+    (s, ph, bcb, bci), (so, oph, obcb, obci) = _mono_pair(
+        pj, 2, n, 4.0, (2.0, 2.0), 10.0, pj.Dirichlet(1.0), po.Dirichlet(1.0), {}, {}, dt, u0, "BE")
+    _check_system(s, so)
+    pj.solve_DiffusionUnsteadyMono_b(s, ph, dt, 3 * dt, bcb, bci, "BE", method="cg", reltol=1e-13)
+    po.solve_DiffusionUnsteadyMono(so, oph, dt, 3 * dt, obcb, obci, "BE", method="\\")
+    assert rel_l2(s.x, so.x) <= TOL_T
+
+
+# ------------------------------------------------------------------------------------ diphasic (config 5)
+@pytest.mark.parametrize("scheme0,scheme", [("BE", "BE"), ("BE", "CN")])
+def test_diphasic_heat_2d(pj, scheme0, scheme):
+    """benchmark/Heat_2ph_2D.jl shape (config 5) at 32^2: ScalarJump(1,He,0), FluxJump(1,1,0), no borders."""
+    n, Lx, c, r = 32, 8.0, (4.0, 4.0), 2.0
+    M = (n + 1) ** 2
+    mesh = pj.Mesh((n, n), (Lx, Lx), (0.0, 0.0))
+    omesh = po.Mesh((n, n), (Lx, Lx), (0.0, 0.0))
+    cap1 = pj.Capacity(pj.Sphere(c, r), mesh)
+    cap2 = pj.Capacity(pj.Sphere(c, r, complement=True), mesh)
+    oc1, oc2 = oracle_capacity_from_product(cap1, omesh), oracle_capacity_from_product(cap2, omesh)
+    op1, op2 = pj.DiffusionOps(cap1), pj.DiffusionOps(cap2)
+    oo1, oo2 = po.make_diffusion_ops(oc1), po.make_diffusion_ops(oc2)
+    f = lambda x, y, z, t: 0.0
+    D1 = lambda x, y, z: 1.0
+    D2 = lambda x, y, z: 2.0
+    p1, p2 = pj.Phase(cap1, op1, f, D1), pj.Phase(cap2, op2, f, D2)
+    q1, q2 = po.Phase(oc1, oo1, f, D1), po.Phase(oc2, oo2, f, D2)
+    ic = pj.InterfaceConditions(pj.ScalarJump(1.0, 0.5, 0.0), pj.FluxJump(1.0, 1.0, 0.0))
+    oic = po.InterfaceConditions(po.ScalarJump(1.0, 0.5, 0.0), po.FluxJump(1.0, 1.0, 0.0))
+    bcb, obcb = pj.BorderConditions({}), po.BorderConditions({})
+    u0 = np.concatenate([np.ones(M), np.ones(M), np.zeros(M), np.zeros(M)])
+    dt = 0.5 * (Lx / n) ** 2
+    s = pj.DiffusionUnsteadyDiph(p1, p2, bcb, ic, dt, u0, scheme0)
+    so = po.DiffusionUnsteadyDiph(q1, q2, obcb, oic, dt, u0, scheme0)
+    _check_system(s, so)
+    pj.solve_DiffusionUnsteadyDiph_b(s, p1, p2, dt, 5 * dt, bcb, ic, scheme, reltol=1e-13)
+    po.solve_DiffusionUnsteadyDiph(so, q1, q2, dt, 5 * dt, obcb, oic, scheme, method="\\")
+    assert len(s.states) == len(so.states)
+    assert rel_l2(s.x, so.x) <= 1e-9
+
+
+def test_diphasic_with_borders(pj):
+    """BC_border_diph!: rows of both phases, skipped where the phase is absent (solver.jl:560-578)."""
+    n, Lx, c, r = 24, 4.0, (2.0, 2.0), 1.0
+    M = (n + 1) ** 2
+    mesh, omesh = pj.Mesh((n, n), (Lx, Lx)), po.Mesh((n, n), (Lx, Lx))
+    cap1, cap2 = pj.Capacity(pj.Sphere(c, r), mesh), pj.Capacity(pj.Sphere(c, r, complement=True), mesh)
+    oc1, oc2 = oracle_capacity_from_product(cap1, omesh), oracle_capacity_from_product(cap2, omesh)
+    f = lambda x, y, z, t: 1.0
+    D = lambda x, y, z: 1.0
+    p1, p2 = pj.Phase(cap1, pj.DiffusionOps(cap1), f, D), pj.Phase(cap2, pj.DiffusionOps(cap2), f, D)
+    q1, q2 = po.Phase(oc1, po.make_diffusion_ops(oc1), f, D), po.Phase(oc2, po.make_diffusion_ops(oc2), f, D)
+    ic = pj.InterfaceConditions(pj.ScalarJump(1.0, 1.0, 0.0), pj.FluxJump(1.0, 1.0, 0.0))
+    oic = po.InterfaceConditions(po.ScalarJump(1.0, 1.0, 0.0), po.FluxJump(1.0, 1.0, 0.0))
+    bcb = pj.BorderConditions({k: pj.Dirichlet(0.0) for k in HEAT_BORDERS})
+    obcb = po.BorderConditions({k: po.Dirichlet(0.0) for k in HEAT_BORDERS})
+    u0 = np.zeros(4 * M)
+    dt = 0.5 * (Lx / n) ** 2
+    s = pj.DiffusionUnsteadyDiph(p1, p2, bcb, ic, dt, u0, "BE")
+    so = po.DiffusionUnsteadyDiph(q1, q2, obcb, oic, dt, u0, "BE")
+    _check_system(s, so)
+    pj.solve_DiffusionUnsteadyDiph_b(s, p1, p2, dt, 4 * dt, bcb, ic, "BE", reltol=1e-13)
+    po.solve_DiffusionUnsteadyDiph(so, q1, q2, dt, 4 * dt, obcb, oic, "BE", method="\\")
+    assert rel_l2(s.x, so.x) <= 1e-9
+
+
+# ------------------------------------------------------------------------------------ end to end incl. geometry
+def test_end_to_end_own_geometry_both_sides(pj):
+    """Everything from the level set on: GPU capacities -> GPU solve vs oracle capacities -> oracle solve."""
+    n = 12
+    M = (n + 1) ** 3
+    mesh, omesh = pj.Mesh((n,) * 3, (4.0,) * 3), po.Mesh((n,) * 3, (4.0,) * 3)
+    cap, ocap = pj.Capacity(pj.Sphere((2.01,) * 3, 1.0), mesh), po.make_capacity(Ball((2.01,) * 3, 1.0), omesh)
+    f = lambda x, y, z, t: 0.0
+    D = lambda x, y, z: 1.0
+    ph, oph = pj.Phase(cap, pj.DiffusionOps(cap), f, D), po.Phase(ocap, po.make_diffusion_ops(ocap), f, D)
+    keys = ("left", "right", "top", "bottom")
+    bcb, obcb = pj.BorderConditions({k: pj.Dirichlet(1.0) for k in keys}), po.BorderConditions({k: po.Dirichlet(1.0) for k in keys})
+    dt = 0.75 * (4.0 / n) ** 2
+    s = pj.DiffusionUnsteadyMono(ph, bcb, pj.Dirichlet(1.0), dt, np.zeros(2 * M), "BE")
+    so = po.DiffusionUnsteadyMono(oph, obcb, po.Dirichlet(1.0), dt, np.zeros(2 * M), "BE")
+    _, _, idx = s.system(0)
+    _, _, oidx = po.remove_zero_rows_cols(so.A, so.b)
+    assert np.array_equal(idx, oidx)
+    pj.solve_DiffusionUnsteadyMono_b(s, ph, dt, 3 * dt, bcb, pj.Dirichlet(1.0), "CN", reltol=1e-13)
+    po.solve_DiffusionUnsteadyMono(so, oph, dt, 3 * dt, obcb, po.Dirichlet(1.0), "CN", method="\\")
+    assert rel_l2(s.x, so.x) <= 1e-8    # geometry formulations differ at the 1e-12 level (parity unpinned vs libvofi)
+
+
+# ------------------------------------------------------------------------------------ full-size properties
+def test_full_size_properties_256(pj):
+    """BASELINE config 3 size (256^3): size-independent properties the domain offers."""
+    n = 256
+    mesh = pj.Mesh((n,) * 3, (4.0,) * 3)
+    cap = pj.Capacity(pj.Sphere((2.01,) * 3, 1.0), mesh)
+    V, G, ct = cap.V, cap.Γ, cap.cell_types
+    assert V.sum() == pytest.approx(4.0 / 3.0 * math.pi, rel=1e-11)             # volumes tile the ball
+    assert G.sum() == pytest.approx(4.0 * math.pi, rel=1e-10)                   # interface pieces tile the sphere
+    for d in range(3):
+        assert cap.W[d].sum() == pytest.approx(V.sum(), rel=1e-11)              # staggered volumes tile it too
+    assert np.array_equal(np.flatnonzero(ct == -1), np.flatnonzero(G > 0))      # cut set == {Γ>0}
+    h = 4.0 / n
+    full = ct == 1
+    assert np.all(V[full] == V[full][0])                                        # full cells: identical expression
+    for d in range(3):
+        assert np.all(cap.A[d][full] == cap.B[d][full])                         # => H vanishes exactly in the bulk
+    M = (n + 1) ** 3
+    ph = pj.Phase(cap, pj.DiffusionOps(cap), lambda x, y, z, t: 0.0, lambda x, y, z: 1.0)
+    keys = ("left", "right", "top", "bottom")
+    bcb = pj.BorderConditions({k: pj.Dirichlet(1.0) for k in keys})
+    dt = 0.75 * h ** 2
+    s = pj.DiffusionUnsteadyMono(ph, bcb, pj.Dirichlet(1.0), dt, np.zeros(2 * M), "BE")
+    info = s.system_info(0)
+    assert info.n_gamma == np.count_nonzero(G > 0)
+    assert info.n_omega >= np.count_nonzero(V > 0)
+    pj.solve_DiffusionUnsteadyMono_b(s, ph, dt, 3 * dt, bcb, pj.Dirichlet(1.0), "CN", save_states=False)
+    Tw = s.x[:M]
+    fluid = V > 0
+    assert Tw[fluid].min() > -1e-9 and Tw[fluid].max() < 1.0 + 1e-9             # discrete maximum principle
+    assert np.all(s.x[M:][G > 0] == pytest.approx(1.0, abs=1e-9))               # Dirichlet interface value
+    # linearity: doubling the interface and border data doubles the solution
+    s2 = pj.DiffusionUnsteadyMono(ph, pj.BorderConditions({k: pj.Dirichlet(2.0) for k in keys}), pj.Dirichlet(2.0), dt,
+                                  np.zeros(2 * M), "BE")
+    pj.solve_DiffusionUnsteadyMono_b(s2, ph, dt, 3 * dt, pj.BorderConditions({k: pj.Dirichlet(2.0) for k in keys}),
+                                     pj.Dirichlet(2.0), "CN", save_states=False)
+    assert rel_l2(s2.x, 2.0 * s.x) <= 1e-9

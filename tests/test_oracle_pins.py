@@ -1,0 +1,197 @@
+"""Pin the ORACLE on the reference's own golden vectors and known answers (CPU, no GPU).
+
+Every expected value below is data taken from the reference's tests / examples (cited per test);
+tests/golden/reference_pins.json holds the same vectors as a committed fixture.
+"""
+import json
+import math
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import penguin_oracle as po
+from oracle.geometry import Ball
+
+GOLD = json.loads((Path(__file__).parent / "golden" / "reference_pins.json").read_text())
+
+
+# ---------------------------------------------------------------- test/mesh_test.jl:4-55
+@pytest.mark.parametrize("N", [1, 2, 3])
+def test_mesh_centers_and_borders(N):
+    g = GOLD["mesh"][str(N)]
+    mesh = po.Mesh((5,) * N, (1.0,) * N, (0.0,) * N)
+    for d in range(N):
+        assert mesh.centers[d].tolist() == g["centers"]          # exact ==, incl. 0.6000000000000001
+    assert mesh.nC() == g["nC"]
+    assert len(mesh.border_cells) == g["n_border"]               # 2 / 16 / 98
+    assert [list(mesh.border_cells[0][0]), list(mesh.border_cells[0][1])] == g["border0"]
+    assert [list(mesh.border_cells[1][0]), list(mesh.border_cells[1][1])] == g["border1"]
+
+
+def test_mesh_4d_border_count_formula():
+    # test/mesh_test.jl:52: 544 border cells for 5^4 = 5^4 - 3^4
+    assert 5 ** 4 - 3 ** 4 == GOLD["mesh"]["4"]["n_border"]
+
+
+# ---------------------------------------------------------------- test/mesh_test.jl:57-80
+def test_mesh_nodes_half_cell_shift():
+    mesh = po.Mesh((5,), (1.0,), (0.0,))
+    assert mesh.nodes[0].tolist() == GOLD["mesh"]["nodes_1d"]    # [0.1, 0.30000000000000004, ...]
+
+
+# ---------------------------------------------------------------- test/operators_test.jl:4-56
+def test_gradient_divergence_of_constants():
+    mesh = po.Mesh((20, 20), (1.0, 1.0), (0.0, 0.0))
+    cap = po.make_capacity(Ball((0.0, 0.0), 0.5), mesh)
+    op = po.make_diffusion_ops(cap)
+    n2 = 2 * 21 * 21
+    assert po.grad(op, np.ones(n2))[1] == 0.0                    # grad[2] == 0.0
+    assert po.div(op, np.ones(n2), np.ones(n2))[1] == 0.0        # div[2] == 0.0
+
+
+@pytest.mark.parametrize("N,n", [(1, 20), (2, 20), (3, 8)])
+def test_operator_sizes(N, n):
+    mesh = po.Mesh((n,) * N, (1.0,) * N, (0.0,) * N)
+    cap = po.make_capacity(Ball((0.0,) * N, 0.5), mesh)
+    op = po.make_diffusion_ops(cap)
+    M = (n + 1) ** N
+    assert (op.G.T @ op.Winv @ op.G).shape == (M, M)
+    assert op.size == (n + 1,) * N
+    assert op.G.shape == (N * M, M) and op.H.shape == (N * M, M)
+
+
+def test_delta_m_last_row_quirk():
+    # src/operators.jl:9: D[n,n] = 0  =>  (D p)[n] = -p[n-1]
+    D = po.delta_m(5).toarray()
+    assert D[4, 4] == 0.0 and D[4, 3] == -1.0 and D[0, 0] == 1.0
+
+
+# ---------------------------------------------------------------- test/capacity_test.jl
+def test_capacity_circle_known_measures():
+    # :6-84  circle r = 0.3 on 20^2: sum V ~ pi r^2, sum Gamma ~ 2 pi r (reference: rtol 0.05 / 0.1)
+    mesh = po.Mesh((20, 20), (1.0, 1.0), (0.0, 0.0))
+    cap = po.make_capacity(Ball((0.5, 0.5), 0.3), mesh)
+    assert cap.V.sum() == pytest.approx(math.pi * 0.09, rel=1e-12)
+    assert cap.G.sum() == pytest.approx(2 * math.pi * 0.3, rel=1e-12)
+    cut = np.flatnonzero(cap.cell_types == -1)
+    d = np.linalg.norm(cap.C_g[cut] - 0.5, axis=1)
+    assert np.all(np.abs(d - 0.3) < 0.05)                        # :81 interface centroids on the circle
+
+
+def test_capacity_cut_set_equals_gamma_support():
+    # :228-258 circle r=0.3 @ (0.51,0.51) on 30^2: sort(findall(cell_types .== -1)) == sort(findall(diag(Gamma) .> 0))
+    mesh = po.Mesh((30, 30), (1.0, 1.0), (0.0, 0.0))
+    cap = po.make_capacity(Ball((0.51, 0.51), 0.3), mesh)
+    assert np.array_equal(np.flatnonzero(cap.cell_types == -1), np.flatnonzero(cap.G > 0))
+    cut = np.flatnonzero(cap.cell_types == -1)
+    assert len(cut) > 0
+    d = np.linalg.norm(cap.C_g[cut] - 0.51, axis=1)
+    assert np.all(np.abs(d - 0.3) < 0.05)
+
+
+def test_capacity_1d_two_interfaces():
+    # :192-226 |x - 0.5| - 0.3 on 20 cells: exactly 2 cells with Gamma > 0, centroids near 0.2 / 0.8
+    mesh = po.Mesh((20,), (1.0,), (0.0,))
+    cap = po.make_capacity(Ball((0.5,), 0.3), mesh)
+    has = np.flatnonzero(cap.G > 0)
+    assert len(has) == 2
+    cg = cap.C_g[has, 0]
+    assert any(abs(c - 0.2) < 0.05 for c in cg) and any(abs(c - 0.8) < 0.05 for c in cg)
+    cap2 = po.make_capacity(Ball((0.5,), 0.3), mesh, compute_centroids=False)
+    assert cap2.C_g.shape[0] == 0                                 # isempty(C_γ)
+
+
+def test_capacity_sphere_known_measures():
+    # :86-145 sphere r = 0.3 on 10^3
+    mesh = po.Mesh((10, 10, 10), (1.0, 1.0, 1.0), (0.0, 0.0, 0.0))
+    cap = po.make_capacity(Ball((0.5, 0.5, 0.5), 0.3), mesh)
+    assert cap.V.sum() == pytest.approx(4 / 3 * math.pi * 0.027, rel=1e-11)
+    assert cap.G.sum() == pytest.approx(4 * math.pi * 0.09, rel=1e-11)
+    for d in range(3):
+        assert cap.W[d].sum() == pytest.approx(cap.V.sum(), rel=1e-11)   # staggered volumes tile the fluid
+    assert np.array_equal(np.flatnonzero(cap.cell_types == -1), np.flatnonzero(cap.G > 0))
+
+
+# ---------------------------------------------------------------- test/solver/diffusion_test.jl:57-80
+def _heat_mono(n, method):
+    mesh = po.Mesh((n, n), (4.0, 4.0), (0.0, 0.0))
+    cap = po.make_capacity(Ball((2.0, 2.0), 1.0), mesh)
+    op = po.make_diffusion_ops(cap)
+    ph = po.Phase(cap, op, lambda x, y, z, t: 0.0, lambda x, y, z: 1.0)
+    bcb = po.BorderConditions({k: po.Dirichlet(0.0) for k in ("left", "right", "top", "bottom")})
+    M = (n + 1) ** 2
+    u0 = np.concatenate([np.zeros(M), np.ones(M)])
+    dt = 0.25 * (4.0 / n) ** 2
+    s = po.DiffusionUnsteadyMono(ph, bcb, po.Dirichlet(1.0), dt, u0, "BE")
+    po.solve_DiffusionUnsteadyMono(s, ph, dt, 0.01, bcb, po.Dirichlet(1.0), "BE", method=method, **({} if method == "\\" else {"reltol": 1e-13}))
+    return s, M
+
+
+def test_heat_monophasic_known_answer():
+    s, M = _heat_mono(20, "\\")
+    assert s.x[M:].max() == pytest.approx(1.0, abs=1e-2)          # maximum(ug) ≈ 1.0 atol=1e-2
+    assert len(s.states) == 2
+    s2, _ = _heat_mono(20, "bicgstab")
+    assert np.linalg.norm(s2.x - s.x) <= 1e-9 * np.linalg.norm(s.x)
+
+
+# ---------------------------------------------------------------- test/convergence_test.jl:72-98
+def test_unsteady_mono_1d_zero_stays_zero():
+    nx, lx = 40, 1.0
+    mesh = po.Mesh((nx,), (lx,), (0.0,))
+    cap = po.make_capacity(Ball((0.5,), 0.25), mesh)
+    op = po.make_diffusion_ops(cap)
+    ph = po.Phase(cap, op, lambda x, y, z, t: 0.0, lambda x, y, z: 1.0)
+    bcb = po.BorderConditions({"top": po.Dirichlet(0.0), "bottom": po.Dirichlet(0.0)})
+    dt = 0.5 * (lx / nx) ** 2
+    s = po.DiffusionUnsteadyMono(ph, bcb, po.Dirichlet(0.0), dt, np.zeros(2 * (nx + 1)), "BE")
+    po.solve_DiffusionUnsteadyMono(s, ph, dt, 5 * dt, bcb, po.Dirichlet(0.0), "BE", method="bicgstab")
+    assert np.max(np.abs(s.x)) < 1e-8
+
+
+# ---------------------------------------------------------------- test/convergence_test.jl:30-49
+def test_poisson_2d_known_error_bound():
+    n = 40
+    mesh = po.Mesh((n, n), (4.0, 4.0), (0.0, 0.0))
+    c = (2.01, 2.01)
+    cap = po.make_capacity(Ball(c, 1.0), mesh)
+    op = po.make_diffusion_ops(cap)
+    ph = po.Phase(cap, op, lambda x, y, z=0.0: 4.0, lambda x, y, z=0.0: 1.0)
+    bcb = po.BorderConditions({k: po.Dirichlet(0.0) for k in ("left", "right", "top", "bottom")})
+    s = po.DiffusionSteadyMono(ph, bcb, po.Dirichlet(0.0))
+    po.solve_system(s, method="\\")
+    u = lambda x, y: 1.0 - (x - c[0]) ** 2 - (y - c[1]) ** 2
+    _, _, global_err, *_ = po.check_convergence(u, s, cap, 2)
+    assert global_err < 1e-2                                       # reference threshold
+
+
+# ---------------------------------------------------------------- examples/2D/Diffusion/Heat.jl:63-100
+def test_config1_disc_cooling_against_bessel_series():
+    """80x80 is config 1; the analytic series is the reference's own (radial_heat_xy)."""
+    from scipy.special import j0, j1, jn_zeros
+
+    n = 40  # coarser than config 1 to keep the CPU suite short; error scales as h^2
+    mesh = po.Mesh((n, n), (4.0, 4.0), (0.0, 0.0))
+    c = (2.01, 2.01)
+    cap = po.make_capacity(Ball(c, 1.0), mesh)
+    op = po.make_diffusion_ops(cap)
+    ph = po.Phase(cap, op, lambda x, y, z, t: 0.0, lambda x, y, z: 1.0)
+    bcb = po.BorderConditions({k: po.Dirichlet(0.0) for k in ("left", "right", "top", "bottom")})
+    M = (n + 1) ** 2
+    u0 = np.concatenate([np.zeros(M), np.ones(M)])
+    dt = 0.25 * (4.0 / n) ** 2
+    Tend = 0.1
+    s = po.DiffusionUnsteadyMono(ph, bcb, po.Dirichlet(1.0), dt, u0, "BE")
+    po.solve_DiffusionUnsteadyMono(s, ph, dt, Tend, bcb, po.Dirichlet(1.0), "BE", method="\\")
+    t_num = dt * len(s.states)        # states[k] is the solution after k+1 implicit steps
+    al = jn_zeros(0, 200)
+
+    def u_ana(x, y):
+        r = math.hypot(x - c[0], y - c[1])
+        if r >= 1.0:
+            return 0.0
+        return 1.0 - 2.0 * float(np.sum(np.exp(-al ** 2 * t_num) * j0(al * r) / (al * j1(al))))
+
+    _, _, global_err, full_err, cut_err, _ = po.check_convergence(u_ana, s, cap, 2)
+    assert global_err < 1e-2
