@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's headline metric on MI355X:
+    time-steps/sec + SpMV GB/s (% HBM roofline), 3D mono diffusion 512^3   (benchmark/Heat3D.jl shape)
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 512]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over the resident problem: one Crank-Nicolson time step of
+solve_DiffusionUnsteadyMono! = right-hand side (1 SpMV + fused vector kernel) + BiCGStab solve to
+reltol 1e-12 + un-scaling, all on the GPU through the C ABI.  Inputs (capacities, CSR system, state) are
+resident in HBM when the timed region starts.
+
+N > 1 is weak scaling: grid (n, n, n*N), domain (4, 4, 4N), one sphere per slab,
+slab-decomposed along z with RCCL halo exchange + dot all-reduce inside libpenguin_hip.so; `value` is the
+aggregate n^3-subdomain time-steps per second (N x global steps/s).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = CSR
+SpMV, HIP-event timed on the library stream inside the timed region) and `cpu_baseline` (the oracle's C
+restatement of the same Krylov loop on the same matrix, on the host cores of this box; rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=512, help="cells per dimension of one slab (512 = the metric's config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=1)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N with N > 1 must be launched through torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import torch  # device sync + torch.distributed control plane (rendezvous, barrier, max-over-ranks)
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import penguin.jl_amd as pj
+    from penguin.jl_amd import _lib as L
+
+    if world > 1:
+        box = [pj.get_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        pj.init_distributed(local_rank, rank, world, box[0])
+    else:
+        pj.init(local_rank)
+    lib = L.lib()
+
+    # ---------------------------------------------------------------- workload (synthetic, deterministic)
+    n, g = args.n, world
+    mesh = pj.Mesh((n, n, n * g), (4.0, 4.0, 4.0 * g), (0.0, 0.0, 0.0))
+    body = pj.Sphere((2.01, 2.01, 2.01), 1.0) if g == 1 else pj.MultiSphere([(2.01, 2.01, 2.01 + 4.0 * s) for s in range(g)], 1.0)
+    t0 = time.time()
+    cap = pj.Capacity(body, mesh)
+    cap_ms = cap.kernel_ms
+    op = pj.DiffusionOps(cap)
+    M = (n + 1) * (n + 1) * (n * g + 1)
+    keys = ("left", "right", "top", "bottom")          # benchmark/Heat3D.jl:57-62
+    bcb = pj.BorderConditions({k: pj.Dirichlet(1.0) for k in keys})
+    bci = pj.Dirichlet(1.0)
+    phase = pj.Phase(cap, op, lambda x, y, z, t: 0.0, lambda x, y, z: 1.0)
+    dt = 0.75 * (4.0 / n) ** 2                         # benchmark/Heat3D.jl:69
+    u0 = np.zeros(2 * M)
+    s = pj.DiffusionUnsteadyMono(phase, bcb, bci, dt, u0, "BE")   # BE first (Heat3D.jl:72)
+    del u0
+    setup_s = time.time() - t0
+    opts = L.pg_krylov_opts(L.PG_METHOD["bicgstab"], 1e-12, 0.0, 0, 4)
+    info = L.pg_step_info()
+    L.check(lib.pg_solver_initial_solve(s._h, C.byref(opts), C.byref(info)))
+    CN = L.PG_SCHEME["CN"]                             # then CN (Heat3D.jl:74)
+    run = L.pg_run_info()
+
+    def steps(k: int) -> L.pg_run_info:
+        r = L.pg_run_info()
+        L.check(lib.pg_solver_run(s._h, C.c_double(1e30), C.c_int32(CN), C.byref(opts), C.c_int32(0), C.c_int64(k),
+                                  C.c_int32(0), C.byref(r)))
+        return r
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        L.check(lib.pg_device_synchronize())
+
+    steps(args.warmup)
+    L.check(lib.pg_set_profiling(1))                   # HIP events around every SpMV launch on the library stream
+    sync()
+    t0 = time.perf_counter()
+    run = steps(args.steps)
+    sync()
+    elapsed = time.perf_counter() - t0
+    L.check(lib.pg_set_profiling(0))
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    sysinfo = s.system_info(1)
+    n_rows, nnz = int(sysinfo.n_own), int(sysinfo.nnz)
+    if world > 1:
+        tot = torch.tensor([n_rows, nnz], dtype=torch.int64, device="cuda")
+        dist.all_reduce(tot)
+        n_rows_g, nnz_g = int(tot[0].item()), int(tot[1].item())
+    else:
+        n_rows_g, nnz_g = n_rows, nnz
+    b_spmv = 12 * nnz + 20 * n_rows                    # algorithmic bytes of one SpMV (this rank's launch)
+    spmv_ms = run.spmv_ms_total / max(run.spmv_launches, 1)
+    achieved = b_spmv / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
+    iters = run.total_iters / max(run.steps, 1)
+
+    traffic = None
+    tf = ROOT / "profiles" / "r01_spmv_traffic.json"
+    if tf.exists():
+        try:
+            traffic = json.loads(tf.read_text()).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "time-steps/sec + SpMV GB/s (% HBM roofline), 3D mono diffusion 512^3",
+        "value": world * args.steps / elapsed,
+        "unit": "time-steps/s" if world == 1 else f"{n}^3-subdomain time-steps/s (aggregate over {world} slabs)",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"3D monophasic unsteady diffusion {n}^3 per GPU (grid {n}x{n}x{n * g}), sphere r=1 per slab, "
+                        "Dirichlet(1) interface, Dirichlet(1) on :left/:right/:top/:bottom, BE first solve then CN steps "
+                        "(benchmark/Heat3D.jl shape), BiCGStab reltol 1e-12 on the Jacobi-equilibrated reduced CSR system",
+            "grid": [n, n, n * g],
+            "rows_global": n_rows_g, "nnz_global": nnz_g, "rows_rank0": n_rows, "nnz_rank0": nnz,
+            "krylov_iters_per_step": iters,
+            "spmv_per_step": run.spmv_launches / max(run.steps, 1),
+            "parallelism": f"slab-z x{world}, RCCL halo + dot all-reduce",
+            "setup_s": setup_s, "capacity_kernels_ms": cap_ms,
+            "device": pj.device_name(),
+        },
+        "roofline": {
+            "kernel": "k_spmv (CSR, fp64 values, int32 indices)",
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "bytes_per_launch": b_spmv,
+            "avg_launch_ms": spmv_ms,
+            "launches_timed": int(run.spmv_launches),
+        },
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(s, dt, args.cpu_steps, n)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(s, dt: float, cpu_steps: int, n: int) -> dict:
+    """The oracle's C restatement of the same loop (oracle/krylov_ref.c) on the SAME reduced system, timed on
+    this box's host cores.  The reference itself (Julia) cannot run here; kind = "port"."""
+    import scipy.sparse as sp
+
+    from oracle import krylov_c
+
+    A, b, idx = s.system(1)
+    nrow = A.shape[0]
+    A = A[:, :nrow].tocsr()
+    d = np.abs(A.diagonal())
+    ds = np.where(d > 0, 1.0 / np.sqrt(np.where(d > 0, d, 1.0)), 1.0)
+    Ds = sp.diags(ds)
+    Ah = (Ds @ A @ Ds).tocsr()
+    bh = ds * b
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    ncores = max(1, min(ncores, 16))   # a 1-GPU box's CPU share
+    res = {}
+    for label, nt, reps in (("single_thread", 1, cpu_steps), ("all_cores", ncores, max(cpu_steps, 2))):
+        t0 = time.perf_counter()
+        its = 0
+        for _ in range(reps):
+            y = krylov_c.spmv(Ah, bh, nthreads=nt)          # the CN right-hand side's SpMV
+            x, it, rn = krylov_c.solve(Ah, bh, "bicgstab", reltol=1e-12, maxiter=10000, nthreads=nt)
+            its += it
+        el = time.perf_counter() - t0
+        res[label] = {"value": reps / el, "cores": nt, "iters_per_step": its / reps, "steps_timed": reps}
+    return {
+        "value": res["single_thread"]["value"],
+        "unit": "time-steps/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{res['single_thread']['steps_timed']} CN step(s) of the same {n}^3 reduced system (n={nrow}, nnz={Ah.nnz}): "
+                  "1 SpMV + BiCGStab reltol 1e-12, oracle/krylov_ref.c, single thread (the reference's Krylov path is "
+                  "single-threaded); all-cores OpenMP figure alongside",
+        "all_cores": res["all_cores"],
+        "host_cores": ncores,
+    }
+
+
+if __name__ == "__main__":
+    main()
