@@ -14,96 +14,13 @@
 // coalesce and hit L2 / Infinity Cache (x = 8 B x n fits the 256 MB MALL at 512^3).  The dots that follow
 // an SpMV in BiCGStab / CG are fused into its epilogue.
 #include "pg_krylov.h"
+#include "pg_spmv.h"
 
 using namespace pg;
 
 namespace {
 
-enum { S_RHO = 0, S_RHO_OLD, S_ALPHA, S_OMEGA, S_BETA, S_RR, S_BB, S_TOL2, S_DONE, S_ITERS, S_RELTOL2, S_ABSTOL2,
-       S_RESTART, S_RHAT2, S_FORCE,
-       S_RED0, S_RED1, S_RED2, S_RED3, S_COUNT };
 enum { PH_INIT = 0, PH_BICG_1, PH_BICG_2, PH_BICG_3, PH_CG_INIT, PH_CG_1, PH_CG_2 };
-
-constexpr int BLOCK = 256;
-constexpr int SPMV_ROWS = 256;          // rows per block iteration
-constexpr int SPMV_LDS_ENTRIES = 3584;  // 256 rows x 14 entries (max row: 2*(2N+1) in 3-D)
-
-__device__ inline double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
-}
-
-// sum over the block; result valid in thread 0
-__device__ inline double block_sum(double v, double* sh /*BLOCK/64*/) {
-  v = wave_sum(v);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __syncthreads();
-  if (lane == 0) sh[wave] = v;
-  __syncthreads();
-  double s = 0.0;
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int w = 0; w < BLOCK / 64; ++w) s += sh[w];
-  }
-  return s;
-}
-
-// ---- SpMV ---------------------------------------------------------------------------------------
-// MODE 0: y = A x.  MODE 1: + partial[0] = aux . y.  MODE 2: + partial[0] = y . x, partial[1] = y . y
-template <int MODE>
-__global__ __launch_bounds__(BLOCK) void k_spmv(i64 n, const int* __restrict__ rowptr, const int* __restrict__ col,
-                                                const double* __restrict__ val, const double* __restrict__ x,
-                                                double* __restrict__ y, const double* __restrict__ aux,
-                                                double* __restrict__ partials, const double* __restrict__ sc) {
-  __shared__ double s_val[SPMV_LDS_ENTRIES];
-  __shared__ int s_col[SPMV_LDS_ENTRIES];
-  __shared__ double s_red[BLOCK / 64];
-  if (sc && sc[S_DONE] != 0.0) return;
-  double acc0 = 0.0, acc1 = 0.0;
-  const i64 nchunks = (n + SPMV_ROWS - 1) / SPMV_ROWS;
-  for (i64 chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    const i64 r0 = chunk * SPMV_ROWS;
-    const i64 r1 = r0 + SPMV_ROWS < n ? r0 + SPMV_ROWS : n;
-    const int base = rowptr[r0];
-    const int cnt = rowptr[r1] - base;
-    const i64 r = r0 + threadIdx.x;
-    int a = 0, b = 0;
-    if (r < r1) {
-      a = rowptr[r] - base;
-      b = rowptr[r + 1] - base;
-    }
-    double sum = 0.0;
-    if (cnt <= SPMV_LDS_ENTRIES) {
-      for (int k = threadIdx.x; k < cnt; k += BLOCK) {
-        s_val[k] = val[base + k];
-        s_col[k] = col[base + k];
-      }
-      __syncthreads();
-      for (int k = a; k < b; ++k) sum += s_val[k] * x[s_col[k]];
-      __syncthreads();
-    } else {
-      // rows longer than the stencil bound (never for this path's systems): direct CSR walk
-      for (int k = a; k < b; ++k) sum += val[base + k] * x[col[base + k]];
-    }
-    if (r < r1) {
-      y[r] = sum;
-      if (MODE == 1) acc0 += aux[r] * sum;
-      if (MODE == 2) {
-        acc0 += sum * x[r];
-        acc1 += sum * sum;
-      }
-    }
-  }
-  if (MODE >= 1) {
-    const double t0 = block_sum(acc0, s_red);
-    if (threadIdx.x == 0) partials[blockIdx.x] = t0;
-  }
-  if (MODE == 2) {
-    const double t1 = block_sum(acc1, s_red);
-    if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = t1;
-  }
-}
 
 // ---- fused vector kernels ---------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_bicg_init(i64 n, i64 nvec, const double* __restrict__ b, double* __restrict__ x,
@@ -298,13 +215,6 @@ void finalize(int phase, int nslots, KrylovWork& w, hipStream_t st, bool check_d
   }
 }
 
-template <int MODE>
-void launch_spmv(const CsrMatrix& A, const double* x, double* y, const double* aux, double* partials, const double* sc,
-                 int grid, hipStream_t st) {
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv<MODE>), dim3(grid), dim3(BLOCK), 0, st, A.n, A.rowptr.p, A.col.p, A.val.p, x, y,
-                     aux, partials, sc);
-}
-
 struct SpmvTimer {
   bool on;
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -375,7 +285,7 @@ void halo_exchange(const Numbering& nb, const Slab& slab, double* vec, hipStream
 
 void spmv(const CsrMatrix& A, const double* x, double* y, hipStream_t st) {
   if (A.n == 0) return;
-  launch_spmv<0>(A, x, y, nullptr, nullptr, nullptr, grid_for(A.n, BLOCK, 256 * 8), st);
+  launch_spmv(0, A, x, y, nullptr, nullptr, nullptr, spmv_default_grid(A.n), st);
   PG_HIP(hipGetLastError());
 }
 
@@ -419,13 +329,13 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
         hipLaunchKernelGGL(k_bicg_p, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.r.p, w.v.p, w.p.p, w.rhat.p);
         halo_exchange(nb, slab, w.p.p, st);
         timer.begin(st);
-        launch_spmv<1>(A, w.p.p, w.v.p, w.rhat.p, w.partials.p, w.sc.p, G, st);
+        launch_spmv(1, A, w.p.p, w.v.p, w.rhat.p, w.partials.p, w.sc.p, G, st);
         timer.end(st);
         finalize(PH_BICG_1, 1, w, st, true);
         hipLaunchKernelGGL(k_bicg_s, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.r.p, w.v.p, w.s.p);
         halo_exchange(nb, slab, w.s.p, st);
         timer.begin(st);
-        launch_spmv<2>(A, w.s.p, w.t.p, nullptr, w.partials.p, w.sc.p, G, st);
+        launch_spmv(2, A, w.s.p, w.t.p, nullptr, w.partials.p, w.sc.p, G, st);
         timer.end(st);
         finalize(PH_BICG_2, 2, w, st, true);
         hipLaunchKernelGGL(k_bicg_xr, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.p.p, w.s.p, w.t.p, w.rhat.p, x, w.r.p,
@@ -434,7 +344,7 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
       } else {
         halo_exchange(nb, slab, w.p.p, st);
         timer.begin(st);
-        launch_spmv<2>(A, w.p.p, w.v.p, nullptr, w.partials.p, w.sc.p, G, st);   // v = A p ; (v.p), (v.v)
+        launch_spmv(2, A, w.p.p, w.v.p, nullptr, w.partials.p, w.sc.p, G, st);   // v = A p ; (v.p), (v.v)
         timer.end(st);
         finalize(PH_CG_1, 1, w, st, true);
         hipLaunchKernelGGL(k_cg_xr, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.p.p, w.v.p, x, w.r.p, w.partials.p);
