@@ -281,8 +281,11 @@ void assemble_csr(const SysParams& P, const Slab& s, const Numbering& nb, CsrMat
   A.rowptr.download(&nnz, 1, n);
   PG_REQUIRE(nnz >= 0, "nnz overflow");
   A.nnz = nnz;
-  A.col.alloc(nnz > 0 ? nnz : 1);
-  A.val.alloc(nnz > 0 ? nnz : 1);
+  // +8: the SpMV streams 16-byte-aligned pairs/quads and may touch a few entries past nnz
+  A.col.alloc(nnz + 8);
+  A.val.alloc(nnz + 8);
+  A.col.zero();
+  A.val.zero();
   hipLaunchKernelGGL(k_fill, dim3(gr), dim3(256), 0, st, P, seg, nb.Mloc, n, nb.row_cell.p, nb.red.p, A.rowptr.p, A.col.p,
                      A.val.p);
   PG_HIP(hipGetLastError());
@@ -294,6 +297,7 @@ void assemble_csr(const SysParams& P, const Slab& s, const Numbering& nb, CsrMat
   hipLaunchKernelGGL(k_scale_vals, dim3(gr), dim3(256), 0, st, n, A.rowptr.p, A.col.p, A.ds.p, A.val.p);
   PG_HIP(hipGetLastError());
   PG_HIP(hipStreamSynchronize(st));
+  build_spmv_chunks(A);
 }
 
 void apply_rows_padded(const SysParams& P, const Slab& s, const double* x, double* y) {

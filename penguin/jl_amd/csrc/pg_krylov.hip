@@ -253,7 +253,7 @@ void KrylovWork::init(i64 n_own, i64 n_vec) {
   nvec = n_vec;
   const i64 a = n_vec > 0 ? n_vec : 1;
   r.alloc(a); rhat.alloc(a); p.alloc(a); v.alloc(a); s.alloc(a); t.alloc(a);
-  grid = grid_for(n_own, BLOCK, 256 * 8);
+  grid = spmv_default_grid(n_own);
   partials.alloc(4 * (i64)grid);
   sc.alloc(S_COUNT);
   sc.zero();

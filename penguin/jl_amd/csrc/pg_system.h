@@ -42,7 +42,12 @@ struct CsrMatrix {
   DevBuf<int> rowptr, col;
   DevBuf<double> val;
   DevBuf<double> ds;   // n_vec
+  // SpMV row blocks: chunk c = rows [chunk_start[c], chunk_start[c+1]), <= 64 rows and <= SPMV_CHUNK_ENTRIES entries
+  DevBuf<int> chunk_start;
+  i64 nchunks = 0;
 };
+constexpr int SPMV_CHUNK_ENTRIES = 512;
+void build_spmv_chunks(CsrMatrix& A);   // pg_spmv.hip
 
 void build_numbering(const SysParams& P, const Slab& slab, Numbering& nb);
 void assemble_csr(const SysParams& P, const Slab& slab, const Numbering& nb, CsrMatrix& A);
