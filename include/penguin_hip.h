@@ -203,6 +203,18 @@ int32_t pg_solver_time_spmv(pg_solver* s, int32_t which, int32_t reps, double* a
    (active rows) into nranks contiguous ranges; bounds has nranks+1 entries. */
 int32_t pg_partition_planes(const int64_t* weight, int64_t nplanes, int32_t nranks, int64_t* bounds);
 
+/* ---- diagnostics (not part of the reference-facing boundary) ------------------------------------------------ */
+/* read-only streaming probe: `bytes` read `reps` times with elem_bytes (4|8) per lane, optional non-temporal hint */
+int32_t pg_debug_read_probe(int64_t bytes, int32_t elem_bytes, int32_t nt, int32_t blocks, int32_t reps, double* gbs);
+/* run the slab-decomposed monophasic path with `nranks` VIRTUAL ranks (host threads sharing this GPU, in-process
+   halo exchange / all-reduce standing in for RCCL): Dirichlet(interface_value) on the body, Dirichlet(border_value)
+   on `keys`, T0 = 0, initial solve with scheme_ctor then `steps` steps with scheme_run.  x_out: 2M. */
+int32_t pg_debug_run_virtual_ranks(int32_t nranks, int32_t N, const int64_t* n, const double* L, int32_t body_kind,
+                                   const double* params, int32_t nparams, double interface_value, double border_value,
+                                   int32_t nkeys, const int32_t* keys, double dt, int32_t scheme_ctor, int32_t scheme_run,
+                                   int64_t steps, double* x_out, int64_t* n_own_out, int64_t* nnz_out,
+                                   int64_t* n_ghost_out, int64_t* iters_out);
+
 #ifdef __cplusplus
 }
 #endif

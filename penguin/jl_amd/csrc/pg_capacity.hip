@@ -349,7 +349,7 @@ int32_t pg_capacity_create_levelset(pg_mesh* m, int32_t body_kind, const double*
     if (hi > lo)
       hipLaunchKernelGGL(k_plane_weights, dim3(grid_for((hi - lo) * s.plane, 256)), dim3(256), 0, st, g, bs, lo, hi, w.p);
     PG_HIP(hipGetLastError());
-    PG_NCCL(ncclAllReduce(w.p, w.p, s.nplanes, ncclUint64, ncclSum, cx.comm, st));
+    comm_allreduce_sum_u64(w.p, s.nplanes, st);
     std::vector<unsigned long long> hw(s.nplanes);
     w.download(hw.data(), s.nplanes);
     std::vector<i64> wt(hw.begin(), hw.end()), bounds(cx.nranks + 1);

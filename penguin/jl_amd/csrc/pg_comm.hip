@@ -1,0 +1,121 @@
+// pg_comm.hip -- the only place that talks to RCCL (C1/C2/C3 of SURVEY.md section 2.3).
+//
+// Two backends behind the same four calls:
+//   * RCCL over xGMI (production): one process per GPU; collectives and nearest-neighbour send/recv are
+//     enqueued on the compute stream, no host synchronisation.
+//   * LocalComm (diagnostics): N "virtual ranks" = N host threads of ONE process sharing one GPU, exchanging
+//     through device-to-device copies and pthread barriers.  It exists so that the slab partition, the ghost
+//     numbering and every send/recv offset of the multi-GPU path can be verified bit for bit on a 1-GPU box
+//     (pg_debug_run_virtual_ranks, tests/test_gpu_virtual_ranks.py).  Same reduction order as RCCL is NOT
+//     assumed anywhere: results only need to be identical on all ranks, which both backends guarantee.
+#include <pthread.h>
+
+#include "pg_krylov.h"
+
+namespace pg {
+
+struct LocalComm {
+  int nranks = 1;
+  pthread_barrier_t bar;
+  std::vector<std::vector<double>> slot_f64;                 // [rank][count]
+  std::vector<std::vector<unsigned long long>> slot_u64;     // [rank][count]
+  struct Post { const double* sendL[MAX_KINDS]; const double* sendU[MAX_KINDS]; i64 cntL[MAX_KINDS]; i64 cntU[MAX_KINDS]; };
+  std::vector<Post> posts;
+  explicit LocalComm(int n) : nranks(n), slot_f64(n), slot_u64(n), posts(n) { pthread_barrier_init(&bar, nullptr, n); }
+  ~LocalComm() { pthread_barrier_destroy(&bar); }
+  void barrier() { pthread_barrier_wait(&bar); }
+};
+
+static thread_local Context* tl_ctx = nullptr;
+void set_thread_context(Context* c) { tl_ctx = c; }
+Context* thread_context() { return tl_ctx; }
+
+LocalComm* local_comm_create(int nranks) { return new LocalComm(nranks); }
+void local_comm_destroy(LocalComm* c) { delete c; }
+
+template <class T, class Slots>
+static void local_allreduce(LocalComm* lc, int rank, Slots& slots, T* dev, i64 count, hipStream_t st, bool do_max) {
+  std::vector<T>& mine = slots[rank];
+  mine.resize(count);
+  PG_HIP(hipMemcpyAsync(mine.data(), dev, sizeof(T) * count, hipMemcpyDeviceToHost, st));
+  PG_HIP(hipStreamSynchronize(st));
+  lc->barrier();
+  std::vector<T> res(count);
+  for (i64 i = 0; i < count; ++i) {
+    T acc = slots[0][i];
+    for (int r = 1; r < lc->nranks; ++r) acc = do_max ? (slots[r][i] > acc ? slots[r][i] : acc) : acc + slots[r][i];
+    res[i] = acc;
+  }
+  lc->barrier();   // everyone has read every slot
+  PG_HIP(hipMemcpyAsync(dev, res.data(), sizeof(T) * count, hipMemcpyHostToDevice, st));
+  PG_HIP(hipStreamSynchronize(st));
+}
+
+void comm_allreduce_sum_f64(double* dev, int count, hipStream_t st) {
+  Context& cx = ctx();
+  if (cx.nranks == 1) return;
+  if (cx.local) local_allreduce<double>(cx.local, cx.rank, cx.local->slot_f64, dev, count, st, false);
+  else PG_NCCL(ncclAllReduce(dev, dev, count, ncclDouble, ncclSum, cx.comm, st));
+}
+
+void comm_allreduce_max_f64(double* dev, int count, hipStream_t st) {
+  Context& cx = ctx();
+  if (cx.nranks == 1) return;
+  if (cx.local) local_allreduce<double>(cx.local, cx.rank, cx.local->slot_f64, dev, count, st, true);
+  else PG_NCCL(ncclAllReduce(dev, dev, count, ncclDouble, ncclMax, cx.comm, st));
+}
+
+void comm_allreduce_sum_u64(unsigned long long* dev, i64 count, hipStream_t st) {
+  Context& cx = ctx();
+  if (cx.nranks == 1) return;
+  if (cx.local) local_allreduce<unsigned long long>(cx.local, cx.rank, cx.local->slot_u64, dev, count, st, false);
+  else PG_NCCL(ncclAllReduce(dev, dev, count, ncclUint64, ncclSum, cx.comm, st));
+}
+
+// C1: ghost segments of `vec` <- boundary chunks of the neighbours' owned parts.  The chunks are contiguous
+// (Numbering), so there is nothing to pack: one send and one recv per unknown kind and neighbour, grouped.
+void halo_exchange(const Numbering& nb, const Slab& slab, double* vec, hipStream_t st) {
+  Context& cx = ctx();
+  if (cx.nranks == 1) return;
+  const bool has_lo = slab.p0 > 0, has_hi = slab.p1 < slab.nplanes;
+  if (cx.local) {
+    LocalComm* lc = cx.local;
+    LocalComm::Post& me = lc->posts[cx.rank];
+    for (int k = 0; k < MAX_KINDS; ++k) {
+      me.sendL[k] = vec + nb.sendL_off[k]; me.cntL[k] = k < nb.K ? nb.sendL_cnt[k] : 0;
+      me.sendU[k] = vec + nb.sendU_off[k]; me.cntU[k] = k < nb.K ? nb.sendU_cnt[k] : 0;
+    }
+    PG_HIP(hipStreamSynchronize(st));   // my boundary values are final
+    lc->barrier();
+    for (int k = 0; k < nb.K; ++k) {
+      if (has_lo && nb.cntL[k] > 0) {   // what the lower neighbour sends UP is my lower ghost
+        const LocalComm::Post& o = lc->posts[cx.rank - 1];
+        PG_REQUIRE(o.cntU[k] == nb.cntL[k], "halo size mismatch with the lower neighbour");
+        PG_HIP(hipMemcpyAsync(vec + nb.offL[k], o.sendU[k], sizeof(double) * nb.cntL[k], hipMemcpyDeviceToDevice, st));
+      }
+      if (has_hi && nb.cntU[k] > 0) {
+        const LocalComm::Post& o = lc->posts[cx.rank + 1];
+        PG_REQUIRE(o.cntL[k] == nb.cntU[k], "halo size mismatch with the upper neighbour");
+        PG_HIP(hipMemcpyAsync(vec + nb.offU[k], o.sendL[k], sizeof(double) * nb.cntU[k], hipMemcpyDeviceToDevice, st));
+      }
+    }
+    PG_HIP(hipStreamSynchronize(st));
+    lc->barrier();                      // nobody overwrites a source before it has been copied
+    return;
+  }
+  // ranks own increasing plane ranges: the lower neighbour is rank-1, the upper one rank+1
+  PG_NCCL(ncclGroupStart());
+  for (int k = 0; k < nb.K; ++k) {
+    if (has_lo) {
+      if (nb.sendL_cnt[k] > 0) PG_NCCL(ncclSend(vec + nb.sendL_off[k], nb.sendL_cnt[k], ncclDouble, cx.rank - 1, cx.comm, st));
+      if (nb.cntL[k] > 0) PG_NCCL(ncclRecv(vec + nb.offL[k], nb.cntL[k], ncclDouble, cx.rank - 1, cx.comm, st));
+    }
+    if (has_hi) {
+      if (nb.sendU_cnt[k] > 0) PG_NCCL(ncclSend(vec + nb.sendU_off[k], nb.sendU_cnt[k], ncclDouble, cx.rank + 1, cx.comm, st));
+      if (nb.cntU[k] > 0) PG_NCCL(ncclRecv(vec + nb.offU[k], nb.cntU[k], ncclDouble, cx.rank + 1, cx.comm, st));
+    }
+  }
+  PG_NCCL(ncclGroupEnd());
+}
+
+}  // namespace pg

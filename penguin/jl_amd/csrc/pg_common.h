@@ -58,8 +58,11 @@ void set_last_error(const std::string& msg);
     return 2;                                       \
   }
 
+struct LocalComm;   // in-process "virtual ranks" backend (pg_comm.hip), diagnostics only
+
 struct Context {
   bool inited = false;
+  LocalComm* local = nullptr;        // non-null: this thread is a virtual rank of a LocalComm
   int device = 0;
   hipStream_t stream = nullptr;      // compute stream: every kernel of the path runs here
   hipStream_t comm_stream = nullptr; // halo exchange stream (overlaps interior SpMV rows)
@@ -68,8 +71,16 @@ struct Context {
   bool profiling = false;
   std::string device_name;
 };
-Context& ctx();
+Context& ctx();                      // the calling thread's context (virtual ranks override the process context)
 void require_init();
+void set_thread_context(Context* c);
+Context* thread_context();
+LocalComm* local_comm_create(int nranks);
+void local_comm_destroy(LocalComm* c);
+// collectives on device buffers, enqueued on `st` (no-ops on one rank)            C2 / C3 of SURVEY.md 2.3
+void comm_allreduce_sum_f64(double* dev, int count, hipStream_t st);
+void comm_allreduce_max_f64(double* dev, int count, hipStream_t st);
+void comm_allreduce_sum_u64(unsigned long long* dev, i64 count, hipStream_t st);
 
 // ---- device buffer -------------------------------------------------------------------------
 template <class T>

@@ -12,7 +12,8 @@ void set_last_error(const std::string& msg) { g_last_error = msg; }
 
 Context& ctx() {
   static Context c;
-  return c;
+  Context* t = thread_context();
+  return t ? *t : c;
 }
 
 void require_init() {

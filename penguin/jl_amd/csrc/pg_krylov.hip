@@ -210,7 +210,7 @@ void finalize(int phase, int nslots, KrylovWork& w, hipStream_t st, bool check_d
     // local sums -> RCCL all-reduce of <=2 doubles over xGMI -> identical scalars on every rank
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, st, phase, nslots, w.grid, w.partials.p, w.sc.p, 0,
                        check_done ? 1 : 0);
-    PG_NCCL(ncclAllReduce(w.sc.p + S_RED0, w.sc.p + S_RED0, nslots, ncclDouble, ncclSum, cx.comm, st));
+    comm_allreduce_sum_f64(w.sc.p + S_RED0, nslots, st);
     hipLaunchKernelGGL(k_derive, dim3(1), dim3(1), 0, st, phase, w.sc.p, check_done ? 1 : 0);
   }
 }
@@ -262,25 +262,6 @@ void KrylovWork::init(i64 n_own, i64 n_vec) {
 
 KrylovWork::~KrylovWork() {
   if (h_sc) (void)hipHostFree(h_sc);
-}
-
-void halo_exchange(const Numbering& nb, const Slab& slab, double* vec, hipStream_t st) {
-  Context& cx = ctx();
-  if (cx.nranks == 1) return;
-  const bool has_lo = slab.p0 > 0, has_hi = slab.p1 < slab.nplanes;
-  // neighbours in rank order: ranks own increasing plane ranges
-  PG_NCCL(ncclGroupStart());
-  for (int k = 0; k < nb.K; ++k) {
-    if (has_lo) {
-      if (nb.sendL_cnt[k] > 0) PG_NCCL(ncclSend(vec + nb.sendL_off[k], nb.sendL_cnt[k], ncclDouble, cx.rank - 1, cx.comm, st));
-      if (nb.cntL[k] > 0) PG_NCCL(ncclRecv(vec + nb.offL[k], nb.cntL[k], ncclDouble, cx.rank - 1, cx.comm, st));
-    }
-    if (has_hi) {
-      if (nb.sendU_cnt[k] > 0) PG_NCCL(ncclSend(vec + nb.sendU_off[k], nb.sendU_cnt[k], ncclDouble, cx.rank + 1, cx.comm, st));
-      if (nb.cntU[k] > 0) PG_NCCL(ncclRecv(vec + nb.offU[k], nb.cntU[k], ncclDouble, cx.rank + 1, cx.comm, st));
-    }
-  }
-  PG_NCCL(ncclGroupEnd());
 }
 
 void spmv(const CsrMatrix& A, const double* x, double* y, hipStream_t st) {

@@ -382,7 +382,7 @@ double max_abs(pg_solver* s) {
   if (ctx().nranks > 1) {
     DevBuf<double> d(1);
     d.upload(&m, 1);
-    PG_NCCL(ncclAllReduce(d.p, d.p, 1, ncclDouble, ncclMax, ctx().comm, st));
+    comm_allreduce_max_f64(d.p, 1, st);
     d.download(&m, 1);
   }
   return m;

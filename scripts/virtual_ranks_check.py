@@ -1,0 +1,48 @@
+"""Run the slab path with virtual ranks on one GPU and compare with the single-rank run (subprocess of the test)."""
+import ctypes as C
+import json
+import sys
+
+import numpy as np
+
+sys.path.insert(0, ".")
+import penguin.jl_amd as pj
+from penguin.jl_amd import _lib as L
+
+pj.init(0)
+lib = L.lib()
+
+
+def run(nranks, n, Lz_factor, centers, steps, scheme_run):
+    N = 3
+    nn = np.array([n, n, n * Lz_factor], dtype=np.int64)
+    LL = np.array([4.0, 4.0, 4.0 * Lz_factor])
+    if len(centers) == 1:
+        kind, params = L.PG_BODY_BALL, np.array(list(centers[0]) + [1.0])
+    else:
+        kind, params = L.PG_BODY_MULTIBALL, np.array([1.0, float(len(centers))] + [v for c in centers for v in c])
+    M = int(np.prod(nn + 1))
+    x = np.zeros(2 * M)
+    keys = np.array([L.PG_KEY[k] for k in ("left", "right", "top", "bottom")], dtype=np.int32)
+    n_own = np.zeros(nranks, dtype=np.int64)
+    nnz = np.zeros(nranks, dtype=np.int64)
+    ngh = np.zeros(nranks, dtype=np.int64)
+    its = np.zeros(nranks, dtype=np.int64)
+    dt = 0.75 * (4.0 / n) ** 2
+    L.check(lib.pg_debug_run_virtual_ranks(nranks, N, L.iptr(nn), L.dptr(LL), kind, L.dptr(params), len(params), C.c_double(1.0),
+                                           C.c_double(1.0), len(keys), keys.ctypes.data_as(L.c_i32_p), C.c_double(dt), 0,
+                                           scheme_run, C.c_int64(steps), L.dptr(x), L.iptr(n_own), L.iptr(nnz), L.iptr(ngh),
+                                           L.iptr(its)))
+    return x, n_own, nnz, ngh, its
+
+
+out = {}
+for case, (n, zf, centers) in {"sphere": (24, 1, [(2.01, 2.01, 2.01)]),
+                               "two_spheres": (16, 2, [(2.01, 2.01, 2.01), (2.01, 2.01, 6.01)])}.items():
+    ref, n1, nnz1, _, it1 = run(1, n, zf, centers, 3, 1)
+    for nr in (2, 3, 4):
+        x, n_own, nnz, ngh, its = run(nr, n, zf, centers, 3, 1)
+        err = float(np.linalg.norm(x - ref) / np.linalg.norm(ref))
+        out[f"{case}_{nr}"] = {"rel_l2": err, "n_own": n_own.tolist(), "n_total_1": int(n1[0]), "nnz": nnz.tolist(),
+                               "nnz_total_1": int(nnz1[0]), "n_ghost": ngh.tolist(), "iters": its.tolist(), "iters_1": int(it1[0])}
+print(json.dumps(out))
