@@ -160,7 +160,7 @@ int32_t pg_diffops_div(const pg_diffops* o, const double* qw /*N*M*/, const doub
 
 /* ---- Solver          replaces DiffusionUnsteadyMono(phase, bc_b, bc_i, Δt, Tᵢ, scheme), diffusion.jl:192-210
    Dcoef: M values D(C_omega) or NULL (=1).  source: M values f(C_omega, Δt) for the first step or NULL (=0).
-   T0: 2M.  Builds A (scheme), b(t=0) and applies the border rows with t = 0 exactly as the ctor does. */
+   T0: 2M, or NULL for zeros.  Builds A (scheme), b(t=0) and applies the border rows with t = 0 exactly as the ctor does. */
 int32_t pg_solver_create_unsteady_mono(pg_capacity* c, pg_diffops* o, const pg_bc_desc* bc_interface,
                                        const pg_border_desc* borders, int32_t nborders, const double* Dcoef,
                                        const double* source, double dt, const double* T0, int32_t scheme,

@@ -256,6 +256,14 @@ class Capacity:
 
     C_gamma = C_γ
 
+    # lazy coordinate getters: closures are only evaluated (and the M x N centroid arrays only fetched from the
+    # GPU) when the user really passed a function -- constants never touch them
+    def _cw(self):
+        return self.C_ω
+
+    def _cg(self):
+        return self.C_γ
+
     @property
     def kernel_ms(self) -> float:
         ms = C.c_double()
@@ -434,6 +442,10 @@ def _eval(fn, coords: np.ndarray, t: Optional[float], nargs_space: int):
     """Evaluate fn at the rows of coords (padded with zero columns up to nargs_space), vectorised when the
     callable accepts arrays.  Mirrors `try value(x..., t) catch value(x...)` (src/solver.jl:315-319,441-448).
     Returns a float when the callable returned a scalar for array input (constant data)."""
+    if not callable(fn):
+        return float(fn)
+    if callable(coords):
+        coords = coords()          # lazy: Capacity._cw / _cg
     cols = [coords[:, d] if d < coords.shape[1] else np.zeros(coords.shape[0]) for d in range(nargs_space)]
     if t is not None and _accepts(fn, nargs_space + 1):
         call = lambda c: fn(*c, t)
@@ -599,9 +611,10 @@ def DiffusionUnsteadyMono(phase: Phase, bc_b: BorderConditions, bc_i, Δt: float
     cap, mesh = phase.capacity, phase.capacity.mesh
     M = int(np.prod(mesh.ext))
     s._nunk = 2 * M
-    Tᵢ = np.ascontiguousarray(Tᵢ, dtype=np.float64)
-    if Tᵢ.shape != (2 * M,):
-        raise ValueError(f"Tᵢ must have length 2*prod(n+1) = {2 * M}")
+    if Tᵢ is not None:     # None = zeros(2M) without materialising it on the host (multi-GPU sizes)
+        Tᵢ = np.ascontiguousarray(Tᵢ, dtype=np.float64)
+        if Tᵢ.shape != (2 * M,):
+            raise ValueError(f"Tᵢ must have length 2*prod(n+1) = {2 * M}")
     sch = "CN" if scheme == "CN" else "BE"   # diffusion.jl:200-206: anything but "CN" is BE
     # interface condition
     if isinstance(bc_i, Dirichlet):
@@ -616,7 +629,7 @@ def DiffusionUnsteadyMono(phase: Phase, bc_b: BorderConditions, bc_i, Δt: float
     g_arr = None
     gval = 0.0
     if callable(bc_i.value):
-        g = _eval(bc_i.value, cap.C_γ, float(Δt), 3)      # b(t=0) uses g(0+Δt)  diffusion.jl:249
+        g = _eval(bc_i.value, cap._cg, float(Δt), 3)      # b(t=0) uses g(0+Δt)  diffusion.jl:249
         if isinstance(g, float):
             gval = g
         else:
@@ -624,24 +637,24 @@ def DiffusionUnsteadyMono(phase: Phase, bc_b: BorderConditions, bc_i, Δt: float
     else:
         gval = float(bc_i.value)
     desc = L.pg_bc_desc(kind, a, b, gval, L.dptr(g_arr) if g_arr is not None else None)
-    D = _eval(phase.Diffusion_coeff, cap.C_ω, None, 3) if callable(phase.Diffusion_coeff) else float(phase.Diffusion_coeff)
+    D = _eval(phase.Diffusion_coeff, cap._cw, None, 3) if callable(phase.Diffusion_coeff) else float(phase.Diffusion_coeff)
     if isinstance(D, float):
         D_arr = None if D == 1.0 else np.full(M, D)
     else:
         D_arr = D
-    f1 = _eval(phase.source, cap.C_ω, float(Δt), 3)        # f(0+Δt)
+    f1 = _eval(phase.source, cap._cw, float(Δt), 3)        # f(0+Δt)
     f_arr = _padded_field(f1, M)
     borders, nb, bvals = _border_descs(bc_b, mesh, 0.0)    # ctor applies borders with t = 0  (:207)
     L.check(L.lib().pg_solver_create_unsteady_mono(
         cap._h, phase.operator._h, C.byref(desc), borders, C.c_int32(nb),
         L.dptr(D_arr) if D_arr is not None else None, L.dptr(f_arr) if f_arr is not None else None,
-        C.c_double(Δt), L.dptr(Tᵢ), C.c_int32(L.PG_SCHEME[sch]), C.byref(s._h)))
+        C.c_double(Δt), L.dptr(Tᵢ) if Tᵢ is not None else None, C.c_int32(L.PG_SCHEME[sch]), C.byref(s._h)))
     if sch == "CN":
-        f0 = _padded_field(_eval(phase.source, cap.C_ω, 0.0, 3), M)
+        f0 = _padded_field(_eval(phase.source, cap._cw, 0.0, 3), M)
         if f0 is not None:
             L.check(L.lib().pg_solver_set_source(s._h, 0, L.dptr(f0), None))
         if callable(bc_i.value):
-            g0 = _eval(bc_i.value, cap.C_γ, 0.0, 3)
+            g0 = _eval(bc_i.value, cap._cg, 0.0, 3)
             g0 = np.full(M, g0) if isinstance(g0, float) else g0
             L.check(L.lib().pg_solver_set_interface_value(s._h, L.dptr(g0), None))
     if bvals is not None:
@@ -685,8 +698,8 @@ def solve_DiffusionUnsteadyMono_b(s: Solver, phase: Phase, Δt: float, Tₑ: flo
         print("Time: ", t)
         print("Solver Extremum: ", info.extremum)
     # is any closure time dependent?  sample t = Δt and 2Δt
-    dyn_f = _time_dependent(phase.source, cap.C_ω, Δt, 2 * Δt, 3)
-    dyn_g = _time_dependent(bc.value, cap.C_γ, Δt, 2 * Δt, 3) if callable(bc.value) else False
+    dyn_f = _time_dependent(phase.source, cap._cw, Δt, 2 * Δt, 3)
+    dyn_g = _time_dependent(bc.value, cap._cg, Δt, 2 * Δt, 3) if callable(bc.value) else False
     dyn_b = any(_time_dependent(getattr(c, "value", None), np.zeros((1, mesh.N)), Δt, 2 * Δt, mesh.N)
                 for c in bc_b.borders.values())
     steps = 0
@@ -724,13 +737,13 @@ def solve_DiffusionUnsteadyMono_b(s: Solver, phase: Phase, Δt: float, Tₑ: flo
         if verbose:
             print("Time: ", t)
         if dyn_f or scheme == "CN":
-            fn = _padded_field(_eval(phase.source, cap.C_ω, t, 3), M)
-            fn1 = _padded_field(_eval(phase.source, cap.C_ω, t + Δt, 3), M)   # f(t+Δt), t already advanced (:248)
+            fn = _padded_field(_eval(phase.source, cap._cw, t, 3), M)
+            fn1 = _padded_field(_eval(phase.source, cap._cw, t + Δt, 3), M)   # f(t+Δt), t already advanced (:248)
             zero = np.zeros(M)
             L.check(L.lib().pg_solver_set_source(s._h, 0, L.dptr(fn if fn is not None else zero),
                                                  L.dptr(fn1 if fn1 is not None else zero)))
         if callable(bc.value) and (dyn_g or scheme == "CN"):
-            gn, gn1 = _eval(bc.value, cap.C_γ, t, 3), _eval(bc.value, cap.C_γ, t + Δt, 3)
+            gn, gn1 = _eval(bc.value, cap._cg, t, 3), _eval(bc.value, cap._cg, t + Δt, 3)
             gn = np.full(M, gn) if isinstance(gn, float) else gn
             gn1 = np.full(M, gn1) if isinstance(gn1, float) else gn1
             L.check(L.lib().pg_solver_set_interface_value(s._h, L.dptr(gn), L.dptr(gn1)))
@@ -766,8 +779,8 @@ def DiffusionUnsteadyDiph(phase1: Phase, phase2: Phase, bc_b: BorderConditions, 
         raise ValueError(f"Tᵢ must have length 4*prod(n+1) = {4 * M}")
     jump, flux = ic.scalar, ic.flux
     # g, h are built WITHOUT t (diffusion.jl:397)
-    g = _eval(jump.value, phase1.capacity.C_γ, None, 3) if callable(jump.value) else float(jump.value)
-    h = _eval(flux.value, phase2.capacity.C_γ, None, 3) if callable(flux.value) else float(flux.value)
+    g = _eval(jump.value, phase1.capacity._cg, None, 3) if callable(jump.value) else float(jump.value)
+    h = _eval(flux.value, phase2.capacity._cg, None, 3) if callable(flux.value) else float(flux.value)
     g_arr = None if isinstance(g, float) else g
     h_arr = None if isinstance(h, float) else h
     desc = L.pg_jump_desc(float(jump.α1), float(jump.α2), g if isinstance(g, float) else 0.0, float(flux.β1),
@@ -775,14 +788,14 @@ def DiffusionUnsteadyDiph(phase1: Phase, phase2: Phase, bc_b: BorderConditions, 
                           L.dptr(g_arr) if g_arr is not None else None, L.dptr(h_arr) if h_arr is not None else None)
 
     def dcoef(ph):
-        D = _eval(ph.Diffusion_coeff, ph.capacity.C_ω, None, 3) if callable(ph.Diffusion_coeff) else float(ph.Diffusion_coeff)
+        D = _eval(ph.Diffusion_coeff, ph.capacity._cw, None, 3) if callable(ph.Diffusion_coeff) else float(ph.Diffusion_coeff)
         if isinstance(D, float):
             return None if D == 1.0 else np.full(M, D)
         return D
 
     D1, D2 = dcoef(phase1), dcoef(phase2)
-    f1 = _padded_field(_eval(phase1.source, phase1.capacity.C_ω, float(Δt), 3), M)
-    f2 = _padded_field(_eval(phase2.source, phase2.capacity.C_ω, float(Δt), 3), M)
+    f1 = _padded_field(_eval(phase1.source, phase1.capacity._cw, float(Δt), 3), M)
+    f2 = _padded_field(_eval(phase2.source, phase2.capacity._cw, float(Δt), 3), M)
     borders, nb, bvals = _border_descs(bc_b, mesh, None)   # BC_border_diph! is called without t (:330)
     sch = "CN" if scheme == "CN" else "BE"
     p = lambda a: L.dptr(a) if a is not None else None
@@ -791,7 +804,7 @@ def DiffusionUnsteadyDiph(phase1: Phase, phase2: Phase, bc_b: BorderConditions, 
         C.c_int32(nb), p(D1), p(D2), p(f1), p(f2), C.c_double(Δt), L.dptr(Tᵢ), C.c_int32(L.PG_SCHEME[sch]), C.byref(s._h)))
     if sch == "CN":
         for q, ph in enumerate((phase1, phase2)):
-            f0 = _padded_field(_eval(ph.source, ph.capacity.C_ω, 0.0, 3), M)
+            f0 = _padded_field(_eval(ph.source, ph.capacity._cw, 0.0, 3), M)
             if f0 is not None:
                 L.check(L.lib().pg_solver_set_source(s._h, q, L.dptr(f0), None))
     if bvals is not None:
@@ -811,7 +824,7 @@ def solve_DiffusionUnsteadyDiph_b(s: Solver, phase1: Phase, phase2: Phase, Δt: 
     opts = _krylov_opts(method, kwargs)
     M = s._ctx["M"]
     sch = L.PG_SCHEME[scheme] if scheme in L.PG_SCHEME else L.PG_SCHEME["BE"]
-    dyn = any(_time_dependent(ph.source, ph.capacity.C_ω, Δt, 2 * Δt, 3) for ph in (phase1, phase2))
+    dyn = any(_time_dependent(ph.source, ph.capacity._cw, Δt, 2 * Δt, 3) for ph in (phase1, phase2))
     t = 0.0
     info = L.pg_step_info()
     if verbose:
@@ -832,8 +845,8 @@ def solve_DiffusionUnsteadyDiph_b(s: Solver, phase1: Phase, phase2: Phase, Δt: 
             print("Time: ", t)
         if dyn or scheme == "CN":
             for q, ph in enumerate((phase1, phase2)):
-                fn = _padded_field(_eval(ph.source, ph.capacity.C_ω, t, 3), M)
-                fn1 = _padded_field(_eval(ph.source, ph.capacity.C_ω, t + Δt, 3), M)
+                fn = _padded_field(_eval(ph.source, ph.capacity._cw, t, 3), M)
+                fn1 = _padded_field(_eval(ph.source, ph.capacity._cw, t + Δt, 3), M)
                 zero = np.zeros(M)
                 L.check(L.lib().pg_solver_set_source(s._h, q, L.dptr(fn if fn is not None else zero),
                                                      L.dptr(fn1 if fn1 is not None else zero)))

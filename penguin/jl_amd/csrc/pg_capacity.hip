@@ -339,7 +339,7 @@ int32_t pg_capacity_create_levelset(pg_mesh* m, int32_t body_kind, const double*
   hipStream_t st = cx.stream;
 
   // ---- slab partition balanced by non-empty cells per plane ----------------
-  if (cx.nranks > 1) {
+  if (cx.nranks > 1 || cx.comm) {
     const Slab& s = c->slab;
     PG_REQUIRE(s.nplanes >= cx.nranks, "fewer planes than ranks");
     GeoView g = geo_view(m, s);

@@ -53,21 +53,21 @@ static void local_allreduce(LocalComm* lc, int rank, Slots& slots, T* dev, i64 c
 
 void comm_allreduce_sum_f64(double* dev, int count, hipStream_t st) {
   Context& cx = ctx();
-  if (cx.nranks == 1) return;
+  if (cx.nranks == 1 && !cx.comm) return;
   if (cx.local) local_allreduce<double>(cx.local, cx.rank, cx.local->slot_f64, dev, count, st, false);
   else PG_NCCL(ncclAllReduce(dev, dev, count, ncclDouble, ncclSum, cx.comm, st));
 }
 
 void comm_allreduce_max_f64(double* dev, int count, hipStream_t st) {
   Context& cx = ctx();
-  if (cx.nranks == 1) return;
+  if (cx.nranks == 1 && !cx.comm) return;
   if (cx.local) local_allreduce<double>(cx.local, cx.rank, cx.local->slot_f64, dev, count, st, true);
   else PG_NCCL(ncclAllReduce(dev, dev, count, ncclDouble, ncclMax, cx.comm, st));
 }
 
 void comm_allreduce_sum_u64(unsigned long long* dev, i64 count, hipStream_t st) {
   Context& cx = ctx();
-  if (cx.nranks == 1) return;
+  if (cx.nranks == 1 && !cx.comm) return;
   if (cx.local) local_allreduce<unsigned long long>(cx.local, cx.rank, cx.local->slot_u64, dev, count, st, false);
   else PG_NCCL(ncclAllReduce(dev, dev, count, ncclUint64, ncclSum, cx.comm, st));
 }

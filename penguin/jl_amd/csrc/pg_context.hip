@@ -77,7 +77,7 @@ int32_t pg_init_distributed(int32_t device_id, int32_t rank, int32_t nranks, con
   init_device(device_id);
   c.rank = rank;
   c.nranks = nranks;
-  if (nranks > 1) {
+  if (nranks > 1 || unique_id128 != nullptr) {   // a 1-rank communicator is legal (used to smoke-test the RCCL path)
     PG_REQUIRE(unique_id128 != nullptr, "pg_init_distributed: unique id required when nranks > 1");
     ncclUniqueId id;
     std::memcpy(&id, unique_id128, sizeof(id));

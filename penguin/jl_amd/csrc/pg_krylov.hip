@@ -203,7 +203,7 @@ __global__ void k_derive(int phase, double* sc, int check_done) {
 
 void finalize(int phase, int nslots, KrylovWork& w, hipStream_t st, bool check_done) {
   Context& cx = ctx();
-  if (cx.nranks == 1) {
+  if (cx.nranks == 1 && !cx.comm) {
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, st, phase, nslots, w.grid, w.partials.p, w.sc.p, 1,
                        check_done ? 1 : 0);
   } else {

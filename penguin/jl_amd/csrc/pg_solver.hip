@@ -341,7 +341,9 @@ void setup_common(pg_solver* s, const pg_border_desc* borders, int nborders, con
 
   // initial condition, padded local layout
   s->T0pad.alloc((i64)s->K * s->Mloc);
-  for (int k = 0; k < s->K; ++k) s->T0pad.upload(T0 + (i64)k * s->M + slab.first_cell(), s->Mloc, (i64)k * s->Mloc);
+  s->T0pad.zero();   // T0 == NULL: zeros(2M) without a host array (multi-GPU sizes)
+  if (T0)
+    for (int k = 0; k < s->K; ++k) s->T0pad.upload(T0 + (i64)k * s->M + slab.first_cell(), s->Mloc, (i64)k * s->Mloc);
 
   // K10 once, K7/K9 for the constructor scheme
   const SysParams P = make_params(s, s->scheme_ctor);
@@ -379,7 +381,7 @@ double max_abs(pg_solver* s) {
     s->red_scratch.download(h.data(), g);
     for (double v : h) m = std::max(m, v);
   }
-  if (ctx().nranks > 1) {
+  if (ctx().nranks > 1 || ctx().comm) {
     DevBuf<double> d(1);
     d.upload(&m, 1);
     comm_allreduce_max_f64(d.p, 1, st);
@@ -484,7 +486,7 @@ int32_t pg_solver_create_unsteady_mono(pg_capacity* c, pg_diffops* o, const pg_b
                                        pg_solver** out) {
   PG_API_BEGIN
   require_init();
-  PG_REQUIRE(c && o && bc_interface && T0 && out, "pg_solver_create_unsteady_mono: NULL argument");
+  PG_REQUIRE(c && o && bc_interface && out, "pg_solver_create_unsteady_mono: NULL argument");
   PG_REQUIRE(o->cap == c, "operators were built from a different capacity");
   PG_REQUIRE(scheme == PG_SCHEME_BE || scheme == PG_SCHEME_CN, "scheme must be BE or CN");
   PG_REQUIRE(dt > 0.0, "dt must be positive");
@@ -514,7 +516,7 @@ int32_t pg_solver_create_unsteady_diph(pg_capacity* c1, pg_diffops* o1, pg_capac
                                        const double* T0, int32_t scheme, pg_solver** out) {
   PG_API_BEGIN
   require_init();
-  PG_REQUIRE(c1 && c2 && o1 && o2 && ic && T0 && out, "pg_solver_create_unsteady_diph: NULL argument");
+  PG_REQUIRE(c1 && c2 && o1 && o2 && ic && out, "pg_solver_create_unsteady_diph: NULL argument");
   PG_REQUIRE(c1->mesh == c2->mesh, "Phase capacities must share the same mesh.");
   PG_REQUIRE(c1->slab.p0 == c2->slab.p0 && c1->slab.p1 == c2->slab.p1, "phase capacities must share the slab partition");
   PG_REQUIRE(scheme == PG_SCHEME_BE || scheme == PG_SCHEME_CN, "scheme must be BE or CN");
