@@ -95,7 +95,7 @@ def main() -> None:
     dt = 0.75 * (4.0 / n) ** 2                         # benchmark/Heat3D.jl:69
     s = pj.DiffusionUnsteadyMono(phase, bcb, bci, dt, None, "BE")   # BE first (Heat3D.jl:72)
     setup_s = time.time() - t0
-    opts = L.pg_krylov_opts(L.PG_METHOD["bicgstab"], 1e-12, 0.0, 0, 4)
+    opts = L.pg_krylov_opts(L.PG_METHOD["bicgstab"], 1e-12, 0.0, 0, 4, int(os.environ.get("PG_WARM_START", "1")))
     info = L.pg_step_info()
     L.check(lib.pg_solver_initial_solve(s._h, C.byref(opts), C.byref(info)))
     CN = L.PG_SCHEME["CN"]                             # then CN (Heat3D.jl:74)

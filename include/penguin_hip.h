@@ -78,6 +78,8 @@ typedef struct {
   double abstol;
   int32_t maxiter;  /* <= 0: size of the reduced system              */
   int32_t check_every; /* host convergence poll period in iterations (<=0: default 4) */
+  int32_t warm_start;  /* != 0: pg_solver_step starts BiCGStab from the previous time level instead of zero
+                          (IterativeSolvers starts from zero; same solution to reltol, fewer iterations) */
 } pg_krylov_opts;
 
 typedef struct {

@@ -52,7 +52,7 @@ class pg_jump_desc(C.Structure):
 
 class pg_krylov_opts(C.Structure):
     _fields_ = [("method", C.c_int32), ("reltol", C.c_double), ("abstol", C.c_double), ("maxiter", C.c_int32),
-                ("check_every", C.c_int32)]
+                ("check_every", C.c_int32), ("warm_start", C.c_int32)]
 
 
 class pg_step_info(C.Structure):

@@ -599,7 +599,8 @@ def _krylov_opts(method, kwargs) -> L.pg_krylov_opts:
     name = name.lower()
     m = L.PG_METHOD["cg"] if name == "cg" else L.PG_METHOD["bicgstab"]
     return L.pg_krylov_opts(m, float(kwargs.get("reltol", 1e-12)), float(kwargs.get("abstol", 0.0)),
-                            int(kwargs.get("maxiter", 0)), int(kwargs.get("check_every", 4)))
+                            int(kwargs.get("maxiter", 0)), int(kwargs.get("check_every", 4)),
+                            int(bool(kwargs.get("warm_start", True))))
 
 
 def DiffusionUnsteadyMono(phase: Phase, bc_b: BorderConditions, bc_i, Δt: float, Tᵢ: np.ndarray, scheme: str,

@@ -27,8 +27,10 @@ struct SolveStats {
 void halo_exchange(const Numbering& nb, const Slab& slab, double* vec, hipStream_t st);
 // y[0..n) = A * x   (x must hold valid ghosts)
 void spmv(const CsrMatrix& A, const double* x, double* y, hipStream_t st);
-// x (n_vec, overwritten; zero initial guess) = A^{-1} b
+// x (n_vec, overwritten) = A^{-1} b.  x0 == nullptr: zero initial guess; else start from x0 with Ax0 = A*x0 given
+// (BiCGStab only).  x must not alias x0.
 void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, const double* b, double* x,
-                  KrylovWork& w, const pg_krylov_opts& opts, SolveStats& stats);
+                  KrylovWork& w, const pg_krylov_opts& opts, SolveStats& stats, const double* x0 = nullptr,
+                  const double* Ax0 = nullptr);
 
 }  // namespace pg

@@ -23,23 +23,31 @@ namespace {
 enum { PH_INIT = 0, PH_BICG_1, PH_BICG_2, PH_BICG_3, PH_CG_INIT, PH_CG_1, PH_CG_2 };
 
 // ---- fused vector kernels ---------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_bicg_init(i64 n, i64 nvec, const double* __restrict__ b, double* __restrict__ x,
-                                                     double* __restrict__ r, double* __restrict__ rhat,
-                                                     double* __restrict__ p, double* __restrict__ v,
-                                                     double* __restrict__ partials) {
+// x0 == nullptr: zero initial guess (IterativeSolvers' default).  Otherwise x = x0 and r = b - Ax0 (warm start with
+// the previous time level; Ax0 is the SpMV the CN right-hand side needs anyway).  partials: slot 0 = r.r, slot 1 = b.b
+__global__ __launch_bounds__(BLOCK) void k_bicg_init(i64 n, i64 nvec, const double* __restrict__ b,
+                                                     const double* __restrict__ x0, const double* __restrict__ Ax0,
+                                                     double* __restrict__ x, double* __restrict__ r,
+                                                     double* __restrict__ rhat, double* __restrict__ p,
+                                                     double* __restrict__ v, double* __restrict__ partials) {
   __shared__ double s_red[BLOCK / 64];
-  double acc = 0.0;
+  double acc = 0.0, accb = 0.0;
   for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < nvec; i += (i64)gridDim.x * BLOCK) {
     if (i < n) {
       const double bi = b[i];
-      x[i] = 0.0; r[i] = bi; rhat[i] = bi; p[i] = 0.0; v[i] = 0.0;
-      acc += bi * bi;
+      const double ri = x0 ? bi - Ax0[i] : bi;
+      x[i] = x0 ? x0[i] : 0.0;
+      r[i] = ri; rhat[i] = ri; p[i] = 0.0; v[i] = 0.0;
+      acc += ri * ri;
+      accb += bi * bi;
     } else {
       x[i] = 0.0; p[i] = 0.0;
     }
   }
   const double t = block_sum(acc, s_red);
   if (threadIdx.x == 0) partials[blockIdx.x] = t;
+  const double tb = block_sum(accb, s_red);
+  if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = tb;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_bicg_p(i64 n, const double* __restrict__ sc, const double* __restrict__ r,
@@ -136,10 +144,11 @@ __device__ inline void derive(int phase, double* sc) {
   switch (phase) {
     case PH_INIT:
     case PH_CG_INIT: {
-      sc[S_BB] = r0; sc[S_RR] = r0; sc[S_RHO] = r0; sc[S_RHO_OLD] = 1.0;
+      const double bb = phase == PH_INIT ? r1 : r0;   // BiCGStab init also reduces b.b (warm start: r0 != b)
+      sc[S_BB] = bb; sc[S_RR] = r0; sc[S_RHO] = r0; sc[S_RHO_OLD] = 1.0;
       sc[S_ALPHA] = 1.0; sc[S_OMEGA] = 1.0; sc[S_BETA] = 0.0; sc[S_ITERS] = 0.0;
       sc[S_RESTART] = 0.0; sc[S_RHAT2] = r0; sc[S_FORCE] = 0.0;
-      const double t2 = sc[S_RELTOL2] * r0;
+      const double t2 = sc[S_RELTOL2] * bb;
       sc[S_TOL2] = t2 > sc[S_ABSTOL2] ? t2 : sc[S_ABSTOL2];
       sc[S_DONE] = (r0 <= sc[S_TOL2]) ? 1.0 : 0.0;
       break;
@@ -271,7 +280,7 @@ void spmv(const CsrMatrix& A, const double* x, double* y, hipStream_t st) {
 }
 
 void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, const double* b, double* x, KrylovWork& w,
-                  const pg_krylov_opts& opts, SolveStats& stats) {
+                  const pg_krylov_opts& opts, SolveStats& stats, const double* x0, const double* Ax0) {
   Context& cx = ctx();
   hipStream_t st = cx.stream;
   const i64 n = A.n, nvec = nb.n_vec();
@@ -293,8 +302,9 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
 
   const bool cg = opts.method == PG_METHOD_CG;
   if (!cg) {
-    hipLaunchKernelGGL(k_bicg_init, dim3(G), dim3(BLOCK), 0, st, n, nvec, b, x, w.r.p, w.rhat.p, w.p.p, w.v.p, w.partials.p);
-    finalize(PH_INIT, 1, w, st, false);
+    hipLaunchKernelGGL(k_bicg_init, dim3(G), dim3(BLOCK), 0, st, n, nvec, b, x0, Ax0, x, w.r.p, w.rhat.p, w.p.p, w.v.p,
+                       w.partials.p);
+    finalize(PH_INIT, 2, w, st, false);
   } else {
     hipLaunchKernelGGL(k_cg_init, dim3(G), dim3(BLOCK), 0, st, n, nvec, b, x, w.r.p, w.p.p, w.partials.p);
     finalize(PH_CG_INIT, 1, w, st, false);

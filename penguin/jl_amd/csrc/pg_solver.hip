@@ -433,6 +433,7 @@ pg_krylov_opts default_opts() {
   o.abstol = 0.0;
   o.maxiter = 0;
   o.check_every = 4;
+  o.warm_start = 1;
   return o;
 }
 
@@ -456,19 +457,21 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
   ensure_run_matrix(s, scheme);
   const CsrMatrix& A = run_matrix(s);
   const i64 n = s->nb.n_own;
+  const bool warm = o.warm_start != 0 && o.method == PG_METHOD_BICGSTAB && n > 0;
   s->t += s->dt;                     // diffusion.jl:287
   ensure_bconst(s, scheme);
   if (n > 0) {
-    if (scheme == PG_SCHEME_CN) {
+    if (scheme == PG_SCHEME_CN || warm) {
       hipLaunchKernelGGL(k_scale_state, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, stream, n, A.ds.p, s->x.p, s->z.p, 1);
       halo_exchange(s->nb, s->slab, s->z.p, stream);
-      spmv(A, s->z.p, s->y.p, stream);   // Â S⁻¹ x = S A x
+      spmv(A, s->z.p, s->y.p, stream);   // Â S⁻¹ x = S A x : CN right-hand side and/or warm-start residual
     }
     hipLaunchKernelGGL(k_rhs, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, stream, n, scheme, s->x.p, s->y.p, A.ds.p, s->mass.p,
                        s->bconst.p, s->fixed.p, s->b.p);
     PG_HIP(hipGetLastError());
   }
-  krylov_solve(A, s->nb, s->slab, s->b.p, s->ysol.p, s->work, o, st);
+  // warm start: y0 = S⁻¹ x_prev (= z), r0 = b̂ - Â z (= b̂ - y): same solution, fewer iterations
+  krylov_solve(A, s->nb, s->slab, s->b.p, s->ysol.p, s->work, o, st, warm ? s->z.p : nullptr, warm ? s->y.p : nullptr);
   if (n > 0) {
     hipLaunchKernelGGL(k_scale_state, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, stream, n, A.ds.p, s->ysol.p, s->x.p, 0);
     PG_HIP(hipGetLastError());

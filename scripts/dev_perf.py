@@ -23,7 +23,8 @@ s = pj.DiffusionUnsteadyMono(ph, bcb, bc1, dt, u0, "BE")
 print(f"ctor (numbering+assembly): wall {time.time()-t0:.2f}s", flush=True)
 info = s.system_info(0)
 print("n_own", info.n_own, "nnz", info.nnz, "n_omega", info.n_omega, "n_gamma", info.n_gamma, flush=True)
-opts = L.pg_krylov_opts(0, 1e-12, 0.0, 0, 4)
+import os
+opts = L.pg_krylov_opts(0, 1e-12, 0.0, 0, 4, int(os.environ.get('PG_WARM_START', '1')))
 si = L.pg_step_info()
 L.check(L.lib().pg_solver_initial_solve(s._h, C.byref(opts), C.byref(si)))
 print("initial solve iters", si.iters, "conv", si.converged, "res", si.resnorm, "bnorm", si.bnorm, "ext", si.extremum, flush=True)
