@@ -49,7 +49,8 @@ def build_library(force: bool = False, verbose: bool = True) -> Path:
     for src in sources:
         obj = OBJ / (src.stem + ".o")
         if force or _newer(src, obj, headers):
-            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", *EXTRA.get(src.name, []), "-c", str(src),
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", *EXTRA.get(src.name, []),
+                   *os.environ.get("PG_HIPCC_FLAGS", "").split(), "-c", str(src),
                    "-o", str(obj)]
             jobs.append((src.name, cmd))
 

@@ -6,32 +6,39 @@
 // is gathered out of L2 / Infinity Cache.
 //
 // Design (CDNA4): the rows are cut once per matrix into CHUNKS of <= 64 consecutive rows and <= 512 entries
-// (CsrMatrix::chunk_start, the row-block idea of CSR-Adaptive).  One WAVE owns one chunk per iteration.  The
-// chunk's val/col entries are one contiguous range of the CSR arrays; the wave streams it with fully coalesced
-// loads into its PRIVATE slice of LDS -- no block barrier anywhere, a wave stalls only on its own loads -- and
-// then lane l walks row l out of LDS: column indices, all x gathers issued together, FMAs.  For a fixed
-// stencil slot consecutive lanes gather consecutive x entries, so the gathers coalesce too.
+// (CsrMatrix::chunk_desc = {first row, first entry} per chunk, the row-block idea of CSR-Adaptive).  One WAVE
+// owns one chunk per iteration.  The chunk's val/col entries are one contiguous range of the CSR arrays; the wave
+// streams it with fully coalesced loads into its PRIVATE slice of LDS -- no block barrier anywhere, a wave
+// stalls only on its own loads -- and then lane l walks row l out of LDS: column indices, all x gathers issued
+// together, FMAs.  For a fixed stencil slot consecutive lanes gather consecutive x entries, so the gathers
+// coalesce too.
 //
 // Everything inside an iteration is branch-free with a FIXED number of vector-memory operations (clamped
-// indices + selects).  Two reasons, both seen in the ISA: (1) hipcc puts every predicated load in its own basic
-// block behind `s_waitcnt vmcnt(0)`, which serialises the gathers; (2) vector-memory operations retire in
-// order, so the software pipeline below needs a COUNTED wait -- `s_waitcnt vmcnt(N)` lets the gathers of chunk
-// i complete while the N younger stream loads of chunk i+1 stay in flight -- and the compiler can only count
-// when every path issues the same number of loads.
+// indices + selects).  Reasons, all seen in the ISA / PMC (profiles/):
+//   (1) hipcc puts every predicated load in its own basic block behind `s_waitcnt vmcnt(0)`: the gathers serialise;
+//   (2) vector-memory operations retire in order, so overlapping the stream of chunk i+1 with the gathers of chunk
+//       i needs a COUNTED wait -- `s_waitcnt vmcnt(N)` lets the gathers complete while the N younger stream loads
+//       stay in flight -- and the compiler can only count when every path issues the same number of loads;
+//   (3) the chunk descriptor is a scalar load the stream addresses depend on: it is fetched TWO chunks ahead
+//       (3-stage software pipeline: descriptor(i+2) | stream(i+1) | gathers+FMA(i)), otherwise its latency sits in
+//       front of every stream (ablation: the kernel ran at the same 0.20 ms with the gathers removed).
 //
 // The dots that follow an SpMV in BiCGStab / CG are fused into the epilogue (one partial per block, summed in
 // fixed order by k_finalize: deterministic).
 //
 // Variants (PG_SPMV_VARIANT; default = best measured, see profiles/):
 //   1   block of 256 rows staged through LDS, two block barriers per chunk     (first version, 2.0 TB/s)
-//   2   chunked, wave-private LDS slices, branch-free                          (bit 1)
+//   2   chunked, wave-private LDS slices, branch-free, no pipelining           (bit 1)
 //   +4  non-temporal hint on the matrix stream (read once; keeps x in L2 / Infinity Cache)
-//   +8  XCD-contiguous chunk ranges (blocks sharing an XCD sweep one eighth of the chunks)
-//   +16 software pipeline inside the wave: the stream of chunk i+1 is issued behind the gathers of chunk i
+//   +16 3-stage software pipeline inside the wave
 #include <cstdlib>
 #include <vector>
 
 #include "pg_spmv.h"
+
+#ifndef PG_SPMV_ABLATE
+#define PG_SPMV_ABLATE 0   // diagnostics builds only (scripts/spmv_ablate.sh)
+#endif
 
 namespace pg {
 namespace {
@@ -103,38 +110,43 @@ __device__ inline T stream_load(const T* p) {
   return *p;
 }
 
-struct Chunk {
-  int r0, nrows;       // wave-uniform (scalar loads)
-  int base, cnt;       // wave-uniform: first entry / number of entries
-  int ra, rb;          // this lane's row bounds, ABSOLUTE and raw: nothing consumes them in the issue phase
+struct Desc {          // wave-uniform (SGPRs): rows [r0,r1), entries [base,end)
+  int r0, base, r1, end;
+};
+
+__device__ inline Desc load_desc(const int* __restrict__ cd, i64 ch) {
+  // 4 consecutive ints at a wave-uniform address: one s_load_dwordx4 (lgkmcnt, independent of vmcnt)
+  const int* p = cd + 2 * ch;
+  Desc d;
+  d.r0 = p[0]; d.base = p[1]; d.r1 = p[2]; d.end = p[3];
+  return d;
+}
+
+struct Stream {        // registers holding one chunk's raw loads
+  int ra, rb;          // this lane's row bounds, ABSOLUTE: nothing consumes them in the issue phase
   double tv[WITER];
   int tc[WITER];
 };
 
-// issue every load of a chunk -- always 2 + 2*WITER vector loads, branch-free
+// issue every vector load of a chunk -- always 2 + 2*WITER loads, branch-free, no dependent scalar load
 template <bool NT>
-__device__ inline void chunk_issue(Chunk& q, i64 ch, const int* __restrict__ chunk_start, const int* __restrict__ rowptr,
-                                   const int* __restrict__ col, const double* __restrict__ val, int lane) {
-  q.r0 = chunk_start[ch];                       // uniform address -> s_load (lgkmcnt, not vmcnt)
-  const int r1 = chunk_start[ch + 1];
-  q.nrows = r1 - q.r0;
-  q.base = rowptr[q.r0];
-  q.cnt = rowptr[r1] - q.base;
-  const int r = q.r0 + lane;
-  q.ra = stream_load<NT>(rowptr + (r < r1 ? r : r1));
-  q.rb = stream_load<NT>(rowptr + (r + 1 < r1 ? r + 1 : r1));
-  const int last = q.cnt > 0 ? q.cnt - 1 : 0;
+__device__ inline void stream_issue(Stream& q, const Desc& d, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                    const double* __restrict__ val, int lane) {
+  const int r = d.r0 + lane;
+  q.ra = stream_load<NT>(rowptr + (r < d.r1 ? r : d.r1));
+  q.rb = stream_load<NT>(rowptr + (r + 1 < d.r1 ? r + 1 : d.r1));
+  const int last = d.end - d.base > 0 ? d.end - d.base - 1 : 0;
 #pragma unroll
   for (int j = 0; j < WITER; ++j) {
     const int k = lane + 64 * j;
     const int kk = k < last ? k : last;         // tail lanes re-read the last entry (one cache line)
-    q.tv[j] = stream_load<NT>(val + q.base + kk);
-    q.tc[j] = stream_load<NT>(col + q.base + kk);
+    q.tv[j] = stream_load<NT>(val + d.base + kk);
+    q.tc[j] = stream_load<NT>(col + d.base + kk);
   }
 }
 
-template <int MODE, bool NT, bool XCD, bool PIPE>
-__global__ __launch_bounds__(BLOCK) void k_spmv_c(i64 n, i64 nchunks, const int* __restrict__ chunk_start,
+template <int MODE, bool NT, bool PIPE>
+__global__ __launch_bounds__(BLOCK) void k_spmv_c(i64 n, i64 nchunks, const int* __restrict__ chunk_desc,
                                                   const int* __restrict__ rowptr, const int* __restrict__ col,
                                                   const double* __restrict__ val, const double* __restrict__ x,
                                                   double* __restrict__ y, const double* __restrict__ aux,
@@ -148,23 +160,34 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_c(i64 n, i64 nchunks, const int*
   double* __restrict__ sv = s_val[wave];
   int* __restrict__ scl = s_col[wave];
   double acc0 = 0.0, acc1 = 0.0;
-  i64 c_hi = nchunks, first = (i64)blockIdx.x * (BLOCK / 64) + wave, wstride = (i64)gridDim.x * (BLOCK / 64);
-  if (XCD && (gridDim.x & 7) == 0) {
-    // blocks b and b+8 share an XCD (observed round-robin placement: speed only, never correctness)
-    const int xcd = blockIdx.x & 7, g = blockIdx.x >> 3, gpx = gridDim.x >> 3;
-    const i64 c_lo = nchunks * xcd / 8;
-    c_hi = nchunks * (xcd + 1) / 8;
-    first = c_lo + (i64)g * (BLOCK / 64) + wave;
-    wstride = (i64)gpx * (BLOCK / 64);
+  const i64 first = (i64)blockIdx.x * (BLOCK / 64) + wave, wstride = (i64)gridDim.x * (BLOCK / 64);
+  const i64 lastc = nchunks - 1;
+  Stream q;
+  Desc dcur, dnext;
+  if (first < nchunks) {
+    dcur = load_desc(chunk_desc, first);
+    dnext = load_desc(chunk_desc, first + wstride < nchunks ? first + wstride : lastc);
+    if (PIPE) stream_issue<NT>(q, dcur, rowptr, col, val, lane);
   }
-  Chunk q;
-  if (PIPE && first < c_hi) chunk_issue<NT>(q, first, chunk_start, rowptr, col, val, lane);
-  for (i64 chunk = first; chunk < c_hi; chunk += wstride) {
-    if (!PIPE) chunk_issue<NT>(q, chunk, chunk_start, rowptr, col, val, lane);
-    const int r = q.r0 + lane;
-    const bool live = lane < q.nrows;
-    const int a = q.ra - q.base, b = q.rb - q.base;
-    // stream -> LDS slice (fixed 2*WITER stores; slots past cnt hold copies of the last entry)
+  for (i64 chunk = first; chunk < nchunks; chunk += wstride) {
+    if (!PIPE) stream_issue<NT>(q, dcur, rowptr, col, val, lane);
+    const int r = dcur.r0 + lane;
+    const bool live = r < dcur.r1;
+    const int a = q.ra - dcur.base, b = q.rb - dcur.base;
+#if PG_SPMV_ABLATE == 3
+    // ablation: stream only -- no LDS, no gathers: consume the registers directly
+    double sum3 = 0.0;
+#pragma unroll
+    for (int j = 0; j < WITER; ++j) sum3 += q.tv[j] * (double)q.tc[j];
+    const i64 c23 = chunk + 2 * wstride;
+    const Desc dn23 = load_desc(chunk_desc, c23 < nchunks ? c23 : lastc);
+    if (PIPE) stream_issue<NT>(q, dnext, rowptr, col, val, lane);
+    if (live) y[r] = sum3 + a + b;
+    dcur = dnext;
+    dnext = dn23;
+    continue;
+#endif
+    // stream -> LDS slice (fixed 2*WITER stores; slots past the chunk hold copies of its last entry)
 #pragma unroll
     for (int j = 0; j < WITER; ++j) {
       sv[lane + 64 * j] = q.tv[j];
@@ -175,28 +198,41 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_c(i64 n, i64 nchunks, const int*
 #pragma unroll
     for (int j = 0; j < WUNR; ++j) {
       const int p = a + j < b ? a + j : 0;      // slot 0 always holds a valid column
+#if PG_SPMV_ABLATE == 1
+      xv[j] = 1.0 + p;                          // ablation: no gathers
+#elif PG_SPMV_ABLATE == 2
+      xv[j] = x[scl[p] & 1023];                 // ablation: gathers always hit L1/L2
+#else
       xv[j] = x[scl[p]];
+#endif
       vv[j] = a + j < b ? sv[p] : 0.0;
     }
-    if (PIPE) {
-      // behind the gathers: these 2 + 2*WITER loads stay in flight while the gathers retire (counted vmcnt)
-      const i64 next = chunk + wstride < c_hi ? chunk + wstride : chunk;
-      chunk_issue<NT>(q, next, chunk_start, rowptr, col, val, lane);
-    }
+    // stage 1 of the NEXT iteration and stage 0 of the one after: both behind this chunk's gathers
+    const i64 c2 = chunk + 2 * wstride;
+    const Desc dnext2 = load_desc(chunk_desc, c2 < nchunks ? c2 : lastc);
+    if (PIPE) stream_issue<NT>(q, dnext, rowptr, col, val, lane);   // counted vmcnt keeps these in flight
     double sum = 0.0;
 #pragma unroll
     for (int j = 0; j < WUNR; ++j) sum += vv[j] * xv[j];
     if (__builtin_expect(b - a > WUNR, 0))
-      for (int k = a + WUNR; k < b; ++k) sum += sv[k] * x[scl[k]];            // cut-cell rows (> 8 entries)
+      for (int k = a + WUNR; k < b; ++k) sum += sv[k] * x[scl[k]];   // cut-cell rows (> 8 entries)
     __builtin_amdgcn_wave_barrier();
     if (live) {
+#if PG_SPMV_ABLATE == 4
+      if (sum == 1.2345e-300) y[r] = sum;   // ablation: no y store
+#elif PG_SPMV_ABLATE == 5
+      __builtin_nontemporal_store(sum, &y[r]);
+#else
       y[r] = sum;
+#endif
       if (MODE == 1) acc0 += aux[r] * sum;
       if (MODE == 2) {
         acc0 += sum * x[r];
         acc1 += sum * sum;
       }
     }
+    dcur = dnext;
+    dnext = dnext2;
   }
   if (MODE >= 1) {
     const double t0 = block_sum(acc0, s_red);
@@ -213,16 +249,9 @@ int variant() {
   return v;
 }
 
-#define PG_LAUNCH_C(KERNEL)                                                                                     \
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL), dim3(grid), dim3(BLOCK), 0, st, A.n, A.nchunks, A.chunk_start.p, \
+#define PG_LAUNCH_C(KERNEL)                                                                                    \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL), dim3(grid), dim3(BLOCK), 0, st, A.n, A.nchunks, A.chunk_desc.p, \
                      A.rowptr.p, A.col.p, A.val.p, x, y, aux, partials, sc)
-
-template <int MODE, bool NT, bool XCD>
-void launch_c(bool pipe, const CsrMatrix& A, const double* x, double* y, const double* aux, double* partials,
-              const double* sc, int grid, hipStream_t st) {
-  if (pipe) PG_LAUNCH_C((k_spmv_c<MODE, NT, XCD, true>));
-  else PG_LAUNCH_C((k_spmv_c<MODE, NT, XCD, false>));
-}
 
 template <int MODE>
 void launch_mode(const CsrMatrix& A, const double* x, double* y, const double* aux, double* partials, const double* sc,
@@ -233,11 +262,11 @@ void launch_mode(const CsrMatrix& A, const double* x, double* y, const double* a
                        aux, partials, sc);
     return;
   }
-  const bool nt = (v & 4) != 0, xcd = (v & 8) != 0, pipe = (v & 16) != 0;
-  if (nt && xcd) launch_c<MODE, true, true>(pipe, A, x, y, aux, partials, sc, grid, st);
-  else if (nt) launch_c<MODE, true, false>(pipe, A, x, y, aux, partials, sc, grid, st);
-  else if (xcd) launch_c<MODE, false, true>(pipe, A, x, y, aux, partials, sc, grid, st);
-  else launch_c<MODE, false, false>(pipe, A, x, y, aux, partials, sc, grid, st);
+  const bool nt = (v & 4) != 0, pipe = (v & 16) != 0;
+  if (nt && pipe) PG_LAUNCH_C((k_spmv_c<MODE, true, true>));
+  else if (nt) PG_LAUNCH_C((k_spmv_c<MODE, true, false>));
+  else if (pipe) PG_LAUNCH_C((k_spmv_c<MODE, false, true>));
+  else PG_LAUNCH_C((k_spmv_c<MODE, false, false>));
 }
 
 }  // namespace
@@ -246,20 +275,24 @@ void launch_mode(const CsrMatrix& A, const double* x, double* y, const double* a
 void build_spmv_chunks(CsrMatrix& A) {
   std::vector<int> rp(A.n + 1);
   A.rowptr.download(rp.data(), A.n + 1);
-  std::vector<int> cs;
-  cs.reserve(A.n / 60 + 16);
+  std::vector<int> cd;   // {first row, first entry} per chunk, closed by {n, nnz}; padded for the 4-int descriptor read
+  cd.reserve(2 * (A.n / 60 + 16));
   i64 r = 0;
-  cs.push_back(0);
   while (r < A.n) {
     i64 e = r + 1;   // a chunk holds at least one row (rows never exceed the slice: <= 4(2N+1) entries)
     PG_REQUIRE(rp[e] - rp[r] <= SPMV_CHUNK_ENTRIES, "CSR row longer than an SpMV chunk");
     while (e < A.n && e - r < 64 && rp[e + 1] - rp[r] <= SPMV_CHUNK_ENTRIES) ++e;
-    cs.push_back((int)e);
+    cd.push_back((int)r);
+    cd.push_back(rp[r]);
     r = e;
   }
-  A.nchunks = (i64)cs.size() - 1;
-  A.chunk_start.alloc((i64)cs.size());
-  A.chunk_start.upload(cs.data(), (i64)cs.size());
+  A.nchunks = (i64)cd.size() / 2;
+  cd.push_back((int)A.n);
+  cd.push_back(rp[A.n]);
+  cd.push_back((int)A.n);   // pad
+  cd.push_back(rp[A.n]);
+  A.chunk_desc.alloc((i64)cd.size());
+  A.chunk_desc.upload(cd.data(), (i64)cd.size());
 }
 
 int spmv_default_grid(i64 n) {

@@ -42,8 +42,9 @@ struct CsrMatrix {
   DevBuf<int> rowptr, col;
   DevBuf<double> val;
   DevBuf<double> ds;   // n_vec
-  // SpMV row blocks: chunk c = rows [chunk_start[c], chunk_start[c+1]), <= 64 rows and <= SPMV_CHUNK_ENTRIES entries
-  DevBuf<int> chunk_start;
+  // SpMV row blocks: chunk c = {first row, first entry} = chunk_desc[2c, 2c+1]; <= 64 rows, <= SPMV_CHUNK_ENTRIES
+  // entries; closed by {n, nnz}
+  DevBuf<int> chunk_desc;
   i64 nchunks = 0;
 };
 constexpr int SPMV_CHUNK_ENTRIES = 512;
