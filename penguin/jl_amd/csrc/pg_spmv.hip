@@ -31,6 +31,7 @@
 //   2   chunked, wave-private LDS slices, branch-free, no pipelining           (bit 1)
 //   +4  non-temporal hint on the matrix stream (read once; keeps x in L2 / Infinity Cache)
 //   +16 3-stage software pipeline inside the wave
+//   +32 16-byte (aligned pair / quad) stream loads
 #include <cstdlib>
 #include <vector>
 
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv(i64 n, const int* __restrict__ r
 }
 
 // ---- chunked wave kernel ---------------------------------------------------------------------------------------
-constexpr int WITER = SPMV_CHUNK_ENTRIES / 64;   // staging loads per lane (8)
+constexpr int WITER = 8;                         // staging loads per lane: 512 slots >= SPMV_CHUNK_ENTRIES
 constexpr int WUNR = 8;                          // gathers issued together per row (bulk rows: 2N+1 <= 7)
 
 template <bool NT, class T>
@@ -151,8 +152,8 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_c(i64 n, i64 nchunks, const int*
                                                   const double* __restrict__ val, const double* __restrict__ x,
                                                   double* __restrict__ y, const double* __restrict__ aux,
                                                   double* __restrict__ partials, const double* __restrict__ sc) {
-  __shared__ double s_val[BLOCK / 64][SPMV_CHUNK_ENTRIES];
-  __shared__ int s_col[BLOCK / 64][SPMV_CHUNK_ENTRIES];
+  __shared__ double s_val[BLOCK / 64][64 * WITER];
+  __shared__ int s_col[BLOCK / 64][64 * WITER];
   __shared__ double s_red[BLOCK / 64];
   if (sc && sc[S_DONE] != 0.0) return;
   const int lane = threadIdx.x & 63;
@@ -244,8 +245,122 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_c(i64 n, i64 nchunks, const int*
   }
 }
 
+// ---- same kernel with 16-byte stream loads (bit 32) ------------------------------------------------------------
+// values are read as aligned pairs of doubles starting at base & ~1, columns as aligned quads of ints starting at
+// base & ~3 (1 KiB per wave instruction, the widest coalesced access; 6 instead of 16 stream instructions per
+// chunk); the LDS image keeps the same shift.  Chunks hold <= 508 entries so the shifted image fits 512 slots;
+// CsrMatrix pads val/col by 8 entries so the widened reads stay inside the allocation.
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef int i4_t __attribute__((ext_vector_type(4)));
+constexpr int XV_IT = 4, XC_IT = 2;
+
+struct StreamW {
+  int ra, rb;
+  d2_t v[XV_IT];
+  i4_t c[XC_IT];
+};
+
+template <bool NT>
+__device__ inline void stream_issue_w(StreamW& q, const Desc& d, const int* __restrict__ rowptr,
+                                      const int* __restrict__ col, const double* __restrict__ val, int lane) {
+  const int r = d.r0 + lane;
+  q.ra = stream_load<NT>(rowptr + (r < d.r1 ? r : d.r1));
+  q.rb = stream_load<NT>(rowptr + (r + 1 < d.r1 ? r + 1 : d.r1));
+  const int basev = d.base & ~1, basec = d.base & ~3;
+  const int endm1 = d.end > d.base ? d.end - 1 : d.base;
+  const int lastp = (endm1 - basev) >> 1, lastq = (endm1 - basec) >> 2;
+  const d2_t* vp = reinterpret_cast<const d2_t*>(val + basev);
+  const i4_t* cp = reinterpret_cast<const i4_t*>(col + basec);
+#pragma unroll
+  for (int j = 0; j < XV_IT; ++j) {
+    const int k = lane + 64 * j;
+    q.v[j] = stream_load<NT>(vp + (k < lastp ? k : lastp));
+  }
+#pragma unroll
+  for (int j = 0; j < XC_IT; ++j) {
+    const int k = lane + 64 * j;
+    q.c[j] = stream_load<NT>(cp + (k < lastq ? k : lastq));
+  }
+}
+
+template <int MODE, bool NT, bool PIPE>
+__global__ __launch_bounds__(BLOCK) void k_spmv_cw(i64 n, i64 nchunks, const int* __restrict__ chunk_desc,
+                                                   const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                   const double* __restrict__ val, const double* __restrict__ x,
+                                                   double* __restrict__ y, const double* __restrict__ aux,
+                                                   double* __restrict__ partials, const double* __restrict__ sc) {
+  __shared__ __attribute__((aligned(16))) double s_val[BLOCK / 64][512];
+  __shared__ __attribute__((aligned(16))) int s_col[BLOCK / 64][512];
+  __shared__ double s_red[BLOCK / 64];
+  if (sc && sc[S_DONE] != 0.0) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double* __restrict__ sv = s_val[wave];
+  int* __restrict__ scl = s_col[wave];
+  d2_t* sv2 = reinterpret_cast<d2_t*>(sv);
+  i4_t* sc4 = reinterpret_cast<i4_t*>(scl);
+  double acc0 = 0.0, acc1 = 0.0;
+  const i64 first = (i64)blockIdx.x * (BLOCK / 64) + wave, wstride = (i64)gridDim.x * (BLOCK / 64);
+  const i64 lastc = nchunks - 1;
+  StreamW q;
+  Desc dcur, dnext;
+  if (first < nchunks) {
+    dcur = load_desc(chunk_desc, first);
+    dnext = load_desc(chunk_desc, first + wstride < nchunks ? first + wstride : lastc);
+    if (PIPE) stream_issue_w<NT>(q, dcur, rowptr, col, val, lane);
+  }
+  for (i64 chunk = first; chunk < nchunks; chunk += wstride) {
+    if (!PIPE) stream_issue_w<NT>(q, dcur, rowptr, col, val, lane);
+    const int r = dcur.r0 + lane;
+    const bool live = r < dcur.r1;
+    const int basev = dcur.base & ~1, basec = dcur.base & ~3;
+    const int av = q.ra - basev, ac = q.ra - basec, len = q.rb - q.ra;
+#pragma unroll
+    for (int j = 0; j < XV_IT; ++j) sv2[lane + 64 * j] = q.v[j];
+#pragma unroll
+    for (int j = 0; j < XC_IT; ++j) sc4[lane + 64 * j] = q.c[j];
+    __builtin_amdgcn_wave_barrier();
+    double xv[WUNR], vv[WUNR];
+    const int c0 = dcur.base - basec;           // first real column slot of the chunk: always valid
+#pragma unroll
+    for (int j = 0; j < WUNR; ++j) {
+      const bool ok = j < len;
+      xv[j] = x[scl[ok ? ac + j : c0]];
+      vv[j] = ok ? sv[av + j] : 0.0;
+    }
+    const i64 c2 = chunk + 2 * wstride;
+    const Desc dnext2 = load_desc(chunk_desc, c2 < nchunks ? c2 : lastc);
+    if (PIPE) stream_issue_w<NT>(q, dnext, rowptr, col, val, lane);
+    double sum = 0.0;
+#pragma unroll
+    for (int j = 0; j < WUNR; ++j) sum += vv[j] * xv[j];
+    if (__builtin_expect(len > WUNR, 0))
+      for (int k = WUNR; k < len; ++k) sum += sv[av + k] * x[scl[ac + k]];
+    __builtin_amdgcn_wave_barrier();
+    if (live) {
+      y[r] = sum;
+      if (MODE == 1) acc0 += aux[r] * sum;
+      if (MODE == 2) {
+        acc0 += sum * x[r];
+        acc1 += sum * sum;
+      }
+    }
+    dcur = dnext;
+    dnext = dnext2;
+  }
+  if (MODE >= 1) {
+    const double t0 = block_sum(acc0, s_red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t0;
+  }
+  if (MODE == 2) {
+    const double t1 = block_sum(acc1, s_red);
+    if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = t1;
+  }
+}
+
 int variant() {
-  static const int v = getenv("PG_SPMV_VARIANT") ? atoi(getenv("PG_SPMV_VARIANT")) : 22;   // chunked + NT + pipelined
+  // default 38 = chunked + non-temporal + 16-byte stream loads (pipelining measured neutral: profiles/r01_spmv_sweeps.txt)
+  static const int v = getenv("PG_SPMV_VARIANT") ? atoi(getenv("PG_SPMV_VARIANT")) : 38;
   return v;
 }
 
@@ -263,6 +378,13 @@ void launch_mode(const CsrMatrix& A, const double* x, double* y, const double* a
     return;
   }
   const bool nt = (v & 4) != 0, pipe = (v & 16) != 0;
+  if (v & 32) {
+    if (nt && pipe) PG_LAUNCH_C((k_spmv_cw<MODE, true, true>));
+    else if (nt) PG_LAUNCH_C((k_spmv_cw<MODE, true, false>));
+    else if (pipe) PG_LAUNCH_C((k_spmv_cw<MODE, false, true>));
+    else PG_LAUNCH_C((k_spmv_cw<MODE, false, false>));
+    return;
+  }
   if (nt && pipe) PG_LAUNCH_C((k_spmv_c<MODE, true, true>));
   else if (nt) PG_LAUNCH_C((k_spmv_c<MODE, true, false>));
   else if (pipe) PG_LAUNCH_C((k_spmv_c<MODE, false, true>));
@@ -296,7 +418,7 @@ void build_spmv_chunks(CsrMatrix& A) {
 }
 
 int spmv_default_grid(i64 n) {
-  static const int per_cu = getenv("PG_SPMV_BLOCKS_PER_CU") ? atoi(getenv("PG_SPMV_BLOCKS_PER_CU")) : 5;
+  static const int per_cu = getenv("PG_SPMV_BLOCKS_PER_CU") ? atoi(getenv("PG_SPMV_BLOCKS_PER_CU")) : 6;
   static int cus = 0;
   if (cus == 0) {
     hipDeviceProp_t prop;

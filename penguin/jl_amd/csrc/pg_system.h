@@ -47,7 +47,7 @@ struct CsrMatrix {
   DevBuf<int> chunk_desc;
   i64 nchunks = 0;
 };
-constexpr int SPMV_CHUNK_ENTRIES = 512;
+constexpr int SPMV_CHUNK_ENTRIES = 508;   // + alignment shift (<= 3) fits the 512-slot LDS slice of a wave
 void build_spmv_chunks(CsrMatrix& A);   // pg_spmv.hip
 
 void build_numbering(const SysParams& P, const Slab& slab, Numbering& nb);

@@ -478,3 +478,62 @@ def test_body_outside_domain_and_body_covering_domain(pj):
 def test_uninitialised_solver_raises(pj):
     with pytest.raises(pj.PenguinHipError, match="Solver is not initialized"):
         pj.solve_DiffusionUnsteadyMono_b(None, None, 0.1, 1.0, None, None, "BE")
+
+
+# ------------------------------------------------------------------------------------ BASELINE configs 2 and 5 at full size
+def test_full_size_properties_config2_2048sq(pj):
+    """BASELINE config 2: 2-D mono 2048^2, circle, BE (BenchmarkHeatSol.jl shape) -- size-independent properties."""
+    n = 2048
+    mesh = pj.Mesh((n, n), (4.0, 4.0))
+    cap = pj.Capacity(pj.Sphere((2.01, 2.01), 1.0), mesh)
+    V, G, ct = cap.V, cap.Γ, cap.cell_types
+    assert V.sum() == pytest.approx(math.pi, rel=1e-11)
+    assert G.sum() == pytest.approx(2.0 * math.pi, rel=1e-11)
+    assert np.array_equal(np.flatnonzero(ct == -1), np.flatnonzero(G > 0))
+    M = (n + 1) ** 2
+    ph = pj.Phase(cap, pj.DiffusionOps(cap), 0.0, 1.0)
+    bcb = pj.BorderConditions({k: pj.Dirichlet(0.0) for k in HEAT_BORDERS})
+    dt = 0.25 * (4.0 / n) ** 2
+    u0 = np.concatenate([np.zeros(M), np.ones(M)])
+    s = pj.DiffusionUnsteadyMono(ph, bcb, pj.Dirichlet(1.0), dt, u0, "BE")
+    info = s.system_info(0)
+    assert info.n_gamma == np.count_nonzero(G > 0)
+    assert info.n_omega == np.count_nonzero(V > 0) + 4 * n - 4          # fluid cells + the solid border ring
+    pj.solve_DiffusionUnsteadyMono_b(s, ph, dt, 5 * dt, bcb, pj.Dirichlet(1.0), "BE", save_states=False)
+    Tw = s.x[:M]
+    fluid = V > 0
+    assert Tw[fluid].min() > -1e-9 and Tw[fluid].max() < 1.0 + 1e-9
+    assert np.all(s.x[M:][G > 0] == pytest.approx(1.0, abs=1e-9))
+    assert np.all(s.x[:M][(V == 0) & (ct == 0)] == 0.0)                 # border ring = Dirichlet(0), eliminated cells = 0
+    # heat enters through the interface: the total grows monotonically with time
+    s2 = pj.DiffusionUnsteadyMono(ph, bcb, pj.Dirichlet(1.0), dt, u0, "BE")
+    pj.solve_DiffusionUnsteadyMono_b(s2, ph, dt, 2 * dt, bcb, pj.Dirichlet(1.0), "BE", save_states=False)
+    assert float(V @ s.x[:M]) > float(V @ s2.x[:M]) > 0.0
+
+
+def test_full_size_properties_config5_1024sq_diphasic(pj):
+    """BASELINE config 5: 2-D diphasic 1024^2 (benchmark/Heat_2ph_2D.jl shape): BE first solve, then CN."""
+    n, Lx, c, r = 1024, 8.0, (4.0, 4.0), 2.0
+    M = (n + 1) ** 2
+    mesh = pj.Mesh((n, n), (Lx, Lx))
+    cap1, cap2 = pj.Capacity(pj.Sphere(c, r), mesh), pj.Capacity(pj.Sphere(c, r, complement=True), mesh)
+    assert cap1.V.sum() + cap2.V.sum() == pytest.approx(Lx * Lx, rel=1e-12)        # the two phases tile the box
+    assert np.allclose(cap1.Γ, cap2.Γ, rtol=0, atol=1e-12)                          # one interface, seen from both sides
+    assert np.array_equal(cap1.cell_types == -1, cap2.cell_types == -1)
+    p1, p2 = pj.Phase(cap1, pj.DiffusionOps(cap1), 0.0, 1.0), pj.Phase(cap2, pj.DiffusionOps(cap2), 0.0, 1.0)
+    ic = pj.InterfaceConditions(pj.ScalarJump(1.0, 1.0, 0.0), pj.FluxJump(1.0, 1.0, 0.0))
+    bcb = pj.BorderConditions({})
+    dt = 0.5 * (Lx / n) ** 2
+    u0 = np.concatenate([np.ones(M), np.ones(M), np.zeros(M), np.zeros(M)])
+    s = pj.DiffusionUnsteadyDiph(p1, p2, bcb, ic, dt, u0, "BE")
+    info = s.system_info(0)
+    assert info.n_own > 2 * n * n * 0.99                                             # both phases are (almost) everywhere
+    pj.solve_DiffusionUnsteadyDiph_b(s, p1, p2, dt, 4 * dt, bcb, ic, "CN", save_states=False)
+    T1, Tg1, T2, Tg2 = s.x[:M], s.x[M:2 * M], s.x[2 * M:3 * M], s.x[3 * M:]
+    f1, f2 = cap1.V > 0, cap2.V > 0
+    assert T1[f1].min() > -1e-8 and T1[f1].max() < 1 + 1e-8 and T2[f2].min() > -1e-8 and T2[f2].max() < 1 + 1e-8
+    cut = cap1.Γ > 0
+    assert np.max(np.abs(Tg1[cut] - Tg2[cut])) < 1e-9                                # scalar jump [[T]] = 0 (He = 1)
+    # far from the interface nothing has happened yet
+    assert T1[lin := (n + 1) * (n // 2) + n // 2] == pytest.approx(1.0, abs=1e-9)
+    assert abs(T2[5 * (n + 1) + 5]) < 1e-12
