@@ -193,7 +193,10 @@ int32_t pg_solver_num_states(const pg_solver* s, int64_t* out);
 /* x: full unknown vector (2M mono / 4M diph) with zeros at eliminated unknowns (solver.jl:186-187).
    state_index < 0: current s.x.  With nranks>1 only owned entries are written (others untouched). */
 int32_t pg_solver_get_state(const pg_solver* s, int64_t state_index, double* x, int64_t len);
-int32_t pg_solver_system_info(const pg_solver* s, int32_t which /*0 = ctor A, 1 = run A*/, pg_system_info* out);
+/* which: 0 = constructor system, 1 = run (loop) system: the reference's reduced A x = b;
+          2 / 3 = the same two systems as the Krylov solver iterates on them, left-preconditioned and
+          equilibrated: (B^-1 S A S) y = B^-1 S b, x = S y (DESIGN.md "Preconditioner"); nnz differs. */
+int32_t pg_solver_system_info(const pg_solver* s, int32_t which, pg_system_info* out);
 /* reduced system of this rank as CSR (rowptr n_own+1, col nnz (local numbering: owned then ghosts), val nnz)
    plus b (n_own) and the map idx[n_own] -> index in the full 2M/4M vector (the reference's common_idx). */
 int32_t pg_solver_get_system_csr(const pg_solver* s, int32_t which, int64_t* rowptr, int64_t* col, double* val,

@@ -258,7 +258,7 @@ void build_numbering(const SysParams& P, const Slab& s, Numbering& nb) {
   PG_HIP(hipStreamSynchronize(st));
 }
 
-void assemble_csr(const SysParams& P, const Slab& s, const Numbering& nb, CsrMatrix& A) {
+void assemble_csr(const SysParams& P, const Slab& s, const Numbering& nb, CsrMatrix& A, bool scale) {
   hipStream_t st = ctx().stream;
   const i64 n = nb.n_own;
   A.n = n;
@@ -289,13 +289,15 @@ void assemble_csr(const SysParams& P, const Slab& s, const Numbering& nb, CsrMat
   hipLaunchKernelGGL(k_fill, dim3(gr), dim3(256), 0, st, P, seg, nb.Mloc, n, nb.row_cell.p, nb.red.p, A.rowptr.p, A.col.p,
                      A.val.p);
   PG_HIP(hipGetLastError());
-  // symmetric diagonal equilibration folded into the values (see CsrMatrix)
-  A.ds.alloc(nb.n_vec());
-  hipLaunchKernelGGL(k_diag_scale, dim3(grid_for((i64)nb.K * nb.Mloc, 256, 256 * 16)), dim3(256), 0, st, P, nb.K, nb.Mloc,
-                     nb.red.p, A.ds.p);
-  PG_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_scale_vals, dim3(gr), dim3(256), 0, st, n, A.rowptr.p, A.col.p, A.ds.p, A.val.p);
-  PG_HIP(hipGetLastError());
+  if (scale) {
+    // symmetric diagonal equilibration folded into the values (see CsrMatrix)
+    A.ds.alloc(nb.n_vec());
+    hipLaunchKernelGGL(k_diag_scale, dim3(grid_for((i64)nb.K * nb.Mloc, 256, 256 * 16)), dim3(256), 0, st, P, nb.K, nb.Mloc,
+                       nb.red.p, A.ds.p);
+    PG_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_scale_vals, dim3(gr), dim3(256), 0, st, n, A.rowptr.p, A.col.p, A.ds.p, A.val.p);
+    PG_HIP(hipGetLastError());
+  }
   PG_HIP(hipStreamSynchronize(st));
   build_spmv_chunks(A);
 }

@@ -172,6 +172,28 @@ __global__ void k_rhs(i64 n, int scheme, const double* __restrict__ x, const dou
   }
 }
 
+// K8 for the rows of cells with a non-trivial preconditioner block (overwrites what k_rhs wrote there):
+//   b̂_r = Σ_j (B⁻¹S)[r,j] c_j  -  Σ_j (B⁻¹MB)[r,j] ŷ_j      c = un-preconditioned constant part, ŷ = Â S⁻¹x
+__global__ void k_rhs_block(i64 nblk, int scheme, const int* __restrict__ blk_rows, const int* __restrict__ blk_idx,
+                            const double* __restrict__ blk_coef, const double* __restrict__ blk_cn,
+                            const double* __restrict__ x, const double* __restrict__ yhat, const double* __restrict__ mass,
+                            const double* __restrict__ bconst, const unsigned char* __restrict__ fixed,
+                            double* __restrict__ b) {
+  const double fac = scheme == PG_SCHEME_CN ? 2.0 : 1.0;
+  for (i64 q = blockIdx.x * (i64)blockDim.x + threadIdx.x; q < nblk; q += (i64)gridDim.x * blockDim.x) {
+    double v = 0.0;
+#pragma unroll
+    for (int a = 0; a < MAX_KINDS; ++a) {
+      const int j = blk_idx[q * MAX_KINDS + a];
+      if (j < 0) continue;
+      const double cj = fixed[j] ? bconst[j] : fac * (mass[j] * x[j]) + bconst[j];
+      v += blk_coef[q * MAX_KINDS + a] * cj;
+      if (scheme == PG_SCHEME_CN) v -= blk_cn[q * MAX_KINDS + a] * yhat[j];
+    }
+    b[blk_rows[q]] = v;
+  }
+}
+
 __global__ void k_scale_state(i64 n, const double* __restrict__ ds, const double* __restrict__ in, double* __restrict__ out,
                               int divide) {
   for (i64 r = blockIdx.x * (i64)blockDim.x + threadIdx.x; r < n; r += (i64)gridDim.x * blockDim.x)
@@ -180,8 +202,8 @@ __global__ void k_scale_state(i64 n, const double* __restrict__ ds, const double
 
 // K8, constructor form: T0 and K*T0 live in the padded layout (T0 may be non-zero at eliminated unknowns)
 __global__ void k_rhs_first(RowSegs seg, i64 n, i64 Mloc, int scheme, const int* row_cell, const double* T0pad,
-                            const double* ypad, const double* ds, const double* mass, const double* bconst,
-                            const unsigned char* fixed, double* b, double* x0) {
+                            const double* ypad, const double* mass, const double* bconst,
+                            const unsigned char* fixed, double* braw, double* x0) {
   for (i64 r = blockIdx.x * (i64)blockDim.x + threadIdx.x; r < n; r += (i64)gridDim.x * blockDim.x) {
     const int k = seg_kind(seg, r);
     const i64 q = (i64)k * Mloc + row_cell[r];
@@ -190,7 +212,7 @@ __global__ void k_rhs_first(RowSegs seg, i64 n, i64 Mloc, int scheme, const int*
     if (fixed[r]) v = bconst[r];
     else if (scheme == PG_SCHEME_CN) v = 2.0 * (mass[r] * T) - ypad[q] + bconst[r];
     else v = mass[r] * T + bconst[r];
-    b[r] = ds[r] * v;
+    braw[r] = v;
     x0[r] = T;
   }
 }
@@ -305,10 +327,13 @@ void build_first_rhs(pg_solver* s) {
     apply_rows_padded(P, s->slab, s->T0pad.p, ypad.p);
   }
   if (n > 0) {
+    DevBuf<double> braw(n);
     hipLaunchKernelGGL(k_rhs_first, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, st, make_segs(s->nb), n, s->Mloc,
-                       s->scheme_ctor, s->nb.row_cell.p, s->T0pad.p, ypad.p, s->A_ctor.ds.p, s->mass.p, s->bconst.p, s->fixed.p,
-                       s->b.p, s->x.p);
+                       s->scheme_ctor, s->nb.row_cell.p, s->T0pad.p, ypad.p, s->mass.p, s->bconst.p, s->fixed.p, braw.p,
+                       s->x.p);
     PG_HIP(hipGetLastError());
+    apply_left(s->A_ctor, braw.p, s->b.p, st);   // b̂ = B⁻¹ S b
+    PG_HIP(hipStreamSynchronize(st));
   }
   PG_HIP(hipStreamSynchronize(st));
 }
@@ -348,7 +373,7 @@ void setup_common(pg_solver* s, const pg_border_desc* borders, int nborders, con
   // K10 once, K7/K9 for the constructor scheme
   const SysParams P = make_params(s, s->scheme_ctor);
   build_numbering(P, slab, s->nb);
-  assemble_csr(P, slab, s->nb, s->A_ctor);
+  assemble_csr_preconditioned(P, slab, s->nb, s->A_ctor);
   s->A_ctor.scheme = s->scheme_ctor;
 
   const i64 n = s->nb.n_own, nv = s->nb.n_vec();
@@ -399,7 +424,7 @@ void ensure_run_matrix(pg_solver* s, int scheme) {
     return;
   }
   const SysParams P = make_params(s, scheme);
-  assemble_csr(P, s->slab, s->nb, s->A_run);
+  assemble_csr_preconditioned(P, s->slab, s->nb, s->A_run);
   s->A_run.scheme = scheme;
   s->scheme_run = scheme;
   s->have_run = true;
@@ -468,6 +493,9 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
     }
     hipLaunchKernelGGL(k_rhs, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, stream, n, scheme, s->x.p, s->y.p, A.ds.p, s->mass.p,
                        s->bconst.p, s->fixed.p, s->b.p);
+    if (A.n_blk > 0)
+      hipLaunchKernelGGL(k_rhs_block, dim3(grid_for(A.n_blk, BLOCK)), dim3(BLOCK), 0, stream, A.n_blk, scheme, A.blk_rows.p,
+                         A.blk_idx.p, A.blk_coef.p, A.blk_cn.p, s->x.p, s->y.p, s->mass.p, s->bconst.p, s->fixed.p, s->b.p);
     PG_HIP(hipGetLastError());
   }
   // warm start: y0 = S⁻¹ x_prev (= z), r0 = b̂ - Â z (= b̂ - y): same solution, fewer iterations
@@ -701,9 +729,9 @@ int32_t pg_solver_get_state(const pg_solver* s, int64_t state_index, double* x, 
 int32_t pg_solver_system_info(const pg_solver* s, int32_t which, pg_system_info* out) {
   PG_API_BEGIN
   PG_REQUIRE(s && out, "pg_solver_system_info: NULL argument");
-  const CsrMatrix& A = (which == 0 || !s->have_run) ? s->A_ctor : run_matrix(s);
+  const CsrMatrix& A = ((which & 1) == 0 || !s->have_run) ? s->A_ctor : run_matrix(s);
   out->n_own = s->nb.n_own;
-  out->nnz = A.nnz;
+  out->nnz = (which & 2) ? A.nnz : A.nnz_raw;
   out->n_ghost = s->nb.n_ghost;
   i64 nw = 0, ng = 0;
   for (int k = 0; k < s->K; ++k) ((k & 1) ? ng : nw) += s->nb.cnt_own[k];
@@ -718,9 +746,17 @@ int32_t pg_solver_get_system_csr(const pg_solver* s, int32_t which, int64_t* row
   PG_API_BEGIN
   require_init();
   PG_REQUIRE(s, "pg_solver_get_system_csr: NULL argument");
-  if (which == 1) PG_REQUIRE(s->have_run, "run matrix not assembled yet");
-  const CsrMatrix& A = which == 0 ? s->A_ctor : run_matrix(s);
+  const bool precond = (which & 2) != 0;   // 2/3: the preconditioned system (Â, b̂) exactly as the Krylov solver sees it
+  const int sel = which & 1;
+  if (sel == 1) PG_REQUIRE(s->have_run, "run matrix not assembled yet");
+  const CsrMatrix& Ah = sel == 0 ? s->A_ctor : run_matrix(s);
   const i64 n = s->nb.n_own;
+  // 0/1: the reference's reduced system A x = b: the matrix is re-assembled without scaling (export is a test /
+  // debugging path), b is recovered from b̂ = B⁻¹ S b
+  CsrMatrix raw;
+  if (!precond && (rowptr || col || val))
+    assemble_csr(make_params(s, sel == 0 ? s->scheme_ctor : s->scheme_run), s->slab, s->nb, raw, false);
+  const CsrMatrix& A = precond ? Ah : raw;
   if (rowptr) {
     std::vector<int> h(n + 1);
     A.rowptr.download(h.data(), n + 1);
@@ -731,20 +767,28 @@ int32_t pg_solver_get_system_csr(const pg_solver* s, int32_t which, int64_t* row
     A.col.download(h.data(), A.nnz);
     for (i64 i = 0; i < A.nnz; ++i) col[i] = h[i];
   }
-  // undo the equilibration: a_rc = â_rc / (s_r s_c), b_r = b̂_r / s_r
-  std::vector<double> hds(s->nb.n_vec() > 0 ? s->nb.n_vec() : 1);
-  if (s->nb.n_vec() > 0) A.ds.download(hds.data(), s->nb.n_vec());
-  if (val && A.nnz > 0) {
-    A.val.download(val, A.nnz);
-    std::vector<int> hr(n + 1), hc(A.nnz);
-    A.rowptr.download(hr.data(), n + 1);
-    A.col.download(hc.data(), A.nnz);
-    for (i64 r = 0; r < n; ++r)
-      for (int k = hr[r]; k < hr[r + 1]; ++k) val[k] = val[k] / (hds[r] * hds[hc[k]]);
-  }
+  if (val && A.nnz > 0) A.val.download(val, A.nnz);
   if (b && n > 0) {
     s->b.download(b, n);
-    for (i64 r = 0; r < n; ++r) b[r] /= hds[r];
+    if (!precond) {
+      std::vector<double> hb(b, b + n), hds(n);
+      Ah.ds.download(hds.data(), n);
+      for (i64 r = 0; r < n; ++r) b[r] = hb[r] / hds[r];
+      if (Ah.n_blk > 0) {
+        const i64 nq = Ah.n_blk;
+        std::vector<int> rows(nq), bi(nq * MAX_KINDS);
+        std::vector<double> fw(nq * MAX_KINDS);
+        Ah.blk_rows.download(rows.data(), nq);
+        Ah.blk_idx.download(bi.data(), nq * MAX_KINDS);
+        Ah.blk_fw.download(fw.data(), nq * MAX_KINDS);
+        for (i64 q = 0; q < nq; ++q) {
+          double v = 0.0;
+          for (int a = 0; a < MAX_KINDS; ++a)
+            if (bi[q * MAX_KINDS + a] >= 0) v += fw[q * MAX_KINDS + a] * hb[bi[q * MAX_KINDS + a]];
+          b[rows[q]] = v / hds[rows[q]];
+        }
+      }
+    }
   }
   if (idx && n > 0) {
     std::vector<int> h(n);

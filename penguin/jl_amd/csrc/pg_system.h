@@ -46,12 +46,24 @@ struct CsrMatrix {
   // entries; closed by {n, nnz}
   DevBuf<int> chunk_desc;
   i64 nchunks = 0;
+  // left cell-block preconditioner (pg_precond.hip): rows of cells with B != I, the local indices of the cell's
+  // unknowns (MAX_KINDS per row, -1 padded) and the coefficient rows (B⁻¹S)[row, idx], (B⁻¹MB)[row, idx]
+  // (Crank-Nicolson right-hand side, see k_blk_table) and B[row, idx] (export of the un-preconditioned b)
+  i64 n_blk = 0;
+  i64 nnz_raw = 0;   // entries of the un-preconditioned reduced matrix (what pg_solver_get_system_csr(0/1) returns)
+  DevBuf<int> blk_rows, blk_idx;
+  DevBuf<double> blk_coef, blk_cn, blk_fw;
 };
 constexpr int SPMV_CHUNK_ENTRIES = 508;   // + alignment shift (<= 3) fits the 512-slot LDS slice of a wave
 void build_spmv_chunks(CsrMatrix& A);   // pg_spmv.hip
 
 void build_numbering(const SysParams& P, const Slab& slab, Numbering& nb);
-void assemble_csr(const SysParams& P, const Slab& slab, const Numbering& nb, CsrMatrix& A);
+// raw reduced matrix A (scale = false, for export) or the point-equilibrated S A S (scale = true)
+void assemble_csr(const SysParams& P, const Slab& slab, const Numbering& nb, CsrMatrix& A, bool scale = true);
+// the matrix the Krylov solver iterates on:  Â = B⁻¹ S A S  (pg_precond.hip)
+void assemble_csr_preconditioned(const SysParams& P, const Slab& slab, const Numbering& nb, CsrMatrix& A);
+// out = B⁻¹ S in over the owned rows (in != out)
+void apply_left(const CsrMatrix& A, const double* in, double* out, hipStream_t st);
 // y (padded, K*Mloc) = K_full * x (padded, K*Mloc): matrix-free application of the un-reduced operator rows
 // `rows` of the planes owned by this rank (used for the constructor's first right-hand side under CN).
 void apply_rows_padded(const SysParams& P, const Slab& slab, const double* x, double* y);

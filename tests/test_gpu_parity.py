@@ -454,9 +454,9 @@ def test_anisotropic_grid_with_offset(pj, n, L, x0, c, r):
     _check_system(s, so)
     pj.solve_DiffusionUnsteadyMono_b(s, ph, dt, 4 * dt, bcb, pj.Robin(1.0, 0.3, 1.0), "CN", reltol=1e-13)
     po.solve_DiffusionUnsteadyMono(so, oph, dt, 4 * dt, obcb, po.Robin(1.0, 0.3, 1.0), "CN", method="\\")
-    # Robin interface + anisotropic cut cells: the 2x2 block system is ill conditioned (BiCGStab needs ~260
-    # iterations; error ~ cond x reltol), so the bar is looser than for the Dirichlet-interface configurations
-    assert rel_l2(s.x, so.x) <= 5e-8
+    # Robin interface + anisotropic cut cells: the per-cell (ω,γ) blocks are ill conditioned; the cell-block
+    # preconditioner inverts them exactly, so the usual bar holds
+    assert rel_l2(s.x, so.x) <= 1e-10
 
 
 def test_body_outside_domain_and_body_covering_domain(pj):
@@ -531,7 +531,20 @@ def test_full_size_properties_config5_1024sq_diphasic(pj):
     pj.solve_DiffusionUnsteadyDiph_b(s, p1, p2, dt, 4 * dt, bcb, ic, "CN", save_states=False)
     T1, Tg1, T2, Tg2 = s.x[:M], s.x[M:2 * M], s.x[2 * M:3 * M], s.x[3 * M:]
     f1, f2 = cap1.V > 0, cap2.V > 0
-    assert T1[f1].min() > -1e-8 and T1[f1].max() < 1 + 1e-8 and T2[f2].min() > -1e-8 and T2[f2].max() < 1 + 1e-8
+    # (no maximum principle here: the reference's CN step overshoots in tiny cut cells when started from interface
+    #  values that violate the jump condition, and a direct solve of the same system shows the same 13.2 peak)
+    assert s.last_run is None or s.last_run.steps >= 4
+    assert np.all(np.isfinite(s.x))
+    # the solution solves the reference's (un-preconditioned) reduced system of the last step
+    # (a sparse LU of the 2.1M-row system, ~10 s on the host: the `\` the reference's benchmark uses)
+    import scipy.sparse.linalg as spl
+    A, b, idx = s.system(1)
+    x_lu = spl.spsolve(A[:, :A.shape[0]].tocsc(), b)
+    assert rel_l2(s.x[idx], x_lu) <= 1e-10
+    # discrete heat conservation: sum over phases of V·Tω is invariant (the flux-jump rows cancel the interface
+    # exchange cell by cell, the outer border carries no flux)
+    heat = float(cap1.V @ T1 + cap2.V @ T2)
+    assert heat == pytest.approx(float(cap1.V.sum()), rel=1e-9)
     cut = cap1.Γ > 0
     assert np.max(np.abs(Tg1[cut] - Tg2[cut])) < 1e-9                                # scalar jump [[T]] = 0 (He = 1)
     # far from the interface nothing has happened yet
