@@ -109,6 +109,12 @@ typedef struct {
   int64_t n_omega;    /* owned active bulk unknowns                                             */
   int64_t n_gamma;    /* owned active interface unknowns                                        */
   int64_t M_global;   /* prod(n_d+1)                                                            */
+  /* stencil-sliced SpMV image of the matrix (DESIGN.md "SpMV"):                                */
+  int64_t spmv_bytes;     /* bytes one y = A x launch has to move with this format               */
+  int64_t spmv_slices;    /* U + P slices + G chunks                                             */
+  int64_t rows_uniform;   /* rows in U slices (shared offsets and values, nothing streamed)      */
+  int64_t rows_pattern;   /* rows in P slices (shared offsets, 8 B/entry value stream)           */
+  int64_t rows_irregular; /* rows in G chunks (packed CSR, 12 B/entry)                           */
 } pg_system_info;
 
 /* ---- library / device -------------------------------------------------------------------- */
@@ -209,6 +215,10 @@ int32_t pg_solver_time_spmv(pg_solver* s, int32_t which, int32_t reps, double* a
 int32_t pg_partition_planes(const int64_t* weight, int64_t nplanes, int32_t nranks, int64_t* bounds);
 
 /* ---- diagnostics (not part of the reference-facing boundary) ------------------------------------------------ */
+/* y = A x with two kernel variants (PG_SPMV_VARIANT numbering: 70 stencil slices, 38 chunked CSR, 1 first CSR kernel)
+   on the same deterministic vector: max |y_a - y_b| and max |y_a| */
+int32_t pg_debug_spmv_compare(pg_solver* s, int32_t which, int32_t variant_a, int32_t variant_b, double* max_abs_diff,
+                              double* max_abs);
 /* read-only streaming probe: `bytes` read `reps` times with elem_bytes (4|8) per lane, optional non-temporal hint */
 int32_t pg_debug_read_probe(int64_t bytes, int32_t elem_bytes, int32_t nt, int32_t blocks, int32_t reps, double* gbs);
 /* run the slab-decomposed monophasic path with `nranks` VIRTUAL ranks (host threads sharing this GPU, in-process

@@ -228,8 +228,11 @@ struct SpmvTimer {
   bool on;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs;
+  std::vector<int> iter_of;   // Krylov iteration each launch belongs to
+  int cur = 0;
   explicit SpmvTimer(bool on_) : on(on_) {}
-  void begin(hipStream_t st) {
+  void begin(hipStream_t st, int iteration) {
+    cur = iteration;
     if (!on) return;
     PG_HIP(hipEventCreate(&e0));
     PG_HIP(hipEventCreate(&e1));
@@ -239,17 +242,24 @@ struct SpmvTimer {
     if (!on) return;
     PG_HIP(hipEventRecord(e1, st));
     pairs.emplace_back(e0, e1);
+    iter_of.push_back(cur);
   }
-  void collect(SolveStats& s) {
-    for (auto& pr : pairs) {
+  // launches queued after convergence return at their first instruction (done flag): they are not SpMVs and are
+  // left out of the launch count and of the average
+  void collect(SolveStats& s, int iters_done) {
+    for (size_t q = 0; q < pairs.size(); ++q) {
+      auto& pr = pairs[q];
       float ms = 0.f;
       (void)hipEventSynchronize(pr.second);
-      if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) s.spmv_ms += ms;
-      s.spmv_launches += 1;
+      if (iter_of[q] < iters_done && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+        s.spmv_ms += ms;
+        s.spmv_launches += 1;
+      }
       (void)hipEventDestroy(pr.first);
       (void)hipEventDestroy(pr.second);
     }
     pairs.clear();
+    iter_of.clear();
   }
 };
 
@@ -311,21 +321,28 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
   }
   PG_HIP(hipGetLastError());
 
-  int launched = 0;
+  // Iterations are queued in batches and the done flag is polled in between.  Consecutive time steps need almost
+  // the same number of iterations, so the first batch runs up to one short of the previous solve's count and the
+  // next few polls come after every iteration: no iterations are queued past convergence (each would still cost
+  // its launch overheads), at the price of two or three extra stream syncs per solve.
+  int launched = 0, polls = 0;
   bool done = false;
   while (!done) {
-    const int batch = std::min(check_every, maxiter - launched);
+    int want = check_every;
+    if (w.last_iters > 1) want = polls == 0 ? w.last_iters - 1 : (polls <= 4 ? 1 : check_every);
+    const int batch = std::max(1, std::min(want, maxiter - launched));
+    ++polls;
     for (int it = 0; it < batch; ++it) {
       if (!cg) {
         hipLaunchKernelGGL(k_bicg_p, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.r.p, w.v.p, w.p.p, w.rhat.p);
         halo_exchange(nb, slab, w.p.p, st);
-        timer.begin(st);
+        timer.begin(st, launched + it);
         launch_spmv(1, A, w.p.p, w.v.p, w.rhat.p, w.partials.p, w.sc.p, G, st);
         timer.end(st);
         finalize(PH_BICG_1, 1, w, st, true);
         hipLaunchKernelGGL(k_bicg_s, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.r.p, w.v.p, w.s.p);
         halo_exchange(nb, slab, w.s.p, st);
-        timer.begin(st);
+        timer.begin(st, launched + it);
         launch_spmv(2, A, w.s.p, w.t.p, nullptr, w.partials.p, w.sc.p, G, st);
         timer.end(st);
         finalize(PH_BICG_2, 2, w, st, true);
@@ -334,7 +351,7 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
         finalize(PH_BICG_3, 2, w, st, true);
       } else {
         halo_exchange(nb, slab, w.p.p, st);
-        timer.begin(st);
+        timer.begin(st, launched + it);
         launch_spmv(2, A, w.p.p, w.v.p, nullptr, w.partials.p, w.sc.p, G, st);   // v = A p ; (v.p), (v.v)
         timer.end(st);
         finalize(PH_CG_1, 1, w, st, true);
@@ -354,10 +371,11 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
             w.h_sc[S_DONE], w.h_sc[S_ITERS], w.h_sc[S_RR], w.h_sc[S_TOL2], w.h_sc[S_RHO], w.h_sc[S_RHO_OLD], w.h_sc[S_ALPHA],
             w.h_sc[S_OMEGA], w.h_sc[S_BETA], w.h_sc[S_RED0], w.h_sc[S_RED1]);
   stats.iters = (int)w.h_sc[S_ITERS];
+  w.last_iters = stats.iters;
   stats.converged = w.h_sc[S_DONE] == 1.0 ? 1 : 0;
   stats.resnorm = std::sqrt(w.h_sc[S_RR]);
   stats.bnorm = std::sqrt(w.h_sc[S_BB]);
-  timer.collect(stats);
+  timer.collect(stats, stats.iters);
 }
 
 }  // namespace pg

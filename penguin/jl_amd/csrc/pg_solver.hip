@@ -14,6 +14,7 @@
 #include <memory>
 
 #include "pg_krylov.h"
+#include "pg_spmv.h"
 
 using namespace pg;
 
@@ -59,7 +60,7 @@ struct pg_solver {
 
 namespace {
 
-constexpr int BLOCK = 256;
+using pg::BLOCK;   // 256 (pg_spmv.h)
 
 struct RowSegs {
   int K;
@@ -738,6 +739,11 @@ int32_t pg_solver_system_info(const pg_solver* s, int32_t which, pg_system_info*
   out->n_omega = nw;
   out->n_gamma = ng;
   out->M_global = s->M;
+  out->spmv_bytes = A.spmv_bytes;
+  out->spmv_slices = A.nslices;
+  out->rows_uniform = A.rows_u;
+  out->rows_pattern = A.rows_p;
+  out->rows_irregular = A.rows_g;
   PG_API_END
 }
 
@@ -796,6 +802,43 @@ int32_t pg_solver_get_system_csr(const pg_solver* s, int32_t which, int64_t* row
     for (i64 r = 0; r < n; ++r) {
       const int k = s->nb.kind_of_row(r);
       idx[r] = (i64)k * s->M + s->slab.first_cell() + h[r];
+    }
+  }
+  PG_API_END
+}
+
+// max |y_a - y_b| between two SpMV kernel variants applied to the same deterministic test vector
+__global__ void k_test_vector(i64 n, double* x) {
+  for (i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+    unsigned long long h = (unsigned long long)i * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+    x[i] = (double)(h >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+  }
+}
+
+int32_t pg_debug_spmv_compare(pg_solver* s, int32_t which, int32_t variant_a, int32_t variant_b, double* max_abs_diff,
+                              double* max_abs) {
+  PG_API_BEGIN
+  require_init();
+  PG_REQUIRE(s && max_abs_diff && max_abs, "pg_debug_spmv_compare: NULL argument");
+  if (which == 1) PG_REQUIRE(s->have_run, "run matrix not assembled yet");
+  const CsrMatrix& A = which == 0 ? s->A_ctor : run_matrix(s);
+  hipStream_t st = ctx().stream;
+  const i64 n = s->nb.n_own, nv = s->nb.n_vec();
+  *max_abs_diff = 0.0;
+  *max_abs = 0.0;
+  if (n > 0) {
+    DevBuf<double> xv(nv), ya(n), yb(n);
+    hipLaunchKernelGGL(k_test_vector, dim3(grid_for(nv, BLOCK)), dim3(BLOCK), 0, st, nv, xv.p);
+    launch_spmv_variant(variant_a, A, xv.p, ya.p, st);
+    launch_spmv_variant(variant_b, A, xv.p, yb.p, st);
+    PG_HIP(hipGetLastError());
+    std::vector<double> ha(n), hb(n);
+    ya.download(ha.data(), n);
+    yb.download(hb.data(), n);
+    for (i64 i = 0; i < n; ++i) {
+      *max_abs_diff = std::max(*max_abs_diff, std::fabs(ha[i] - hb[i]));
+      *max_abs = std::max(*max_abs, std::fabs(ha[i]));
     }
   }
   PG_API_END

@@ -37,6 +37,8 @@ __device__ inline double block_sum(double v, double* sh /*BLOCK/64*/) {
 // `grid` must be the value used to size `partials` (KrylovWork::grid) for modes 1/2.
 void launch_spmv(int mode, const CsrMatrix& A, const double* x, double* y, const double* aux, double* partials,
                  const double* sc, int grid, hipStream_t st);
+// plain y = A x with an explicit kernel variant (PG_SPMV_VARIANT numbering): kernel-vs-kernel parity checks
+void launch_spmv_variant(int variant, const CsrMatrix& A, const double* x, double* y, hipStream_t st);
 int spmv_default_grid(i64 n);
 
 }  // namespace pg
