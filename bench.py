@@ -134,7 +134,11 @@ def main() -> None:
         n_rows_g, nnz_g = int(tot[0].item()), int(tot[1].item())
     else:
         n_rows_g, nnz_g = n_rows, nnz
-    b_spmv = 12 * nnz + 20 * n_rows                    # algorithmic bytes of one SpMV (this rank's launch)
+    b_csr = 12 * nnz + 20 * n_rows                     # algorithmic bytes of one plain-CSR SpMV (this rank)
+    # the kernel in the loop streams the stencil-sliced image of the same matrix: its algorithmic bytes are the
+    # bytes of THAT format (records + P/G streams + x and y once) -- pricing it with the CSR figure would credit
+    # bytes it never has to move (DESIGN.md "SpMV")
+    b_spmv = int(sysinfo.spmv_bytes) if os.environ.get("PG_SPMV_VARIANT", "70") in ("70", "66") else b_csr
     spmv_ms = run.spmv_ms_total / max(run.spmv_launches, 1)
     achieved = b_spmv / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
     iters = run.total_iters / max(run.steps, 1)
@@ -173,7 +177,7 @@ def main() -> None:
             "device": pj.device_name(),
         },
         "roofline": {
-            "kernel": "k_spmv (CSR, fp64 values, int32 indices)",
+            "kernel": "k_spmv_s (stencil-sliced CSR: uniform / pattern slices + packed irregular rows, fp64)",
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
@@ -181,6 +185,10 @@ def main() -> None:
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
             "bytes_per_launch": b_spmv,
+            "csr_bytes_per_launch": b_csr,
+            "csr_equivalent_GBs": b_csr / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0,
+            "rows_uniform": int(sysinfo.rows_uniform), "rows_pattern": int(sysinfo.rows_pattern),
+            "rows_irregular": int(sysinfo.rows_irregular), "slices": int(sysinfo.spmv_slices),
             "avg_launch_ms": spmv_ms,
             "launches_timed": int(run.spmv_launches),
         },

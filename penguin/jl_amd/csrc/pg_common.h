@@ -104,7 +104,8 @@ struct DevBuf {
   void alloc(i64 n_) {
     release();
     n = n_;
-    if (n > 0) PG_HIP(hipMalloc(reinterpret_cast<void**>(&p), sizeof(T) * static_cast<size_t>(n)));
+    // 64 bytes of slack: 16-byte loads that start at the last element (SpMV pair loads) stay inside the allocation
+    if (n > 0) PG_HIP(hipMalloc(reinterpret_cast<void**>(&p), sizeof(T) * static_cast<size_t>(n) + 64));
   }
   void zero() {
     if (n > 0) PG_HIP(hipMemsetAsync(p, 0, sizeof(T) * static_cast<size_t>(n), ctx().stream));

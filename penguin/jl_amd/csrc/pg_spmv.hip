@@ -34,8 +34,6 @@
 //   +32 16-byte (aligned pair / quad) stream loads
 #include <algorithm>
 #include <cstdlib>
-#include <string>
-#include <unordered_map>
 #include <vector>
 
 #include "pg_spmv.h"
@@ -365,33 +363,146 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_cw(i64 n, i64 nchunks, const int
 // The assembler knows what a generic CSR kernel cannot: away from the interface every row of a line carries the
 // SAME stencil -- identical (col - row) offsets, and on a uniform mesh bitwise identical (equilibrated) values.
 // build_spmv_chunks() detects that once per matrix (k_row_same) and re-slices the rows:
-//   U slice   <= 255 consecutive rows, identical offsets and values: the slice is 16 bytes of descriptor + a shared
-//             stencil-table entry read through the scalar cache; lane l computes row r0+l from COALESCED x loads.
-//             Nothing of the matrix is streamed.
+//   U slice   <= 254 consecutive rows, identical offsets and values: the slice is ONE 128-byte record (descriptor,
+//             offsets, values); lane l computes rows r0+2l, r0+2l+1 from coalesced 16-byte x loads.  Nothing else
+//             of the matrix is streamed.
 //   P slice   identical offsets, per-row values: values re-laid slot-major (pval[j*rows + l]) so the 8 B/entry
 //             stream is coalesced without LDS; the 4 B/entry column stream disappears.
-//   G chunk   the remaining irregular rows (cut cells, their neighbours, line ends), packed 64 at a time into a
-//             compact CSR of their own and processed exactly like k_spmv_cw (LDS-staged stream + gathers).
+//   G chunk   the remaining irregular rows (cut cells, their neighbours, line ends, rows with > 8 entries), packed 64
+//             at a time into a compact CSR of their own and processed like k_spmv_cw (LDS-staged stream + gathers).
 // The products are accumulated in the CSR entry order in all three paths, so y is bitwise what the CSR kernels give.
+//
+// What bounds the U path (SQ counters + ablations, profiles/r01_spmv_slices.txt): the kernel ran at the same speed with
+// every x load forced to hit one L1 line, with the record loads forced to one line, at 4, 5, 6 or 8 waves per SIMD,
+// and with 8- or 16-byte accesses: ~22 cycles per vector-memory INSTRUCTION per CU whatever its width -- the
+// address unit, not HBM, L2 or latency.  Hence: two rows per lane (16-byte accesses), no padded slots (the slot
+// count is a template parameter: 1 border identity rows, 3 / 5 / 7 the 1-D / 2-D / 3-D stencils), and one record
+// load per slice instead of descriptor + offsets + values.
+//
 // Slices are sorted by first row; with `xcd` each XCD (blocks are dispatched round-robin over the 8 XCDs) sweeps one
 // contiguous eighth of them, so the +-line / +-plane x neighbours are found in that XCD's own L2.
 enum { SL_U = 0, SL_P = 1, SL_G = 2 };
-constexpr int SL_MAXROWS = 255, SL_MAXCNT = 16;
+constexpr int SL_MAXROWS_U = 254, SL_MAXROWS_P = 128, SL_MAXCNT = 8, SL_REC = 32;   // record: 32 dwords
 
 struct SDesc {
   int r0, meta, base, aux;
 };
 
-__device__ inline SDesc load_sdesc(const int* __restrict__ sd, i64 ch) {
-  const int* p = sd + 4 * ch;   // wave-uniform address: one s_load_dwordx4
-  SDesc d;
-  d.r0 = p[0]; d.meta = p[1]; d.base = p[2]; d.aux = p[3];
-  return d;
+// wave-uniform values out of a vector register (the result lives in SGPRs)
+__device__ inline int rlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+
+typedef double d2u_t __attribute__((ext_vector_type(2), aligned(8)));   // 16-byte access, 8-byte aligned
+
+template <bool NT>
+__device__ inline d2_t load_pair(const double* p) {
+  const d2u_t* q = reinterpret_cast<const d2u_t*>(p);
+  d2u_t v = NT ? __builtin_nontemporal_load(q) : *q;
+  d2_t r;
+  r.x = v.x; r.y = v.y;
+  return r;
+}
+
+// rows of one U (PSL = false) or P (PSL = true) slice with CNT stencil slots; rec = the slice's record (lane & 31).
+// NB batches of 128 rows: every load of the slice is issued before the first FMA (one exposed latency per slice).
+template <int CNT, int NB, bool PSL, int MODE, bool NT>
+__device__ inline void slice_rows(const SDesc& d, int nrows, int rec, const double* __restrict__ pval,
+                                  const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ aux,
+                                  int lane, double& acc0, double& acc1, int dbg) {
+  int o[CNT];
+#pragma unroll
+  for (int j = 0; j < CNT; ++j) o[j] = (dbg & 4) ? 0 : rlane(rec, 4 + j);
+  int l0[NB];
+  bool live0[NB], live1[NB];
+  d2_t xv[NB][CNT];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int l = 128 * b + 2 * lane;
+    live0[b] = l < nrows;
+    live1[b] = l + 1 < nrows;
+    l0[b] = live0[b] ? l : 0;
+#pragma unroll
+    for (int j = 0; j < CNT; ++j) xv[b][j] = load_pair<false>(x + d.r0 + l0[b] + o[j]);
+  }
+  d2_t sum[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) { sum[b].x = 0.0; sum[b].y = 0.0; }
+  if (!PSL) {
+#pragma unroll
+    for (int j = 0; j < CNT; ++j) {
+      const double c = __hiloint2double(rlane(rec, 13 + 2 * j), rlane(rec, 12 + 2 * j));
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        sum[b].x += c * xv[b][j].x;
+        sum[b].y += c * xv[b][j].y;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const double* __restrict__ pv = pval + d.base + l0[b];
+      d2_t vv[CNT];
+#pragma unroll
+      for (int j = 0; j < CNT; ++j) vv[j] = load_pair<NT>(pv + j * nrows);
+#pragma unroll
+      for (int j = 0; j < CNT; ++j) {
+        sum[b].x += vv[j].x * xv[b][j].x;
+        sum[b].y += vv[j].y * xv[b][j].y;
+      }
+    }
+  }
+  d2_t ax[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (MODE == 1) ax[b] = load_pair<false>(aux + d.r0 + l0[b]);
+    else if (MODE == 2) ax[b] = load_pair<false>(x + d.r0 + l0[b]);
+    else { ax[b].x = 0.0; ax[b].y = 0.0; }
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const bool st = !(dbg & 8) || sum[b].x == 1.2345e-300;
+    double* yp = y + d.r0 + l0[b];
+    if (live1[b]) {
+      if (st) {
+        d2u_t out;
+        out.x = sum[b].x; out.y = sum[b].y;
+        *reinterpret_cast<d2u_t*>(yp) = out;
+      }
+      if (MODE >= 1) acc0 += ax[b].x * sum[b].x + ax[b].y * sum[b].y;
+      if (MODE == 2) acc1 += sum[b].x * sum[b].x + sum[b].y * sum[b].y;
+    } else if (live0[b]) {
+      if (st) *yp = sum[b].x;
+      if (MODE >= 1) acc0 += ax[b].x * sum[b].x;
+      if (MODE == 2) acc1 += sum[b].x * sum[b].x;
+    }
+  }
+}
+
+template <int CNT, bool PSL, int MODE, bool NT>
+__device__ inline void slice_nb(const SDesc& d, int nrows, int rec, const double* __restrict__ pval,
+                                const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ aux,
+                                int lane, double& acc0, double& acc1, int dbg) {
+  if (!PSL && nrows > 128) slice_rows<CNT, 2, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, dbg);
+  else slice_rows<CNT, 1, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, dbg);
+}
+
+template <bool PSL, int MODE, bool NT>
+__device__ inline void slice_dispatch(int cnt, const SDesc& d, int nrows, int rec, const double* __restrict__ pval,
+                                      const double* __restrict__ x, double* __restrict__ y,
+                                      const double* __restrict__ aux, int lane, double& acc0, double& acc1, int dbg) {
+  switch (cnt) {   // wave-uniform
+    case 1: slice_nb<1, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, dbg); break;
+    case 3: slice_nb<3, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, dbg); break;
+    case 5: slice_nb<5, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, dbg); break;
+    case 7: slice_nb<7, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, dbg); break;
+    case 2: slice_nb<2, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, dbg); break;
+    case 4: slice_nb<4, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, dbg); break;
+    case 6: slice_nb<6, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, dbg); break;
+    default: slice_nb<8, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, dbg); break;
+  }
 }
 
 template <int MODE, bool NT>
-__global__ __launch_bounds__(BLOCK) void k_spmv_s(i64 nslices, const int* __restrict__ sdesc,
-                                                  const int* __restrict__ stab_off, const double* __restrict__ stab_val,
+__global__ __launch_bounds__(BLOCK) void k_spmv_s(i64 nslices, const int* __restrict__ srec,
                                                   const double* __restrict__ pval, const int* __restrict__ g_rowid,
                                                   const int* __restrict__ g_rowptr, const int* __restrict__ g_col,
                                                   const double* __restrict__ g_val, const double* __restrict__ x,
@@ -408,6 +519,10 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_s(i64 nslices, const int* __rest
   d2_t* sv2 = reinterpret_cast<d2_t*>(sv);
   i4_t* sc4 = reinterpret_cast<i4_t*>(scl);
   double acc0 = 0.0, acc1 = 0.0;
+  // diagnostics (PG_SPMV_XCD bits 8..; results are wrong with any of them): 1 skip G chunks, 2 skip U/P slices,
+  // 4 every x load hits one line, 8 no y stores in U/P slices
+  const int dbg = xcd >> 8;
+  xcd &= 255;
   i64 first, wstride, hi;
   if (xcd && gridDim.x >= 8) {
     const int xid = blockIdx.x & 7;
@@ -422,83 +537,59 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_s(i64 nslices, const int* __rest
     hi = nslices;
   }
   const i64 lastc = hi - 1;
-  SDesc dcur, dnext;
-  if (first < hi) {
-    dcur = load_sdesc(sdesc, first);
-    dnext = load_sdesc(sdesc, first + wstride < hi ? first + wstride : lastc);
-  }
+  const int l31 = lane & 31;
+  // the record of a slice is fetched with ONE vector load one slice ahead (lane l reads dword l & 31) and its
+  // wave-uniform fields are broadcast with v_readlane
+  int rec = first < hi ? srec[SL_REC * first + l31] : 0;
   for (i64 chunk = first; chunk < hi; chunk += wstride) {
-    const i64 c2 = chunk + 2 * wstride;
-    const SDesc dnext2 = load_sdesc(sdesc, c2 < hi ? c2 : lastc);   // two slices ahead: off the critical path
-    const int nrows = dcur.meta & 255, type = (dcur.meta >> 8) & 3, cnt = dcur.meta >> 16;
-    if (type != SL_G) {
-      const int* __restrict__ so = stab_off + 16 * (i64)dcur.aux;
-      const double* __restrict__ svl = stab_val + 16 * (i64)dcur.aux;
-      int o[WUNR];
-      double cf[WUNR];
-#pragma unroll
-      for (int j = 0; j < WUNR; ++j) { o[j] = so[j]; cf[j] = svl[j]; }   // uniform: scalar loads; padded table
-      const double* __restrict__ pv = pval + (type == SL_P ? dcur.base : 0);
-      for (int ofs = 0; ofs < nrows; ofs += 64) {
-        const int l = ofs + lane;
-        const bool live = l < nrows;
-        const int ll = live ? l : 0;
-        const int r = dcur.r0 + ll;
-        double xv[WUNR], vv[WUNR];
-#pragma unroll
-        for (int j = 0; j < WUNR; ++j) xv[j] = x[r + o[j]];
-        if (type == SL_P) {
-#pragma unroll
-          for (int j = 0; j < WUNR; ++j) {
-            const double v = stream_load<NT>(pv + (j < cnt ? j : 0) * nrows + ll);
-            vv[j] = j < cnt ? v : 0.0;
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < WUNR; ++j) vv[j] = cf[j];
-        }
-        double sum = 0.0;
-#pragma unroll
-        for (int j = 0; j < WUNR; ++j) sum += vv[j] * xv[j];
-        if (__builtin_expect(cnt > WUNR, 0))
-          for (int j = WUNR; j < cnt; ++j) sum += (type == SL_P ? pv[j * nrows + ll] : svl[j]) * x[r + so[j]];
-        if (live) {
-          y[r] = sum;
-          if (MODE == 1) acc0 += aux[r] * sum;
-          if (MODE == 2) {
-            acc0 += sum * x[r];
-            acc1 += sum * sum;
-          }
-        }
-      }
+    const i64 cn = chunk + wstride;
+    const int rec_n = srec[SL_REC * (cn < hi ? cn : lastc) + l31];
+    SDesc d;
+    d.r0 = rlane(rec, 0); d.meta = rlane(rec, 1); d.base = rlane(rec, 2); d.aux = rlane(rec, 3);
+    const int nrows = d.meta & 255, type = (d.meta >> 8) & 3, cnt = d.meta >> 16;
+    const bool skip = ((dbg & 1) && type == SL_G) || ((dbg & 2) && type != SL_G);
+    if (skip) {
+    } else if (type == SL_U) {
+      slice_dispatch<false, MODE, NT>(cnt, d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, dbg);
+    } else if (type == SL_P) {
+      slice_dispatch<true, MODE, NT>(cnt, d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, dbg);
     } else {
       // packed irregular rows: same data flow as k_spmv_cw on the compact CSR, plus the row-id indirection
-      Desc d;
-      d.r0 = dcur.r0; d.base = dcur.base; d.r1 = dcur.r0 + nrows; d.end = dcur.aux;
+      Desc dd;
+      dd.r0 = d.r0; dd.base = d.base; dd.r1 = d.r0 + nrows; dd.end = d.aux;
       StreamW q;
-      stream_issue_w<NT>(q, d, g_rowptr, g_col, g_val, lane);
+      stream_issue_w<NT>(q, dd, g_rowptr, g_col, g_val, lane);
       const bool live = lane < nrows;
-      const int rid = g_rowid[dcur.r0 + (live ? lane : 0)];
-      const int basev = d.base & ~1, basec = d.base & ~3;
+      const int rid = g_rowid[d.r0 + (live ? lane : 0)];
+      const int basev = dd.base & ~1, basec = dd.base & ~3;
       const int av = q.ra - basev, ac = q.ra - basec, len = q.rb - q.ra;
 #pragma unroll
       for (int j = 0; j < XV_IT; ++j) sv2[lane + 64 * j] = q.v[j];
 #pragma unroll
       for (int j = 0; j < XC_IT; ++j) sc4[lane + 64 * j] = q.c[j];
       __builtin_amdgcn_wave_barrier();
-      double xv[WUNR], vv[WUNR];
-      const int c0 = d.base - basec;
-#pragma unroll
-      for (int j = 0; j < WUNR; ++j) {
-        const bool ok = j < len;
-        xv[j] = x[scl[ok ? ac + j : c0]];
-        vv[j] = ok ? sv[av + j] : 0.0;
-      }
+      const int c0 = dd.base - basec;
       double sum = 0.0;
+      // rounds of 8 gathers issued together (irregular rows often hold 9..14 entries: a per-entry tail loop would
+      // expose one full memory latency per entry)
+      int maxlen = len;
 #pragma unroll
-      for (int j = 0; j < WUNR; ++j) sum += vv[j] * xv[j];
-      if (len > WUNR)
-        for (int k = WUNR; k < len; ++k) sum += sv[av + k] * x[scl[ac + k]];
+      for (int off = 32; off > 0; off >>= 1) {
+        const int other = __shfl_xor(maxlen, off, 64);
+        maxlen = other > maxlen ? other : maxlen;
+      }
+      maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+      for (int j0 = 0; j0 < maxlen; j0 += WUNR) {
+        double xv[WUNR], vv[WUNR];
+#pragma unroll
+        for (int j = 0; j < WUNR; ++j) {
+          const bool ok = j0 + j < len;
+          xv[j] = x[scl[ok ? ac + j0 + j : c0]];
+          vv[j] = ok ? sv[av + j0 + j] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < WUNR; ++j) sum += vv[j] * xv[j];
+      }
       __builtin_amdgcn_wave_barrier();
       if (live) {
         y[rid] = sum;
@@ -509,8 +600,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_s(i64 nslices, const int* __rest
         }
       }
     }
-    dcur = dnext;
-    dnext = dnext2;
+    rec = rec_n;
   }
   if (MODE >= 1) {
     const double t0 = block_sum(acc0, s_red);
@@ -543,10 +633,10 @@ __global__ void k_row_same(i64 n, const int* __restrict__ rowptr, const int* __r
 }
 
 // P slices: pval[base + j*rows + l] = val[rowptr[r0+l] + j]
-__global__ void k_pval_fill(i64 nslices, const int* __restrict__ sdesc, const int* __restrict__ rowptr,
+__global__ void k_pval_fill(i64 nslices, const int* __restrict__ srec, const int* __restrict__ rowptr,
                             const double* __restrict__ val, double* __restrict__ pval) {
   for (i64 sidx = blockIdx.x; sidx < nslices; sidx += gridDim.x) {
-    const int r0 = sdesc[4 * sidx], meta = sdesc[4 * sidx + 1], base = sdesc[4 * sidx + 2];
+    const int r0 = srec[SL_REC * sidx], meta = srec[SL_REC * sidx + 1], base = srec[SL_REC * sidx + 2];
     if (((meta >> 8) & 3) != SL_P) continue;
     const int nrows = meta & 255, cnt = meta >> 16;
     for (int q = threadIdx.x; q < nrows * cnt; q += blockDim.x) {
@@ -569,15 +659,19 @@ __global__ void k_gpack(i64 ng, const int* __restrict__ g_rowid, const int* __re
   }
 }
 
-// offsets / values of the first row of every U / P slice (for the stencil table)
-__global__ void k_fetch_stencil(i64 ns, const int* __restrict__ rows, const int* __restrict__ rowptr,
-                                const int* __restrict__ col, const double* __restrict__ val, int* __restrict__ off16,
-                                double* __restrict__ val16) {
-  for (i64 q = blockIdx.x * (i64)blockDim.x + threadIdx.x; q < ns; q += (i64)gridDim.x * blockDim.x) {
-    const int r = rows[q], a = rowptr[r], len = rowptr[r + 1] - a;
+// offsets (dwords 4..11) and values (dwords 12..27) of every U / P record, from the slice's first row
+__global__ void k_fill_records(i64 nslices, int* __restrict__ srec, const int* __restrict__ rowptr,
+                               const int* __restrict__ col, const double* __restrict__ val) {
+  for (i64 q = blockIdx.x * (i64)blockDim.x + threadIdx.x; q < nslices; q += (i64)gridDim.x * blockDim.x) {
+    int* rec = srec + SL_REC * q;
+    const int type = (rec[1] >> 8) & 3;
+    if (type == SL_G) continue;
+    const int r = rec[0], a = rowptr[r], len = rowptr[r + 1] - a;
     for (int k = 0; k < SL_MAXCNT; ++k) {
-      off16[q * SL_MAXCNT + k] = col[a + (k < len ? k : 0)] - r;
-      val16[q * SL_MAXCNT + k] = k < len ? val[a + k] : 0.0;
+      rec[4 + k] = col[a + (k < len ? k : 0)] - r;
+      const double v = (k < len && type == SL_U) ? val[a + k] : 0.0;
+      rec[12 + 2 * k] = __double2loint(v);
+      rec[13 + 2 * k] = __double2hiint(v);
     }
   }
 }
@@ -603,13 +697,11 @@ void launch_mode(int v, const CsrMatrix& A, const double* x, double* y, const do
                  const double* sc, int grid, hipStream_t st) {
   if (v & 64) {
     if (v & 4)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_s<MODE, true>), dim3(grid), dim3(BLOCK), 0, st, A.nslices, A.sdesc.p,
-                         A.stab_off.p, A.stab_val.p, A.pval.p, A.g_rowid.p, A.g_rowptr.p, A.g_col.p, A.g_val.p, x, y, aux,
-                         partials, sc, xcd_map());
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_s<MODE, true>), dim3(grid), dim3(BLOCK), 0, st, A.nslices, A.srec.p, A.pval.p,
+                         A.g_rowid.p, A.g_rowptr.p, A.g_col.p, A.g_val.p, x, y, aux, partials, sc, xcd_map());
     else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_s<MODE, false>), dim3(grid), dim3(BLOCK), 0, st, A.nslices, A.sdesc.p,
-                         A.stab_off.p, A.stab_val.p, A.pval.p, A.g_rowid.p, A.g_rowptr.p, A.g_col.p, A.g_val.p, x, y, aux,
-                         partials, sc, xcd_map());
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_s<MODE, false>), dim3(grid), dim3(BLOCK), 0, st, A.nslices, A.srec.p, A.pval.p,
+                         A.g_rowid.p, A.g_rowptr.p, A.g_col.p, A.g_val.p, x, y, aux, partials, sc, xcd_map());
     return;
   }
   if (v == 1) {
@@ -645,7 +737,7 @@ struct Slice {
 void build_slices(CsrMatrix& A, const std::vector<int>& rp) {
   hipStream_t st = ctx().stream;
   const i64 n = A.n;
-  static const int minrun = getenv("PG_SPMV_MINRUN") ? atoi(getenv("PG_SPMV_MINRUN")) : 12;
+  static const int minrun = getenv("PG_SPMV_MINRUN") ? atoi(getenv("PG_SPMV_MINRUN")) : 24;
   std::vector<unsigned char> fl(n);
   {
     DevBuf<unsigned char> flags(n);
@@ -656,8 +748,9 @@ void build_slices(CsrMatrix& A, const std::vector<int>& rp) {
   std::vector<Slice> up;       // U and P slices
   std::vector<int> grows;      // irregular rows, ascending
   auto emit = [&](int type, i64 a, i64 b, int cnt) {
-    for (i64 r = a; r < b; r += SL_MAXROWS) {
-      const int rows = (int)std::min<i64>(SL_MAXROWS, b - r);
+    const i64 maxrows = type == SL_U ? SL_MAXROWS_U : SL_MAXROWS_P;
+    for (i64 r = a; r < b; r += maxrows) {
+      const int rows = (int)std::min<i64>(maxrows, b - r);
       up.push_back(Slice{(int)r, rows | (type << 8) | (cnt << 16), 0, 0, (int)r});
     }
     (type == SL_U ? A.rows_u : A.rows_p) += b - a;
@@ -672,7 +765,7 @@ void build_slices(CsrMatrix& A, const std::vector<int>& rp) {
     i64 j = i + 1;
     while (j < n && (fl[j] & 1)) ++j;                 // pattern run [i, j)
     const int cnt = rp[i + 1] - rp[i];
-    if (j - i >= minrun && cnt >= 1 && cnt <= SL_MAXCNT) {
+    if (j - i >= minrun && cnt >= 1 && cnt <= SL_MAXCNT) {   // rows with more entries than a record holds stay irregular
       i64 pstart = i, k = i;
       auto flush_p = [&](i64 a, i64 b) {
         if (b - a >= minrun) emit(SL_P, a, b, cnt);
@@ -694,56 +787,17 @@ void build_slices(CsrMatrix& A, const std::vector<int>& rp) {
     }
     i = j;
   }
-  // (a row flushed out of order above keeps `grows` ascending only within a run: restore the global order)
   std::sort(grows.begin(), grows.end());
-  // stencil table: first row of every U / P slice, de-duplicated
-  const i64 nup = (i64)up.size();
-  std::vector<int> toff;
-  std::vector<double> tval;
-  if (nup > 0) {
-    std::vector<int> first(nup);
-    for (i64 q = 0; q < nup; ++q) first[q] = up[q].r0;
-    DevBuf<int> dfirst(nup), doff(nup * SL_MAXCNT);
-    DevBuf<double> dval(nup * SL_MAXCNT);
-    dfirst.upload(first.data(), nup);
-    hipLaunchKernelGGL(k_fetch_stencil, dim3(grid_for(nup, 256)), dim3(256), 0, st, nup, dfirst.p, A.rowptr.p, A.col.p, A.val.p,
-                       doff.p, dval.p);
-    PG_HIP(hipGetLastError());
-    std::vector<int> hoff(nup * SL_MAXCNT);
-    std::vector<double> hval(nup * SL_MAXCNT);
-    doff.download(hoff.data(), nup * SL_MAXCNT);
-    dval.download(hval.data(), nup * SL_MAXCNT);
-    std::unordered_map<std::string, int> dict;
+  // P value bases
+  {
     i64 pbase = 0;
-    for (i64 q = 0; q < nup; ++q) {
-      const int type = (up[q].meta >> 8) & 3, rows = up[q].meta & 255, cnt = up[q].meta >> 16;
-      double* v = hval.data() + q * SL_MAXCNT;
-      if (type == SL_P)
-        for (int k2 = 0; k2 < SL_MAXCNT; ++k2) v[k2] = 0.0;
-      std::string key(reinterpret_cast<const char*>(hoff.data() + q * SL_MAXCNT), sizeof(int) * SL_MAXCNT);
-      key.append(reinterpret_cast<const char*>(v), sizeof(double) * SL_MAXCNT);
-      auto it = dict.find(key);
-      int id;
-      if (it == dict.end()) {
-        id = (int)dict.size();
-        dict.emplace(std::move(key), id);
-        toff.insert(toff.end(), hoff.begin() + q * SL_MAXCNT, hoff.begin() + (q + 1) * SL_MAXCNT);
-        tval.insert(tval.end(), v, v + SL_MAXCNT);
-      } else id = it->second;
-      up[q].aux = id;
-      if (type == SL_P) {
-        PG_REQUIRE(pbase + (i64)rows * cnt < (i64)2147483647, "P-slice value array exceeds int32 indexing");
-        up[q].base = (int)pbase;
-        pbase += (i64)rows * cnt;
-      }
+    for (auto& sl : up) {
+      if (((sl.meta >> 8) & 3) != SL_P) continue;
+      const int rows = sl.meta & 255, cnt = sl.meta >> 16;
+      PG_REQUIRE(pbase + (i64)rows * cnt < (i64)2147483647, "P-slice value array exceeds int32 indexing");
+      sl.base = (int)pbase;
+      pbase += (i64)rows * cnt;
     }
-  }
-  A.nstencils = (i64)toff.size() / SL_MAXCNT;
-  A.stab_off.alloc(toff.empty() ? SL_MAXCNT : (i64)toff.size());
-  A.stab_val.alloc(tval.empty() ? SL_MAXCNT : (i64)tval.size());
-  if (!toff.empty()) {
-    A.stab_off.upload(toff.data(), (i64)toff.size());
-    A.stab_val.upload(tval.data(), (i64)tval.size());
   }
   A.pval.alloc(A.nnz_p + 8);
   // packed CSR of the irregular rows + its chunks
@@ -776,22 +830,28 @@ void build_slices(CsrMatrix& A, const std::vector<int>& rp) {
   }
   std::stable_sort(all.begin(), all.end(), [](const Slice& a, const Slice& b) { return a.key < b.key; });
   A.nslices = (i64)all.size();
-  std::vector<int> sd(4 * (A.nslices + 1), 0);
+  std::vector<int> sd(SL_REC * (A.nslices + 1), 0);
   for (i64 q = 0; q < A.nslices; ++q) {
-    sd[4 * q] = all[q].r0; sd[4 * q + 1] = all[q].meta; sd[4 * q + 2] = all[q].base; sd[4 * q + 3] = all[q].aux;
+    int* rec = sd.data() + SL_REC * q;
+    rec[0] = all[q].r0; rec[1] = all[q].meta; rec[2] = all[q].base; rec[3] = all[q].aux;
   }
-  A.sdesc.alloc((i64)sd.size());
-  A.sdesc.upload(sd.data(), (i64)sd.size());
+  A.srec.alloc((i64)sd.size());
+  A.srec.upload(sd.data(), (i64)sd.size());
+  if (A.nslices > 0) {
+    hipLaunchKernelGGL(k_fill_records, dim3(grid_for(A.nslices, 256)), dim3(256), 0, st, A.nslices, A.srec.p, A.rowptr.p, A.col.p,
+                       A.val.p);
+    PG_HIP(hipGetLastError());
+  }
   if (A.nnz_p > 0) {
-    hipLaunchKernelGGL(k_pval_fill, dim3((unsigned)std::min<i64>(A.nslices, 65535)), dim3(256), 0, st, A.nslices, A.sdesc.p,
+    hipLaunchKernelGGL(k_pval_fill, dim3((unsigned)std::min<i64>(A.nslices, 65535)), dim3(256), 0, st, A.nslices, A.srec.p,
                        A.rowptr.p, A.val.p, A.pval.p);
     PG_HIP(hipGetLastError());
   }
   PG_HIP(hipStreamSynchronize(st));
-  A.spmv_bytes = 16 * A.nslices + 8 * A.nnz_p + 12 * A.nnz_g + 8 * ng + 16 * n;
+  A.spmv_bytes = 4 * SL_REC * A.nslices + 8 * A.nnz_p + 12 * A.nnz_g + 8 * ng + 16 * n;
   if (getenv("PG_DEBUG"))
-    fprintf(stderr, "[pg_spmv] slices %lld (stencils %lld): rows U %lld P %lld G %lld of %lld; nnz P %lld G %lld of %lld; bytes/launch %lld (CSR %lld)\n",
-            (long long)A.nslices, (long long)A.nstencils, (long long)A.rows_u, (long long)A.rows_p, (long long)A.rows_g,
+    fprintf(stderr, "[pg_spmv] slices %lld: rows U %lld P %lld G %lld of %lld; nnz P %lld G %lld of %lld; bytes/launch %lld (CSR %lld)\n",
+            (long long)A.nslices, (long long)A.rows_u, (long long)A.rows_p, (long long)A.rows_g,
             (long long)n, (long long)A.nnz_p, (long long)A.nnz_g, (long long)A.nnz, (long long)A.spmv_bytes,
             (long long)(12 * A.nnz + 20 * n));
 }
@@ -824,7 +884,8 @@ void build_spmv_chunks(CsrMatrix& A) {
 }
 
 int spmv_default_grid(i64 n) {
-  static const int per_cu = getenv("PG_SPMV_BLOCKS_PER_CU") ? atoi(getenv("PG_SPMV_BLOCKS_PER_CU")) : 6;
+  // resident blocks per CU: the slice kernel holds ~100 VGPRs (4 waves / SIMD), the CSR kernels 24.6 KB of LDS (6 blocks)
+  static const int per_cu = getenv("PG_SPMV_BLOCKS_PER_CU") ? atoi(getenv("PG_SPMV_BLOCKS_PER_CU")) : ((variant() & 64) ? 4 : 6);
   static int cus = 0;
   if (cus == 0) {
     hipDeviceProp_t prop;

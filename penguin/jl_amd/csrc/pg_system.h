@@ -50,18 +50,17 @@ struct CsrMatrix {
   // unknowns (MAX_KINDS per row, -1 padded) and the coefficient rows (B⁻¹S)[row, idx], (B⁻¹MB)[row, idx]
   // (Crank-Nicolson right-hand side, see k_blk_table) and B[row, idx] (export of the un-preconditioned b)
   // stencil-sliced image of the same matrix, the default SpMV path (pg_spmv.hip "Stencil slices"):
-  //   U slice: <= 255 consecutive rows with identical (col - row) offsets AND bitwise identical values
-  //   P slice: <= 255 consecutive rows with identical offsets, per-row values stored slot-major in pval
+  //   U slice: <= 128 consecutive rows with identical (col - row) offsets AND bitwise identical values
+  //   P slice: <= 128 consecutive rows with identical offsets, per-row values stored slot-major in pval
   //   G chunk: <= 64 of the remaining (irregular) rows, packed contiguously into their own CSR (g_*)
-  DevBuf<int> sdesc;         // 4 ints per slice: {row0 | first packed row, rows | type<<8 | cnt<<16, base, aux}
-  DevBuf<int> stab_off;      // stencil table, 16 ints per entry: col - row (padded with entry 0)
-  DevBuf<double> stab_val;   // 16 doubles per entry (padded with 0.0)
+  // one 128-byte record per slice: {row0 | first packed row, rows | type<<8 | cnt<<16, base, end} + 8 offsets + 8 values
+  DevBuf<int> srec;
   DevBuf<double> pval;
   DevBuf<int> g_rowid, g_rowptr, g_col;
   DevBuf<double> g_val;
-  i64 nslices = 0, nstencils = 0;
+  i64 nslices = 0;
   i64 rows_u = 0, rows_p = 0, rows_g = 0, nnz_p = 0, nnz_g = 0;
-  i64 spmv_bytes = 0;        // bytes one launch has to move with this format: slices + P/G streams + 16 n (x, y)
+  i64 spmv_bytes = 0;        // bytes one launch has to move with this format: records + P/G streams + 16 n (x, y)
   i64 n_blk = 0;
   i64 nnz_raw = 0;   // entries of the un-preconditioned reduced matrix (what pg_solver_get_system_csr(0/1) returns)
   DevBuf<int> blk_rows, blk_idx;
