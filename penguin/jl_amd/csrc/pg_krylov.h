@@ -6,8 +6,8 @@ namespace pg {
 
 struct KrylovWork {
   i64 n = 0, nvec = 0;
-  DevBuf<double> r, rhat, p, v, s, t;   // n_vec each (p and s carry ghost entries)
-  DevBuf<double> partials;              // per-block partial sums, 4 slots x grid
+  DevBuf<double> r, rhat, p, v, t;      // n_vec each (p and r -- which holds s between the two SpMVs -- carry ghosts)
+  DevBuf<double> partials;              // per-block partial sums, 5 slots x grid
   DevBuf<double> sc;                    // device scalars (see pg_krylov.hip)
   double* h_sc = nullptr;               // pinned host mirror of sc
   int grid = 1;

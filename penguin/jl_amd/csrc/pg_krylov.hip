@@ -37,7 +37,7 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_init(i64 n, i64 nvec, const doub
       const double bi = b[i];
       const double ri = x0 ? bi - Ax0[i] : bi;
       x[i] = x0 ? x0[i] : 0.0;
-      r[i] = ri; rhat[i] = ri; p[i] = 0.0; v[i] = 0.0;
+      r[i] = ri; rhat[i] = ri; p[i] = ri; v[i] = 0.0;   // p₀ = r₀ (β = 0)
       acc += ri * ri;
       accb += bi * bi;
     } else {
@@ -50,50 +50,54 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_init(i64 n, i64 nvec, const doub
   if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = tb;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_bicg_p(i64 n, const double* __restrict__ sc, const double* __restrict__ r,
-                                                  const double* __restrict__ v, double* __restrict__ p,
-                                                  double* __restrict__ rhat) {
-  if (sc[S_DONE] != 0.0) return;
-  const double beta = sc[S_BETA], omega = sc[S_OMEGA];
-  if (sc[S_RESTART] != 0.0) {
-    for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) {
-      const double ri = r[i];
-      rhat[i] = ri;
-      p[i] = ri;
-    }
-    return;
-  }
-  for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK)
-    p[i] = r[i] + beta * (p[i] - omega * v[i]);
-}
-
-__global__ __launch_bounds__(BLOCK) void k_bicg_s(i64 n, const double* __restrict__ sc, const double* __restrict__ r,
-                                                  const double* __restrict__ v, double* __restrict__ s) {
-  if (sc[S_DONE] != 0.0) return;
-  const double alpha = sc[S_ALPHA];
-  for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) s[i] = r[i] - alpha * v[i];
-}
-
-__global__ __launch_bounds__(BLOCK) void k_bicg_xr(i64 n, const double* __restrict__ sc, const double* __restrict__ p,
-                                                   const double* __restrict__ s, const double* __restrict__ t,
-                                                   const double* __restrict__ rhat, double* __restrict__ x,
-                                                   double* __restrict__ r, double* __restrict__ partials) {
+// s = r - αv written over r (r is not needed again: r_new = s - ωt); partials slots 2, 3 = (r̂,s), (s,s): they are
+// summed together with the dots of the SpMV that follows (one scalar kernel instead of two)
+__global__ __launch_bounds__(BLOCK) void k_bicg_s(i64 n, const double* __restrict__ sc, const double* __restrict__ v,
+                                                  const double* __restrict__ rhat, double* __restrict__ r,
+                                                  double* __restrict__ partials) {
   __shared__ double s_red[BLOCK / 64];
   if (sc[S_DONE] != 0.0) return;
-  const double alpha = sc[S_ALPHA], omega = sc[S_OMEGA];
+  const double alpha = sc[S_ALPHA];
   double a0 = 0.0, a1 = 0.0;
   for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) {
-    const double si = s[i];
-    x[i] = x[i] + alpha * p[i] + omega * si;
+    const double si = r[i] - alpha * v[i];
+    r[i] = si;
+    a0 += rhat[i] * si;
+    a1 += si * si;
+  }
+  const double t0 = block_sum(a0, s_red);
+  if (threadIdx.x == 0) partials[2 * (size_t)gridDim.x + blockIdx.x] = t0;
+  const double t1 = block_sum(a1, s_red);
+  if (threadIdx.x == 0) partials[3 * (size_t)gridDim.x + blockIdx.x] = t1;
+}
+
+// x += αp + ωs;  r = s - ωt;  p = r + β(p - ωv)  (restart: p = r̂ = r);  partial slot 0 = (r,r).
+// β is known before r exists because ρ_new = (r̂,r) = (r̂,s) - ω(r̂,t) comes out of the dots of k_bicg_s and of the
+// second SpMV: the classical p-update kernel (4 vector passes) and one scalar kernel per iteration disappear.
+__global__ __launch_bounds__(BLOCK) void k_bicg_xrp(i64 n, const double* __restrict__ sc, const double* __restrict__ t,
+                                                    const double* __restrict__ v, double* __restrict__ x,
+                                                    double* __restrict__ r, double* __restrict__ p,
+                                                    double* __restrict__ rhat, double* __restrict__ partials) {
+  __shared__ double s_red[BLOCK / 64];
+  if (sc[S_DONE] != 0.0) return;
+  const double alpha = sc[S_ALPHA], omega = sc[S_OMEGA], beta = sc[S_BETA];
+  const bool restart = sc[S_RESTART] != 0.0;
+  double a0 = 0.0;
+  for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) {
+    const double si = r[i], pi = p[i];
+    x[i] = x[i] + alpha * pi + omega * si;
     const double ri = si - omega * t[i];
     r[i] = ri;
-    a0 += rhat[i] * ri;
-    a1 += ri * ri;
+    if (restart) {
+      p[i] = ri;
+      rhat[i] = ri;
+    } else {
+      p[i] = ri + beta * (pi - omega * v[i]);
+    }
+    a0 += ri * ri;
   }
   const double t0 = block_sum(a0, s_red);
   if (threadIdx.x == 0) partials[blockIdx.x] = t0;
-  const double t1 = block_sum(a1, s_red);
-  if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = t1;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_cg_init(i64 n, i64 nvec, const double* __restrict__ b, double* __restrict__ x,
@@ -154,30 +158,38 @@ __device__ inline void derive(int phase, double* sc) {
       break;
     }
     case PH_BICG_1:
-      sc[S_RESTART] = 0.0;
       // (r̂, A p) == 0: take a pure minimal-residual half step (alpha = 0) and restart afterwards
       if (r0 == 0.0) { sc[S_ALPHA] = 0.0; sc[S_FORCE] = 1.0; } else sc[S_ALPHA] = sc[S_RHO] / r0;
       break;
-    case PH_BICG_2:
-      sc[S_OMEGA] = r1 != 0.0 ? r0 / r1 : 0.0;
-      break;
-    case PH_BICG_3: {
-      const double rho_old = sc[S_RHO];
+    case PH_BICG_2: {
+      // r0 = (t,s), r1 = (t,t), RED2 = (r̂,s), RED3 = (s,s), RED4 = (r̂,t)
+      const double ts = r0, tt = r1, rs = sc[S_RED2], ss = sc[S_RED3], rt = sc[S_RED4];
+      const double omega = tt != 0.0 ? ts / tt : 0.0;
+      const double rho_old = sc[S_RHO], rho_new = rs - omega * rt;
+      double rr_pred = ss - 2.0 * omega * ts + omega * omega * tt;   // (r,r) of the coming update, restart test only
+      rr_pred = rr_pred > 0.0 ? rr_pred : 0.0;
+      sc[S_OMEGA] = omega;
       sc[S_RHO_OLD] = rho_old;
-      sc[S_RHO] = r0;
-      sc[S_RR] = r1;
-      sc[S_ITERS] += 1.0;
-      if (r1 <= sc[S_TOL2]) sc[S_DONE] = 1.0;
-      else if (sc[S_OMEGA] == 0.0 || sc[S_FORCE] != 0.0 || r0 * r0 < 1e-20 * sc[S_RHAT2] * r1) {
+      sc[S_RHO] = rho_new;
+      if (omega == 0.0 || sc[S_FORCE] != 0.0 || rho_new * rho_new < 1e-20 * sc[S_RHAT2] * rr_pred) {
         // (r̂,r) collapsed -- r̂ = b is often supported on a few identity rows (T⁰ = 0) and r leaves that
         // support: restart with r̂ := r (the remedy Eigen's BiCGSTAB uses, with a relative threshold:
-        // cos(r̂,r) < 1e-10).  k_bicg_p copies r into r̂ and p.
+        // cos(r̂,r) < 1e-10).  k_bicg_xrp copies r into r̂ and p; PH_BICG_3 sets ρ = (r,r).
         sc[S_FORCE] = 0.0;
         sc[S_RESTART] = 1.0;
-        sc[S_RHO] = r1; sc[S_RHAT2] = r1; sc[S_BETA] = 0.0; sc[S_OMEGA] = 1.0; sc[S_ALPHA] = 1.0;
-      } else sc[S_BETA] = (r0 / rho_old) * (sc[S_ALPHA] / sc[S_OMEGA]);
+        sc[S_BETA] = 0.0;
+      } else {
+        sc[S_RESTART] = 0.0;
+        sc[S_BETA] = (rho_new / rho_old) * (sc[S_ALPHA] / omega);
+      }
       break;
     }
+    case PH_BICG_3:
+      sc[S_RR] = r0;
+      sc[S_ITERS] += 1.0;
+      if (r0 <= sc[S_TOL2]) sc[S_DONE] = 1.0;
+      else if (sc[S_RESTART] != 0.0) { sc[S_RHO] = r0; sc[S_RHAT2] = r0; }
+      break;
     case PH_CG_1:
       if (r0 == 0.0) sc[S_DONE] = 2.0; else sc[S_ALPHA] = sc[S_RR] / r0;
       break;
@@ -271,9 +283,9 @@ void KrylovWork::init(i64 n_own, i64 n_vec) {
   n = n_own;
   nvec = n_vec;
   const i64 a = n_vec > 0 ? n_vec : 1;
-  r.alloc(a); rhat.alloc(a); p.alloc(a); v.alloc(a); s.alloc(a); t.alloc(a);
+  r.alloc(a); rhat.alloc(a); p.alloc(a); v.alloc(a); t.alloc(a);
   grid = spmv_default_grid(n_own);
-  partials.alloc(4 * (i64)grid);
+  partials.alloc(5 * (i64)grid);
   sc.alloc(S_COUNT);
   sc.zero();
   if (!h_sc) PG_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_sc), sizeof(double) * S_COUNT));
@@ -334,21 +346,20 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
     ++polls;
     for (int it = 0; it < batch; ++it) {
       if (!cg) {
-        hipLaunchKernelGGL(k_bicg_p, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.r.p, w.v.p, w.p.p, w.rhat.p);
         halo_exchange(nb, slab, w.p.p, st);
         timer.begin(st, launched + it);
-        launch_spmv(1, A, w.p.p, w.v.p, w.rhat.p, w.partials.p, w.sc.p, G, st);
+        launch_spmv(1, A, w.p.p, w.v.p, w.rhat.p, w.partials.p, w.sc.p, G, st);       // v = Â p, (r̂,v)
         timer.end(st);
-        finalize(PH_BICG_1, 1, w, st, true);
-        hipLaunchKernelGGL(k_bicg_s, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.r.p, w.v.p, w.s.p);
-        halo_exchange(nb, slab, w.s.p, st);
+        finalize(PH_BICG_1, 1, w, st, true);                                           // α
+        hipLaunchKernelGGL(k_bicg_s, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p);
+        halo_exchange(nb, slab, w.r.p, st);                                            // r now holds s
         timer.begin(st, launched + it);
-        launch_spmv(2, A, w.s.p, w.t.p, nullptr, w.partials.p, w.sc.p, G, st);
+        launch_spmv(3, A, w.r.p, w.t.p, w.rhat.p, w.partials.p, w.sc.p, G, st);       // t = Â s, (t,s), (t,t), (r̂,t)
         timer.end(st);
-        finalize(PH_BICG_2, 2, w, st, true);
-        hipLaunchKernelGGL(k_bicg_xr, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.p.p, w.s.p, w.t.p, w.rhat.p, x, w.r.p,
+        finalize(PH_BICG_2, 5, w, st, true);                                           // ω, ρ, β / restart
+        hipLaunchKernelGGL(k_bicg_xrp, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.t.p, w.v.p, x, w.r.p, w.p.p, w.rhat.p,
                            w.partials.p);
-        finalize(PH_BICG_3, 2, w, st, true);
+        finalize(PH_BICG_3, 1, w, st, true);                                           // (r,r): convergence
       } else {
         halo_exchange(nb, slab, w.p.p, st);
         timer.begin(st, launched + it);

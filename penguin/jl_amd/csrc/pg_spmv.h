@@ -7,7 +7,7 @@ namespace pg {
 // device scalar block of one Krylov solve (KrylovWork::sc)
 enum { S_RHO = 0, S_RHO_OLD, S_ALPHA, S_OMEGA, S_BETA, S_RR, S_BB, S_TOL2, S_DONE, S_ITERS, S_RELTOL2, S_ABSTOL2,
        S_RESTART, S_RHAT2, S_FORCE,
-       S_RED0, S_RED1, S_RED2, S_RED3, S_COUNT };
+       S_RED0, S_RED1, S_RED2, S_RED3, S_RED4, S_COUNT };
 
 constexpr int BLOCK = 256;
 
@@ -33,7 +33,7 @@ __device__ inline double block_sum(double v, double* sh /*BLOCK/64*/) {
 }
 
 // y = A x on rows [0, A.n).  mode 0: plain; 1: partials[0..grid) = aux . y; 2: partials[0..grid) = y . x and
-// partials[grid..2grid) = y . y.  `sc` (may be NULL): kernels return immediately when sc[S_DONE] != 0.
+// partials[grid..2grid) = y . y; 3: mode 2 plus partials[4grid..5grid) = aux . y.  `sc` (may be NULL): kernels return immediately when sc[S_DONE] != 0.
 // `grid` must be the value used to size `partials` (KrylovWork::grid) for modes 1/2.
 void launch_spmv(int mode, const CsrMatrix& A, const double* x, double* y, const double* aux, double* partials,
                  const double* sc, int grid, hipStream_t st);

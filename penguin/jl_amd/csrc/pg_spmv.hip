@@ -58,7 +58,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv(i64 n, const int* __restrict__ r
   __shared__ int s_col[SPMV_LDS_ENTRIES];
   __shared__ double s_red[BLOCK / 64];
   if (sc && sc[S_DONE] != 0.0) return;
-  double acc0 = 0.0, acc1 = 0.0;
+  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
   const i64 nchunks = (n + SPMV_ROWS - 1) / SPMV_ROWS;
   for (i64 chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
     const i64 r0 = chunk * SPMV_ROWS;
@@ -86,19 +86,24 @@ __global__ __launch_bounds__(BLOCK) void k_spmv(i64 n, const int* __restrict__ r
     if (r < r1) {
       y[r] = sum;
       if (MODE == 1) acc0 += aux[r] * sum;
-      if (MODE == 2) {
+      if (MODE >= 2) {
         acc0 += sum * x[r];
         acc1 += sum * sum;
       }
+      if (MODE == 3) acc2 += aux[r] * sum;
     }
   }
   if (MODE >= 1) {
     const double t0 = block_sum(acc0, s_red);
     if (threadIdx.x == 0) partials[blockIdx.x] = t0;
   }
-  if (MODE == 2) {
+  if (MODE >= 2) {
     const double t1 = block_sum(acc1, s_red);
     if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = t1;
+  }
+  if (MODE == 3) {
+    const double t2 = block_sum(acc2, s_red);
+    if (threadIdx.x == 0) partials[4 * (size_t)gridDim.x + blockIdx.x] = t2;
   }
 }
 
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_c(i64 n, i64 nchunks, const int*
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   double* __restrict__ sv = s_val[wave];
   int* __restrict__ scl = s_col[wave];
-  double acc0 = 0.0, acc1 = 0.0;
+  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
   const i64 first = (i64)blockIdx.x * (BLOCK / 64) + wave, wstride = (i64)gridDim.x * (BLOCK / 64);
   const i64 lastc = nchunks - 1;
   Stream q;
@@ -228,10 +233,11 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_c(i64 n, i64 nchunks, const int*
       y[r] = sum;
 #endif
       if (MODE == 1) acc0 += aux[r] * sum;
-      if (MODE == 2) {
+      if (MODE >= 2) {
         acc0 += sum * x[r];
         acc1 += sum * sum;
       }
+      if (MODE == 3) acc2 += aux[r] * sum;
     }
     dcur = dnext;
     dnext = dnext2;
@@ -240,9 +246,13 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_c(i64 n, i64 nchunks, const int*
     const double t0 = block_sum(acc0, s_red);
     if (threadIdx.x == 0) partials[blockIdx.x] = t0;
   }
-  if (MODE == 2) {
+  if (MODE >= 2) {
     const double t1 = block_sum(acc1, s_red);
     if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = t1;
+  }
+  if (MODE == 3) {
+    const double t2 = block_sum(acc2, s_red);
+    if (threadIdx.x == 0) partials[4 * (size_t)gridDim.x + blockIdx.x] = t2;
   }
 }
 
@@ -300,7 +310,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_cw(i64 n, i64 nchunks, const int
   int* __restrict__ scl = s_col[wave];
   d2_t* sv2 = reinterpret_cast<d2_t*>(sv);
   i4_t* sc4 = reinterpret_cast<i4_t*>(scl);
-  double acc0 = 0.0, acc1 = 0.0;
+  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
   const i64 first = (i64)blockIdx.x * (BLOCK / 64) + wave, wstride = (i64)gridDim.x * (BLOCK / 64);
   const i64 lastc = nchunks - 1;
   StreamW q;
@@ -341,10 +351,11 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_cw(i64 n, i64 nchunks, const int
     if (live) {
       y[r] = sum;
       if (MODE == 1) acc0 += aux[r] * sum;
-      if (MODE == 2) {
+      if (MODE >= 2) {
         acc0 += sum * x[r];
         acc1 += sum * sum;
       }
+      if (MODE == 3) acc2 += aux[r] * sum;
     }
     dcur = dnext;
     dnext = dnext2;
@@ -353,9 +364,13 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_cw(i64 n, i64 nchunks, const int
     const double t0 = block_sum(acc0, s_red);
     if (threadIdx.x == 0) partials[blockIdx.x] = t0;
   }
-  if (MODE == 2) {
+  if (MODE >= 2) {
     const double t1 = block_sum(acc1, s_red);
     if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = t1;
+  }
+  if (MODE == 3) {
+    const double t2 = block_sum(acc2, s_red);
+    if (threadIdx.x == 0) partials[4 * (size_t)gridDim.x + blockIdx.x] = t2;
   }
 }
 
@@ -407,7 +422,7 @@ __device__ inline d2_t load_pair(const double* p) {
 template <int CNT, int NB, bool PSL, int MODE, bool NT>
 __device__ inline void slice_rows(const SDesc& d, int nrows, int rec, const double* __restrict__ pval,
                                   const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ aux,
-                                  int lane, double& acc0, double& acc1, int dbg) {
+                                  int lane, double& acc0, double& acc1, double& acc2, int dbg) {
   int o[CNT];
 #pragma unroll
   for (int j = 0; j < CNT; ++j) o[j] = (dbg & 4) ? 0 : rlane(rec, 4 + j);
@@ -450,12 +465,14 @@ __device__ inline void slice_rows(const SDesc& d, int nrows, int rec, const doub
       }
     }
   }
-  d2_t ax[NB];
+  d2_t ax[NB], ax2[NB];   // ax: the vector of the first dot (aux in mode 1, x in modes 2/3); ax2: aux in mode 3
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     if (MODE == 1) ax[b] = load_pair<false>(aux + d.r0 + l0[b]);
-    else if (MODE == 2) ax[b] = load_pair<false>(x + d.r0 + l0[b]);
+    else if (MODE >= 2) ax[b] = load_pair<false>(x + d.r0 + l0[b]);
     else { ax[b].x = 0.0; ax[b].y = 0.0; }
+    if (MODE == 3) ax2[b] = load_pair<false>(aux + d.r0 + l0[b]);
+    else { ax2[b].x = 0.0; ax2[b].y = 0.0; }
   }
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
@@ -468,11 +485,13 @@ __device__ inline void slice_rows(const SDesc& d, int nrows, int rec, const doub
         *reinterpret_cast<d2u_t*>(yp) = out;
       }
       if (MODE >= 1) acc0 += ax[b].x * sum[b].x + ax[b].y * sum[b].y;
-      if (MODE == 2) acc1 += sum[b].x * sum[b].x + sum[b].y * sum[b].y;
+      if (MODE >= 2) acc1 += sum[b].x * sum[b].x + sum[b].y * sum[b].y;
+      if (MODE == 3) acc2 += ax2[b].x * sum[b].x + ax2[b].y * sum[b].y;
     } else if (live0[b]) {
       if (st) *yp = sum[b].x;
       if (MODE >= 1) acc0 += ax[b].x * sum[b].x;
-      if (MODE == 2) acc1 += sum[b].x * sum[b].x;
+      if (MODE >= 2) acc1 += sum[b].x * sum[b].x;
+      if (MODE == 3) acc2 += ax2[b].x * sum[b].x;
     }
   }
 }
@@ -480,24 +499,24 @@ __device__ inline void slice_rows(const SDesc& d, int nrows, int rec, const doub
 template <int CNT, bool PSL, int MODE, bool NT>
 __device__ inline void slice_nb(const SDesc& d, int nrows, int rec, const double* __restrict__ pval,
                                 const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ aux,
-                                int lane, double& acc0, double& acc1, int dbg) {
-  if (!PSL && nrows > 128) slice_rows<CNT, 2, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, dbg);
-  else slice_rows<CNT, 1, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, dbg);
+                                int lane, double& acc0, double& acc1, double& acc2, int dbg) {
+  if (!PSL && nrows > 128) slice_rows<CNT, 2, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, acc2, dbg);
+  else slice_rows<CNT, 1, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, acc2, dbg);
 }
 
 template <bool PSL, int MODE, bool NT>
 __device__ inline void slice_dispatch(int cnt, const SDesc& d, int nrows, int rec, const double* __restrict__ pval,
                                       const double* __restrict__ x, double* __restrict__ y,
-                                      const double* __restrict__ aux, int lane, double& acc0, double& acc1, int dbg) {
+                                      const double* __restrict__ aux, int lane, double& acc0, double& acc1, double& acc2, int dbg) {
   switch (cnt) {   // wave-uniform
-    case 1: slice_nb<1, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, dbg); break;
-    case 3: slice_nb<3, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, dbg); break;
-    case 5: slice_nb<5, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, dbg); break;
-    case 7: slice_nb<7, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, dbg); break;
-    case 2: slice_nb<2, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, dbg); break;
-    case 4: slice_nb<4, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, dbg); break;
-    case 6: slice_nb<6, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, dbg); break;
-    default: slice_nb<8, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, dbg); break;
+    case 1: slice_nb<1, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, acc2, dbg); break;
+    case 3: slice_nb<3, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, acc2, dbg); break;
+    case 5: slice_nb<5, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, acc2, dbg); break;
+    case 7: slice_nb<7, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, acc2, dbg); break;
+    case 2: slice_nb<2, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, acc2, dbg); break;
+    case 4: slice_nb<4, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, acc2, dbg); break;
+    case 6: slice_nb<6, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, acc2, dbg); break;
+    default: slice_nb<8, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, acc2, dbg); break;
   }
 }
 
@@ -518,7 +537,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_s(i64 nslices, const int* __rest
   int* __restrict__ scl = s_col[wave];
   d2_t* sv2 = reinterpret_cast<d2_t*>(sv);
   i4_t* sc4 = reinterpret_cast<i4_t*>(scl);
-  double acc0 = 0.0, acc1 = 0.0;
+  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
   // diagnostics (PG_SPMV_XCD bits 8..; results are wrong with any of them): 1 skip G chunks, 2 skip U/P slices,
   // 4 every x load hits one line, 8 no y stores in U/P slices
   const int dbg = xcd >> 8;
@@ -550,9 +569,9 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_s(i64 nslices, const int* __rest
     const bool skip = ((dbg & 1) && type == SL_G) || ((dbg & 2) && type != SL_G);
     if (skip) {
     } else if (type == SL_U) {
-      slice_dispatch<false, MODE, NT>(cnt, d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, dbg);
+      slice_dispatch<false, MODE, NT>(cnt, d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, acc2, dbg);
     } else if (type == SL_P) {
-      slice_dispatch<true, MODE, NT>(cnt, d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, dbg);
+      slice_dispatch<true, MODE, NT>(cnt, d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, acc2, dbg);
     } else {
       // packed irregular rows: same data flow as k_spmv_cw on the compact CSR, plus the row-id indirection
       Desc dd;
@@ -594,10 +613,11 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_s(i64 nslices, const int* __rest
       if (live) {
         y[rid] = sum;
         if (MODE == 1) acc0 += aux[rid] * sum;
-        if (MODE == 2) {
+        if (MODE >= 2) {
           acc0 += sum * x[rid];
           acc1 += sum * sum;
         }
+        if (MODE == 3) acc2 += aux[rid] * sum;
       }
     }
     rec = rec_n;
@@ -606,9 +626,13 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_s(i64 nslices, const int* __rest
     const double t0 = block_sum(acc0, s_red);
     if (threadIdx.x == 0) partials[blockIdx.x] = t0;
   }
-  if (MODE == 2) {
+  if (MODE >= 2) {
     const double t1 = block_sum(acc1, s_red);
     if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = t1;
+  }
+  if (MODE == 3) {
+    const double t2 = block_sum(acc2, s_red);
+    if (threadIdx.x == 0) partials[4 * (size_t)gridDim.x + blockIdx.x] = t2;
   }
 }
 
@@ -901,7 +925,8 @@ void launch_spmv(int mode, const CsrMatrix& A, const double* x, double* y, const
   const int v = variant();
   if (mode == 0) launch_mode<0>(v, A, x, y, aux, partials, sc, grid, st);
   else if (mode == 1) launch_mode<1>(v, A, x, y, aux, partials, sc, grid, st);
-  else launch_mode<2>(v, A, x, y, aux, partials, sc, grid, st);
+  else if (mode == 2) launch_mode<2>(v, A, x, y, aux, partials, sc, grid, st);
+  else launch_mode<3>(v, A, x, y, aux, partials, sc, grid, st);
 }
 
 void launch_spmv_variant(int v, const CsrMatrix& A, const double* x, double* y, hipStream_t st) {
