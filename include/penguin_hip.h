@@ -47,7 +47,8 @@ enum { PG_BC_NONE = 0, PG_BC_DIRICHLET = 1, PG_BC_NEUMANN = 2, PG_BC_ROBIN = 3, 
 /* border keys, in the reference's (unusual) naming           src/solver.jl:379-409 */
 enum { PG_KEY_LEFT = 0 /* dim2 = 1 */, PG_KEY_RIGHT = 1 /* dim2 = n2 */, PG_KEY_BOTTOM = 2 /* dim1 = 1 */,
        PG_KEY_TOP = 3 /* dim1 = n1 */, PG_KEY_BACKWARD = 4 /* dim3 = 1 */, PG_KEY_FORWARD = 5 /* dim3 = n3 */ };
-enum { PG_SCHEME_BE = 0, PG_SCHEME_CN = 1 };                 /* "BE" / "CN" strings of the reference */
+enum { PG_SCHEME_BE = 0, PG_SCHEME_CN = 1,                   /* "BE" / "CN" strings of the reference */
+       PG_SCHEME_STEADY = 2 };                                /* internal: the steady constructors */
 enum { PG_METHOD_BICGSTAB = 0, PG_METHOD_CG = 1 };           /* IterativeSolvers methods kept     */
 
 /* ---- plain structs ------------------------------------------------------------------- */
@@ -178,6 +179,18 @@ int32_t pg_solver_create_unsteady_diph(pg_capacity* c1, pg_diffops* o1, pg_capac
                                        const pg_jump_desc* ic, const pg_border_desc* borders, int32_t nborders,
                                        const double* D1, const double* D2, const double* f1, const double* f2,
                                        double dt, const double* T0, int32_t scheme, pg_solver** out);
+/* DiffusionSteadyMono(phase, bc_b, bc_i), diffusion.jl:14-28 (A_mono_stead_diff :30-43, b_mono_stead_diff :45-58):
+   the same blocks without V and Δt; source = f(C_ω) (no time).  solve_DiffusionSteadyMono! (:60-71) =
+   pg_solver_initial_solve; pg_solver_step / _run refuse a steady solver. */
+int32_t pg_solver_create_steady_mono(pg_capacity* c, pg_diffops* o, const pg_bc_desc* bc_interface,
+                                     const pg_border_desc* borders, int32_t nborders, const double* Dcoef,
+                                     const double* source, pg_solver** out);
+/* DiffusionSteadyDiph(phase1, phase2, bc_b, ic), diffusion.jl:88-101 (A_diph_stead_diff :103-144,
+   b_diph_stead_diff :146-162); solve_DiffusionSteadyDiph! (:164-175) = pg_solver_initial_solve. */
+int32_t pg_solver_create_steady_diph(pg_capacity* c1, pg_diffops* o1, pg_capacity* c2, pg_diffops* o2,
+                                     const pg_jump_desc* ic, const pg_border_desc* borders, int32_t nborders,
+                                     const double* D1, const double* D2, const double* f1, const double* f2,
+                                     pg_solver** out);
 int32_t pg_solver_destroy(pg_solver* s);
 
 /* per-step data for time-dependent closures; the host evaluates them at the reference's points and

@@ -776,6 +776,57 @@ def DiffusionSteadyMono(phase: Phase, bc_b, bc_i) -> Solver:
     return s
 
 
+def solve_DiffusionSteadyMono(s: Solver, method: str = "\\", **kwargs):
+    """src/solver/diffusion.jl:60-71."""
+    if s.A is None:
+        raise RuntimeError("Solver is not initialized. Call a solver constructor first.")
+    solve_system(s, method=method, **kwargs)
+    return s
+
+
+def A_diph_stead_diff(op1, op2, cap1, cap2, D1, D2, ic: InterfaceConditions):
+    """src/solver/diffusion.jl:103-144."""
+    n = int(np.prod(op1.size))
+    jump, flux = ic.scalar, ic.flux
+    I_n = sp.identity(n, format="csr")
+    Id1 = sp.diags(build_I_D(op1, D1, cap1))
+    Id2 = sp.diags(build_I_D(op2, D2, cap2))
+    L1, M1, P1, Q1 = _blocks(op1)
+    L2, M2, P2, Q2 = _blocks(op2)
+    return sp.bmat(
+        [[Id1 @ L1, Id1 @ M1, None, None],
+         [None, jump.alpha1 * I_n, None, -jump.alpha2 * I_n],
+         [None, None, Id2 @ L2, Id2 @ M2],
+         [flux.beta1 * P1, flux.beta1 * Q1, flux.beta2 * P2, flux.beta2 * Q2]], format="csr")
+
+
+def b_diph_stead_diff(op1, op2, f1, f2, cap1, cap2, ic):
+    """src/solver/diffusion.jl:146-162."""
+    gg = build_g_g(op1, ic.scalar, cap1)
+    hh = build_g_g(op2, ic.flux, cap2)
+    return np.concatenate([cap1.V * build_source(op1, f1, None, cap1), gg,
+                           cap2.V * build_source(op2, f2, None, cap2), cap2.G * hh])
+
+
+def DiffusionSteadyDiph(phase1: Phase, phase2: Phase, bc_b, ic) -> Solver:
+    """src/solver/diffusion.jl:88-101."""
+    s = Solver("Steady", "Diphasic", "Diffusion")
+    s.A = A_diph_stead_diff(phase1.operator, phase2.operator, phase1.capacity, phase2.capacity,
+                            phase1.Diffusion_coeff, phase2.Diffusion_coeff, ic)
+    s.b = b_diph_stead_diff(phase1.operator, phase2.operator, phase1.source, phase2.source, phase1.capacity,
+                            phase2.capacity, ic)
+    s.A, s.b = BC_border_diph(s.A, s.b, bc_b, phase1.capacity, phase2.capacity)
+    return s
+
+
+def solve_DiffusionSteadyDiph(s: Solver, method: str = "\\", **kwargs):
+    """src/solver/diffusion.jl:164-175."""
+    if s.A is None:
+        raise RuntimeError("Solver is not initialized. Call a solver constructor first.")
+    solve_system(s, method=method, **kwargs)
+    return s
+
+
 # ---- unsteady diphasic (config 5) -----------------------------------------------------
 
 

@@ -862,6 +862,119 @@ def solve_DiffusionUnsteadyDiph_b(s: Solver, phase1: Phase, phase2: Phase, Δt: 
     return s
 
 
+# =============================================================================== steady diffusion
+
+
+def _interface_desc(bc_i, cg, t):
+    """pg_bc_desc of a monophasic interface condition (value constant or evaluated at C_γ)."""
+    if isinstance(bc_i, Dirichlet):
+        kind, a, b = L.PG_BC_DIRICHLET, 0.0, 0.0
+    elif isinstance(bc_i, Neumann):
+        kind, a, b = L.PG_BC_NEUMANN, 0.0, 0.0
+    elif isinstance(bc_i, Robin):
+        kind, a, b = L.PG_BC_ROBIN, float(bc_i.α), float(bc_i.β)
+    else:
+        raise TypeError(f"unsupported interface condition {bc_i!r}")
+    g_arr, gval = None, 0.0
+    if callable(bc_i.value):
+        g = _eval(bc_i.value, cg, t, 3)
+        if isinstance(g, float):
+            gval = g
+        else:
+            g_arr = g
+    else:
+        gval = float(bc_i.value)
+    return L.pg_bc_desc(kind, a, b, gval, L.dptr(g_arr) if g_arr is not None else None), g_arr
+
+
+def _dcoef(ph: Phase, M: int):
+    D = _eval(ph.Diffusion_coeff, ph.capacity._cw, None, 3) if callable(ph.Diffusion_coeff) else float(ph.Diffusion_coeff)
+    if isinstance(D, float):
+        return None if D == 1.0 else np.full(M, D)
+    return D
+
+
+def DiffusionSteadyMono(phase: Phase, bc_b: BorderConditions, bc_i, verbose: bool = False) -> Solver:
+    """DiffusionSteadyMono(phase, bc_b, bc_i) -- src/solver/diffusion.jl:14-28."""
+    if verbose:
+        print("Solver creation:\n- Monophasic problem\n- Steady problem\n- Diffusion problem")
+    s = Solver("Steady", "Monophasic", "Diffusion")
+    cap, mesh = phase.capacity, phase.capacity.mesh
+    M = int(np.prod(mesh.ext))
+    s._nunk = 2 * M
+    desc, g_keep = _interface_desc(bc_i, cap._cg, None)            # build_g_g without t  (:51)
+    D_arr = _dcoef(phase, M)
+    f_arr = _padded_field(_eval(phase.source, cap._cw, None, 3), M)  # build_source without t  (:50)
+    borders, nb, bvals = _border_descs(bc_b, mesh, None)             # BC_border_mono!(A, b, bc_b, mesh)  (:25)
+    p = lambda a: L.dptr(a) if a is not None else None
+    L.check(L.lib().pg_solver_create_steady_mono(cap._h, phase.operator._h, C.byref(desc), borders, C.c_int32(nb),
+                                                 p(D_arr), p(f_arr), C.byref(s._h)))
+    if bvals is not None:
+        L.check(L.lib().pg_solver_set_border_values(s._h, L.dptr(bvals)))
+    s._ctx = dict(M=M)
+    s._ctor_scheme = "STEADY"
+    return s
+
+
+def _solve_steady(s: Solver, method, kwargs, banner: str, verbose: bool):
+    if s is None or not s._h:
+        raise PenguinHipError("Solver is not initialized. Call a solver constructor first.")
+    if verbose:
+        print(banner)
+    kwargs = dict(kwargs)
+    kwargs.setdefault("warm_start", False)
+    opts = _krylov_opts(method, kwargs)
+    info = L.pg_step_info()
+    L.check(L.lib().pg_solver_initial_solve(s._h, C.byref(opts), C.byref(info)))   # solve_system!(s; ...)
+    s._initial_done = True
+    s.x = s._fetch_state()
+    s.ch.append(dict(iters=info.iters, converged=bool(info.converged), resnorm=info.resnorm, bnorm=info.bnorm))
+    return s
+
+
+def solve_DiffusionSteadyMono_b(s: Solver, method="bicgstab", algorithm=None, verbose: bool = False, **kwargs):
+    """solve_DiffusionSteadyMono!(s; method, algorithm, kwargs...) -- src/solver/diffusion.jl:60-71."""
+    return _solve_steady(s, method, kwargs, "Solving the system:\n- Monophasic problem\n- Steady problem\n- Diffusion problem",
+                         verbose)
+
+
+def DiffusionSteadyDiph(phase1: Phase, phase2: Phase, bc_b: BorderConditions, ic: InterfaceConditions,
+                        verbose: bool = False) -> Solver:
+    """DiffusionSteadyDiph(phase1, phase2, bc_b, ic) -- src/solver/diffusion.jl:88-101."""
+    if verbose:
+        print("Solver creation:\n- Diphasic problem\n- Steady problem\n- Diffusion problem")
+    s = Solver("Steady", "Diphasic", "Diffusion")
+    mesh = phase1.capacity.mesh
+    M = int(np.prod(mesh.ext))
+    s._nunk = 4 * M
+    jump, flux = ic.scalar, ic.flux
+    g = _eval(jump.value, phase1.capacity._cg, None, 3) if callable(jump.value) else float(jump.value)
+    h = _eval(flux.value, phase2.capacity._cg, None, 3) if callable(flux.value) else float(flux.value)
+    g_arr = None if isinstance(g, float) else g
+    h_arr = None if isinstance(h, float) else h
+    p = lambda a: L.dptr(a) if a is not None else None
+    desc = L.pg_jump_desc(float(jump.α1), float(jump.α2), g if isinstance(g, float) else 0.0, float(flux.β1),
+                          float(flux.β2), h if isinstance(h, float) else 0.0, p(g_arr), p(h_arr))
+    D1, D2 = _dcoef(phase1, M), _dcoef(phase2, M)
+    f1 = _padded_field(_eval(phase1.source, phase1.capacity._cw, None, 3), M)
+    f2 = _padded_field(_eval(phase2.source, phase2.capacity._cw, None, 3), M)
+    borders, nb, bvals = _border_descs(bc_b, mesh, None)
+    L.check(L.lib().pg_solver_create_steady_diph(
+        phase1.capacity._h, phase1.operator._h, phase2.capacity._h, phase2.operator._h, C.byref(desc), borders,
+        C.c_int32(nb), p(D1), p(D2), p(f1), p(f2), C.byref(s._h)))
+    if bvals is not None:
+        L.check(L.lib().pg_solver_set_border_values(s._h, L.dptr(bvals)))
+    s._ctx = dict(M=M)
+    s._ctor_scheme = "STEADY"
+    return s
+
+
+def solve_DiffusionSteadyDiph_b(s: Solver, method="bicgstab", algorithm=None, verbose: bool = False, **kwargs):
+    """solve_DiffusionSteadyDiph!(s; method, algorithm, kwargs...) -- src/solver/diffusion.jl:164-175."""
+    return _solve_steady(s, method, kwargs, "Solving the system:\n- Diphasic problem\n- Steady problem\n- Diffusion problem",
+                         verbose)
+
+
 # =============================================================================== convergence metric
 
 

@@ -103,7 +103,7 @@ __global__ void k_row_static(SysParams P, RowSegs seg, i64 n_own, const int* row
         fx = 1;
         bv = (bk == PG_BC_PERIODIC) ? 0.0 : kv.v[key];
       } else {
-        m = P.cap[ph].V[lc];
+        m = P.mass * P.cap[ph].V[lc];
       }
     } else if (P.nphase == 2) {
       fx = 1;   // jump rows: b2 = g, b4 = Γ₂h for both schemes (diffusion.jl:415-416)
@@ -264,9 +264,11 @@ SysParams make_params(const pg_solver* s, int scheme) {
     P.Id[q] = s->Id[q].p;
   }
   if (s->nphase == 1) { P.cap[1] = P.cap[0]; P.ct[1] = P.ct[0]; P.Id[1] = nullptr; }
+  // steady (diffusion.jl:30-43): the unsteady BE blocks with Δt = 1 and without the V term
   const double th = scheme == PG_SCHEME_CN ? s->dt / 2 : s->dt;
   P.theta = th;
   P.gscale = scheme == PG_SCHEME_CN ? s->dt / 2 : 1.0;
+  P.mass = scheme == PG_SCHEME_STEADY ? 0.0 : 1.0;
   if (s->nphase == 1) {
     switch (s->bc_i.kind) {     // build_I_bc, solver.jl:203-223
       case PG_BC_DIRICHLET: P.Ia = 1.0; P.Ib = 0.0; break;
@@ -477,6 +479,7 @@ void do_initial(pg_solver* s, const pg_krylov_opts* opts, SolveStats& st) {
 }
 
 void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& st) {
+  PG_REQUIRE(s->scheme_ctor != PG_SCHEME_STEADY, "a steady solver has no time loop");
   PG_REQUIRE(s->initial_done, "Solver is not initialized. Call pg_solver_initial_solve first.");
   const pg_krylov_opts o = opts ? *opts : default_opts();
   hipStream_t stream = ctx().stream;
@@ -512,15 +515,11 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
 
 extern "C" {
 
-int32_t pg_solver_create_unsteady_mono(pg_capacity* c, pg_diffops* o, const pg_bc_desc* bc_interface,
-                                       const pg_border_desc* borders, int32_t nborders, const double* Dcoef,
-                                       const double* source, double dt, const double* T0, int32_t scheme,
-                                       pg_solver** out) {
-  PG_API_BEGIN
-  require_init();
-  PG_REQUIRE(c && o && bc_interface && out, "pg_solver_create_unsteady_mono: NULL argument");
+static void create_mono(pg_capacity* c, pg_diffops* o, const pg_bc_desc* bc_interface, const pg_border_desc* borders,
+                        int32_t nborders, const double* Dcoef, const double* source, double dt, const double* T0,
+                        int32_t scheme, pg_solver** out) {
+  PG_REQUIRE(c && o && bc_interface && out, "solver constructor: NULL argument");
   PG_REQUIRE(o->cap == c, "operators were built from a different capacity");
-  PG_REQUIRE(scheme == PG_SCHEME_BE || scheme == PG_SCHEME_CN, "scheme must be BE or CN");
   PG_REQUIRE(dt > 0.0, "dt must be positive");
   auto* s = new pg_solver();
   std::unique_ptr<pg_solver> guard(s);
@@ -539,19 +538,35 @@ int32_t pg_solver_create_unsteady_mono(pg_capacity* c, pg_diffops* o, const pg_b
   s->bc_i.value_array = nullptr;
   setup_common(s, borders, nborders, T0);
   *out = guard.release();
+}
+
+int32_t pg_solver_create_unsteady_mono(pg_capacity* c, pg_diffops* o, const pg_bc_desc* bc_interface,
+                                       const pg_border_desc* borders, int32_t nborders, const double* Dcoef,
+                                       const double* source, double dt, const double* T0, int32_t scheme,
+                                       pg_solver** out) {
+  PG_API_BEGIN
+  require_init();
+  PG_REQUIRE(scheme == PG_SCHEME_BE || scheme == PG_SCHEME_CN, "scheme must be BE or CN");
+  create_mono(c, o, bc_interface, borders, nborders, Dcoef, source, dt, T0, scheme, out);
   PG_API_END
 }
 
-int32_t pg_solver_create_unsteady_diph(pg_capacity* c1, pg_diffops* o1, pg_capacity* c2, pg_diffops* o2,
-                                       const pg_jump_desc* ic, const pg_border_desc* borders, int32_t nborders,
-                                       const double* D1, const double* D2, const double* f1, const double* f2, double dt,
-                                       const double* T0, int32_t scheme, pg_solver** out) {
+int32_t pg_solver_create_steady_mono(pg_capacity* c, pg_diffops* o, const pg_bc_desc* bc_interface,
+                                     const pg_border_desc* borders, int32_t nborders, const double* Dcoef,
+                                     const double* source, pg_solver** out) {
   PG_API_BEGIN
   require_init();
-  PG_REQUIRE(c1 && c2 && o1 && o2 && ic && out, "pg_solver_create_unsteady_diph: NULL argument");
+  create_mono(c, o, bc_interface, borders, nborders, Dcoef, source, 1.0, nullptr, PG_SCHEME_STEADY, out);
+  PG_API_END
+}
+
+static void create_diph(pg_capacity* c1, pg_diffops* o1, pg_capacity* c2, pg_diffops* o2, const pg_jump_desc* ic,
+                        const pg_border_desc* borders, int32_t nborders, const double* D1, const double* D2,
+                        const double* f1, const double* f2, double dt, const double* T0, int32_t scheme, pg_solver** out) {
+  PG_REQUIRE(c1 && c2 && o1 && o2 && ic && out, "solver constructor: NULL argument");
   PG_REQUIRE(c1->mesh == c2->mesh, "Phase capacities must share the same mesh.");
   PG_REQUIRE(c1->slab.p0 == c2->slab.p0 && c1->slab.p1 == c2->slab.p1, "phase capacities must share the slab partition");
-  PG_REQUIRE(scheme == PG_SCHEME_BE || scheme == PG_SCHEME_CN, "scheme must be BE or CN");
+  PG_REQUIRE(dt > 0.0, "dt must be positive");
   auto* s = new pg_solver();
   std::unique_ptr<pg_solver> guard(s);
   s->nphase = 2;
@@ -570,6 +585,26 @@ int32_t pg_solver_create_unsteady_diph(pg_capacity* c1, pg_diffops* o1, pg_capac
   s->ic.g_array = s->ic.h_array = nullptr;
   setup_common(s, borders, nborders, T0);
   *out = guard.release();
+}
+
+int32_t pg_solver_create_unsteady_diph(pg_capacity* c1, pg_diffops* o1, pg_capacity* c2, pg_diffops* o2,
+                                       const pg_jump_desc* ic, const pg_border_desc* borders, int32_t nborders,
+                                       const double* D1, const double* D2, const double* f1, const double* f2, double dt,
+                                       const double* T0, int32_t scheme, pg_solver** out) {
+  PG_API_BEGIN
+  require_init();
+  PG_REQUIRE(scheme == PG_SCHEME_BE || scheme == PG_SCHEME_CN, "scheme must be BE or CN");
+  create_diph(c1, o1, c2, o2, ic, borders, nborders, D1, D2, f1, f2, dt, T0, scheme, out);
+  PG_API_END
+}
+
+int32_t pg_solver_create_steady_diph(pg_capacity* c1, pg_diffops* o1, pg_capacity* c2, pg_diffops* o2,
+                                     const pg_jump_desc* ic, const pg_border_desc* borders, int32_t nborders,
+                                     const double* D1, const double* D2, const double* f1, const double* f2,
+                                     pg_solver** out) {
+  PG_API_BEGIN
+  require_init();
+  create_diph(c1, o1, c2, o2, ic, borders, nborders, D1, D2, f1, f2, 1.0, nullptr, PG_SCHEME_STEADY, out);
   PG_API_END
 }
 

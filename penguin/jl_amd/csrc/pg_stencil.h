@@ -24,6 +24,7 @@ struct SysParams {
   double a1, a2, b1, b2; // diph jump coefficients α₁ α₂ β₁ β₂
   double theta;          // Δt (BE) or Δt/2 (CN): multiplies the diffusion part of bulk rows
   double gscale;         // mono interface rows: 1 (BE) or Δt/2 (CN)
+  double mass;           // coefficient of V in the bulk rows: 1 (unsteady), 0 (steady: A_mono_stead_diff, diffusion.jl:30-43)
   int border_kind[6];    // per PG_KEY_*
   double inv_dx;         // 1/Δx for the 1-D Neumann border row
 };
@@ -176,7 +177,7 @@ __device__ inline void eval_row(const SysParams& P, int kind, i64 lc, const i64*
       }
     }
     if (bulk) {
-      emit(kw, lc, c.V[lc] + scale * dW);          // V + θ·Id·(GᵀWꜝG)_jj
+      emit(kw, lc, P.mass * c.V[lc] + scale * dW);          // V + θ·Id·(GᵀWꜝG)_jj  (steady: no V)
       emit(kg, lc, scale * dG);
     } else if (P.nphase == 1) {
       emit(kw, lc, scale * dW);

@@ -605,3 +605,71 @@ def test_spmv_stencil_slices_bitwise_equal_csr_kernels(pj, case):
         diff, mx = _spmv_compare(pj, s, 0, 70, other)
         assert mx > 0.0
         assert diff == 0.0, (case, other, diff, mx)
+
+
+# ------------------------------------------------------------------------------------ steady diffusion
+def test_steady_monophasic_reference_test(pj):
+    """test/solver/diffusion_test.jl:5-26: 20^2, circle r=0.5 at (0.5,0.5), Dirichlet(1) everywhere, f = 0."""
+    n = 20
+    M = (n + 1) ** 2
+    mesh, omesh = pj.Mesh((n, n), (2.0, 2.0)), po.Mesh((n, n), (2.0, 2.0), (0.0, 0.0))
+    cap = pj.Capacity(pj.Sphere((0.5, 0.5), 0.5), mesh)
+    ocap = oracle_capacity_from_product(cap, omesh)
+    f, D = (lambda x, y, z=0.0: 0.0), (lambda x, y, z=0.0: 1.0)
+    ph, oph = pj.Phase(cap, pj.DiffusionOps(cap), f, D), po.Phase(ocap, po.make_diffusion_ops(ocap), f, D)
+    s = pj.DiffusionSteadyMono(ph, pj.BorderConditions({k: pj.Dirichlet(1.0) for k in HEAT_BORDERS}), pj.Dirichlet(1.0))
+    so = po.DiffusionSteadyMono(oph, po.BorderConditions({k: po.Dirichlet(1.0) for k in HEAT_BORDERS}), po.Dirichlet(1.0))
+    _check_system(s, so)
+    pj.solve_DiffusionSteadyMono_b(s, reltol=1e-13)
+    po.solve_DiffusionSteadyMono(so, method="\\")
+    assert s.ch[-1]["converged"]
+    assert rel_l2(s.x, so.x) <= TOL_T
+    assert s.x[:M].max() == pytest.approx(1.0, abs=1e-2) and s.x[M:].max() == pytest.approx(1.0, abs=1e-2)
+    with pytest.raises(pj.PenguinHipError):      # a steady solver has no time loop
+        pj.solve_DiffusionUnsteadyMono_b(s, ph, 0.1, 1.0, pj.BorderConditions({}), pj.Dirichlet(1.0), "BE")
+
+
+@pytest.mark.parametrize("N,n", [(2, 40), (3, 24)])
+def test_steady_poisson_convergence_shape(pj, N, n):
+    """test/convergence_test.jl:30-70: -Δu = 2N in the ball r=1, u = 0 on the interface; u = 1 - |x-c|^2."""
+    c = (2.0,) * N
+    mesh, omesh = pj.Mesh((n,) * N, (4.0,) * N), po.Mesh((n,) * N, (4.0,) * N, (0.0,) * N)
+    cap = pj.Capacity(pj.Sphere(c, 1.0), mesh)
+    f, D = (lambda x, y, z=0.0: 2.0 * N), (lambda x, y, z=0.0: 1.0)
+    keys = HEAT_BORDERS + (("forward", "backward") if N == 3 else ())
+    ph = pj.Phase(cap, pj.DiffusionOps(cap), f, D)
+    s = pj.DiffusionSteadyMono(ph, pj.BorderConditions({k: pj.Dirichlet(1.0) for k in keys}), pj.Dirichlet(0.0))
+    pj.solve_DiffusionSteadyMono_b(s, reltol=1e-12)
+    assert s.ch[-1]["converged"]
+    u = (lambda x, y: 1.0 - (x - 2) ** 2 - (y - 2) ** 2) if N == 2 else (lambda x, y, z: 1.0 - (x - 2) ** 2 - (y - 2) ** 2 - (z - 2) ** 2)
+    _, _, global_err, *_ = pj.check_convergence(u, s, cap, 2)
+    assert global_err < 1e-2                                       # the reference's threshold
+    if N == 2:
+        ocap = oracle_capacity_from_product(cap, omesh)
+        so = po.DiffusionSteadyMono(po.Phase(ocap, po.make_diffusion_ops(ocap), f, D),
+                                    po.BorderConditions({k: po.Dirichlet(1.0) for k in keys}), po.Dirichlet(0.0))
+        po.solve_DiffusionSteadyMono(so, method="\\")
+        assert rel_l2(s.x, so.x) <= TOL_T
+
+
+def test_steady_diphasic_reference_test(pj):
+    """test/solver/diffusion_test.jl:28-56: 80^2, circle r=1 and its complement, f = 1, [[T]] = 0, [[q]] = 0."""
+    n = 80
+    M = (n + 1) ** 2
+    mesh, omesh = pj.Mesh((n, n), (4.0, 4.0)), po.Mesh((n, n), (4.0, 4.0), (0.0, 0.0))
+    c1, c2 = pj.Capacity(pj.Sphere((2.0, 2.0), 1.0), mesh), pj.Capacity(pj.Sphere((2.0, 2.0), 1.0, complement=True), mesh)
+    oc1, oc2 = oracle_capacity_from_product(c1, omesh), oracle_capacity_from_product(c2, omesh)
+    one = lambda x, y, z=0.0: 1.0
+    bcb = pj.BorderConditions({k: pj.Dirichlet(0.0) for k in HEAT_BORDERS})
+    obcb = po.BorderConditions({k: po.Dirichlet(0.0) for k in HEAT_BORDERS})
+    ic = pj.InterfaceConditions(pj.ScalarJump(1.0, 1.0, 0.0), pj.FluxJump(1.0, 1.0, 0.0))
+    oic = po.InterfaceConditions(po.ScalarJump(1.0, 1.0, 0.0), po.FluxJump(1.0, 1.0, 0.0))
+    s = pj.DiffusionSteadyDiph(pj.Phase(c1, pj.DiffusionOps(c1), one, one), pj.Phase(c2, pj.DiffusionOps(c2), one, one), bcb, ic)
+    so = po.DiffusionSteadyDiph(po.Phase(oc1, po.make_diffusion_ops(oc1), one, one),
+                                po.Phase(oc2, po.make_diffusion_ops(oc2), one, one), obcb, oic)
+    _check_system(s, so)
+    pj.solve_DiffusionSteadyDiph_b(s, reltol=1e-13)
+    po.solve_DiffusionSteadyDiph(so, method="\\")
+    assert s.ch[-1]["converged"]
+    assert rel_l2(s.x, so.x) <= 1e-9
+    assert s.x[:M].max() == pytest.approx(1.15, abs=1e-2)          # the reference's assertion

@@ -195,3 +195,35 @@ def test_config1_disc_cooling_against_bessel_series():
 
     _, _, global_err, full_err, cut_err, _ = po.check_convergence(u_ana, s, cap, 2)
     assert global_err < 1e-2
+
+
+# ---------------------------------------------------------------- test/solver/diffusion_test.jl:5-56 (steady drivers)
+def test_steady_monophasic_known_answer():
+    n = 20
+    mesh = po.Mesh((n, n), (2.0, 2.0), (0.0, 0.0))
+    cap = po.make_capacity(Ball((0.5, 0.5), 0.5), mesh)
+    op = po.make_diffusion_ops(cap)
+    ph = po.Phase(cap, op, lambda x, y, z=0.0: 0.0, lambda x, y, z=0.0: 1.0)
+    bcb = po.BorderConditions({k: po.Dirichlet(1.0) for k in ("left", "right", "top", "bottom")})
+    s = po.DiffusionSteadyMono(ph, bcb, po.Dirichlet(1.0))
+    po.solve_DiffusionSteadyMono(s, method="\\")
+    M = (n + 1) ** 2
+    pin = GOLD["known_answers"]["steady_mono_20x20_max"]
+    assert s.x[:M].max() == pytest.approx(pin["value"], abs=pin["atol"])
+    assert s.x[M:].max() == pytest.approx(pin["value"], abs=pin["atol"])
+
+
+def test_steady_diphasic_known_answer():
+    n = 80
+    mesh = po.Mesh((n, n), (4.0, 4.0), (0.0, 0.0))
+    cap1 = po.make_capacity(Ball((2.0, 2.0), 1.0), mesh)
+    cap2 = po.make_capacity(Ball((2.0, 2.0), 1.0, complement=True), mesh)
+    one = lambda x, y, z=0.0: 1.0
+    p1, p2 = po.Phase(cap1, po.make_diffusion_ops(cap1), one, one), po.Phase(cap2, po.make_diffusion_ops(cap2), one, one)
+    bcb = po.BorderConditions({k: po.Dirichlet(0.0) for k in ("left", "right", "top", "bottom")})
+    ic = po.InterfaceConditions(po.ScalarJump(1.0, 1.0, 0.0), po.FluxJump(1.0, 1.0, 0.0))
+    s = po.DiffusionSteadyDiph(p1, p2, bcb, ic)
+    po.solve_DiffusionSteadyDiph(s, method="\\")
+    M = (n + 1) ** 2
+    pin = GOLD["known_answers"]["steady_diph_80x80_max_u1o"]
+    assert s.x[:M].max() == pytest.approx(pin["value"], abs=pin["atol"])
