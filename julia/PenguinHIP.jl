@@ -255,4 +255,41 @@ function solve_DiffusionUnsteadyMono!(s::Solver, phase::Phase, Î”t::Float64, Tâ‚
     end
 end
 
+# ---- steady diffusion (src/solver/diffusion.jl:14-71): same blocks without V and Î”t ---------------------------------
+evalf0(f, C) = [f(coords3(c)...) for c in C]                                  # build_source / build_g_g without t
+
+function DiffusionSteadyMono(phase::Phase, bc_b::BorderConditions, bc_i::AbstractBoundary)
+    println("Solver creation:"); println("- Monophasic problem"); println("- Steady problem"); println("- Diffusion problem")
+    cap = phase.capacity
+    kind = bc_i isa Dirichlet ? 1 : bc_i isa Neumann ? 2 : 3
+    Î±, Î² = bc_i isa Robin ? (Float64(bc_i.Î±), Float64(bc_i.Î²)) : (0.0, 0.0)
+    g = bc_i.value isa Function ? evalf0(bc_i.value, cap.C_Î³) : Float64[]
+    D = [phase.Diffusion_coeff(coords3(c)...) for c in cap.C_Ï‰]
+    f = evalf0(phase.source, cap.C_Ï‰)
+    borders = [pg_border_desc(KEYS[k], v isa Dirichlet ? 1 : v isa Periodic ? 4 : v isa Neumann ? 2 : 3,
+                              v isa Periodic || v.value isa Function ? 0.0 : Float64(v.value)) for (k, v) in bc_b.borders if haskey(KEYS, k)]
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve g D f borders begin
+        desc = Ref(pg_bc_desc(kind, Î±, Î², bc_i.value isa Function ? 0.0 : Float64(bc_i.value), isempty(g) ? C_NULL : pointer(g)))
+        check(ccall((:pg_solver_create_steady_mono, libpg), Int32,
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{pg_bc_desc}, Ptr{pg_border_desc}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Ptr{Cvoid}}),
+                    cap.handle, phase.operator.handle, desc, borders, length(borders), D, f, h))
+    end
+    s = Solver(:Steady, :Monophasic, :Diffusion, nothing, nothing, nothing, [], [], h[], 2 * length(cap.C_Ï‰))
+    finalizer(x -> ccall((:pg_solver_destroy, libpg), Int32, (Ptr{Cvoid},), x.handle), s)
+    s
+end
+
+function solve_DiffusionSteadyMono!(s::Solver; method=nothing, algorithm=nothing, kwargs...)
+    s.handle == C_NULL && error("Solver is not initialized. Call a solver constructor first.")
+    println("Solving the system:"); println("- Monophasic problem"); println("- Steady problem"); println("- Diffusion problem")
+    kw = (; kwargs...)
+    opts = Ref(pg_krylov_opts(method === :cg ? 1 : 0, get(kw, :reltol, 1e-12), get(kw, :abstol, 0.0), get(kw, :maxiter, 0), 4, 0))
+    info = pg_step_info()
+    check(ccall((:pg_solver_initial_solve, libpg), Int32, (Ptr{Cvoid}, Ptr{pg_krylov_opts}, Ref{pg_step_info}), s.handle, opts, info))
+    s.x = _state(s)
+end
+# DiffusionSteadyDiph / solve_DiffusionSteadyDiph! (:88-175) bind pg_solver_create_steady_diph the same way (two
+# capacities / operators, pg_jump_desc as in DiffusionUnsteadyDiph).
+
 end # module
