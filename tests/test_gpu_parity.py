@@ -673,3 +673,35 @@ def test_steady_diphasic_reference_test(pj):
     assert s.ch[-1]["converged"]
     assert rel_l2(s.x, so.x) <= 1e-9
     assert s.x[:M].max() == pytest.approx(1.15, abs=1e-2)          # the reference's assertion
+
+
+# ------------------------------------------------------------------------------------ the C ABI from plain C
+def test_c_abi_driver_matches_python_host_layer(pj, tmp_path):
+    """examples/heat2d_c_abi.c (gcc, no Python in the process) reproduces the host-mirror result bit for bit."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    libdir = root / "penguin" / "jl_amd" / "lib"
+    exe = tmp_path / "heat2d_c_abi"
+    subprocess.run([gcc, "-std=c11", "-O2", f"-I{root / 'include'}", str(root / "examples" / "heat2d_c_abi.c"), f"-L{libdir}",
+                    "-lpenguin_hip", f"-Wl,-rpath,{libdir}", "-o", str(exe)], check=True)
+    n, steps = 80, 10
+    out = subprocess.run([str(exe), str(n), str(steps)], check=True, capture_output=True, text=True, timeout=300).stdout.split()
+    assert int(out[0]) == n and int(out[2]) == steps
+    extremum, heat, tc = float(out[3]), float(out[4]), float(out[5])
+    M = (n + 1) ** 2
+    mesh = pj.Mesh((n, n), (4.0, 4.0))
+    cap = pj.Capacity(pj.Sphere((2.01, 2.01), 1.0), mesh)
+    ph = pj.Phase(cap, pj.DiffusionOps(cap), 0.0, 1.0)
+    bcb = pj.BorderConditions({k: pj.Dirichlet(0.0) for k in HEAT_BORDERS})
+    dt = 0.25 * (4.0 / n) ** 2
+    s = pj.DiffusionUnsteadyMono(ph, bcb, pj.Dirichlet(1.0), dt, np.concatenate([np.zeros(M), np.ones(M)]), "BE")
+    pj.solve_DiffusionUnsteadyMono_b(s, ph, dt, 1e30, bcb, pj.Dirichlet(1.0), "BE", max_steps=steps, save_states=False,
+                                     reltol=1e-13)
+    assert np.abs(s.x).max() == extremum
+    assert float(cap.V @ s.x[:M]) == pytest.approx(heat, rel=1e-14)
+    assert s.x[(n // 2) * (n + 1) + n // 2] == tc
