@@ -13,7 +13,7 @@ from pathlib import Path
 import numpy as np
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "lib" / "libpenguin_hip.so"
+LIB_PATH = Path(os.environ["PG_LIB_PATH"]) if os.environ.get("PG_LIB_PATH") else _HERE / "lib" / "libpenguin_hip.so"   # override: A/B runs of two builds
 HEADER_PATH = _HERE.parent.parent / "include" / "penguin_hip.h"
 
 

@@ -71,10 +71,10 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_s(i64 n, const double* __restric
   if (threadIdx.x == 0) partials[3 * (size_t)gridDim.x + blockIdx.x] = t1;
 }
 
-// x += αp + ωs;  r = s - ωt;  p = r + β(p - ωv)  (restart: p = r̂ = r);  partial slot 0 = (r,r).
+// x += αp + ωs;  r = s - ωt;  p = r + β(p - ωv)  (restart: p = r̂ = r);  partial slot 1 = (r,r).
 // β is known before r exists because ρ_new = (r̂,r) = (r̂,s) - ω(r̂,t) comes out of the dots of k_bicg_s and of the
 // second SpMV: the classical p-update kernel (4 vector passes) and one scalar kernel per iteration disappear.
-__global__ __launch_bounds__(BLOCK) void k_bicg_xrp(i64 n, const double* __restrict__ sc, const double* __restrict__ t,
+__global__ __launch_bounds__(BLOCK) void k_bicg_xrp(i64 n, double* sc, const double* __restrict__ t,
                                                     const double* __restrict__ v, double* __restrict__ x,
                                                     double* __restrict__ r, double* __restrict__ p,
                                                     double* __restrict__ rhat, double* __restrict__ partials) {
@@ -96,8 +96,10 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_xrp(i64 n, const double* __restr
     }
     a0 += ri * ri;
   }
+  // slot 1: summed together with the next SpMV's (r̂,v) in slot 0 (or alone, before a host poll)
   const double t0 = block_sum(a0, s_red);
-  if (threadIdx.x == 0) partials[blockIdx.x] = t0;
+  if (threadIdx.x == 0) partials[(size_t)gridDim.x + blockIdx.x] = t0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) sc[S_PENDING3] = 1.0;   // (only the scalar kernels read it)
 }
 
 __global__ __launch_bounds__(BLOCK) void k_cg_init(i64 n, i64 nvec, const double* __restrict__ b, double* __restrict__ x,
@@ -143,6 +145,18 @@ __global__ __launch_bounds__(BLOCK) void k_cg_p(i64 n, const double* __restrict_
 }
 
 // ---- scalar phase: sum block partials (deterministic order), then derive the iteration scalars ----
+// end of a BiCGStab iteration: (r,r) -> convergence, restart bookkeeping.  Its reduction rides with the next
+// iteration's (r̂,v) (PH_BICG_1) -- one scalar kernel and, with several ranks, one all-reduce less per iteration --
+// or stands alone before the host polls (PH_BICG_3).
+__device__ inline void end_of_iteration(double* sc) {
+  const double rr = sc[S_RED1];
+  sc[S_PENDING3] = 0.0;
+  sc[S_RR] = rr;
+  sc[S_ITERS] += 1.0;
+  if (rr <= sc[S_TOL2]) sc[S_DONE] = 1.0;
+  else if (sc[S_RESTART] != 0.0) { sc[S_RHO] = rr; sc[S_RHAT2] = rr; }
+}
+
 __device__ inline void derive(int phase, double* sc) {
   const double r0 = sc[S_RED0], r1 = sc[S_RED1];
   switch (phase) {
@@ -151,13 +165,15 @@ __device__ inline void derive(int phase, double* sc) {
       const double bb = phase == PH_INIT ? r1 : r0;   // BiCGStab init also reduces b.b (warm start: r0 != b)
       sc[S_BB] = bb; sc[S_RR] = r0; sc[S_RHO] = r0; sc[S_RHO_OLD] = 1.0;
       sc[S_ALPHA] = 1.0; sc[S_OMEGA] = 1.0; sc[S_BETA] = 0.0; sc[S_ITERS] = 0.0;
-      sc[S_RESTART] = 0.0; sc[S_RHAT2] = r0; sc[S_FORCE] = 0.0;
+      sc[S_RESTART] = 0.0; sc[S_RHAT2] = r0; sc[S_FORCE] = 0.0; sc[S_PENDING3] = 0.0;
       const double t2 = sc[S_RELTOL2] * bb;
       sc[S_TOL2] = t2 > sc[S_ABSTOL2] ? t2 : sc[S_ABSTOL2];
       sc[S_DONE] = (r0 <= sc[S_TOL2]) ? 1.0 : 0.0;
       break;
     }
     case PH_BICG_1:
+      if (sc[S_PENDING3] != 0.0) end_of_iteration(sc);
+      if (sc[S_DONE] != 0.0) break;
       // (r̂, A p) == 0: take a pure minimal-residual half step (alpha = 0) and restart afterwards
       if (r0 == 0.0) { sc[S_ALPHA] = 0.0; sc[S_FORCE] = 1.0; } else sc[S_ALPHA] = sc[S_RHO] / r0;
       break;
@@ -185,10 +201,7 @@ __device__ inline void derive(int phase, double* sc) {
       break;
     }
     case PH_BICG_3:
-      sc[S_RR] = r0;
-      sc[S_ITERS] += 1.0;
-      if (r0 <= sc[S_TOL2]) sc[S_DONE] = 1.0;
-      else if (sc[S_RESTART] != 0.0) { sc[S_RHO] = r0; sc[S_RHAT2] = r0; }
+      if (sc[S_PENDING3] != 0.0) end_of_iteration(sc);
       break;
     case PH_CG_1:
       if (r0 == 0.0) sc[S_DONE] = 2.0; else sc[S_ALPHA] = sc[S_RR] / r0;
@@ -204,13 +217,14 @@ __device__ inline void derive(int phase, double* sc) {
   }
 }
 
-__global__ __launch_bounds__(BLOCK) void k_finalize(int phase, int nslots, int grid, const double* __restrict__ partials,
-                                                    double* __restrict__ sc, int do_derive, int check_done) {
+__global__ __launch_bounds__(BLOCK) void k_finalize(int phase, int slot0, int nslots, int grid,
+                                                    const double* __restrict__ partials, double* __restrict__ sc,
+                                                    int do_derive, int check_done) {
   __shared__ double s_red[BLOCK / 64];
   if (check_done && sc[S_DONE] != 0.0) return;
-  for (int s = 0; s < nslots; ++s) {
+  for (int s = slot0; s < slot0 + nslots; ++s) {
     double a = 0.0;
-    for (int i = threadIdx.x; i < grid; i += BLOCK) a += partials[s * grid + i];
+    for (int i = threadIdx.x; i < grid; i += BLOCK) a += partials[(size_t)s * grid + i];
     const double t = block_sum(a, s_red);
     if (threadIdx.x == 0) sc[S_RED0 + s] = t;
   }
@@ -222,16 +236,16 @@ __global__ void k_derive(int phase, double* sc, int check_done) {
   derive(phase, sc);
 }
 
-void finalize(int phase, int nslots, KrylovWork& w, hipStream_t st, bool check_done) {
+void finalize(int phase, int nslots, KrylovWork& w, hipStream_t st, bool check_done, int slot0 = 0) {
   Context& cx = ctx();
   if (cx.nranks == 1 && !cx.comm) {
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, st, phase, nslots, w.grid, w.partials.p, w.sc.p, 1,
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, st, phase, slot0, nslots, w.grid, w.partials.p, w.sc.p, 1,
                        check_done ? 1 : 0);
   } else {
-    // local sums -> RCCL all-reduce of <=2 doubles over xGMI -> identical scalars on every rank
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, st, phase, nslots, w.grid, w.partials.p, w.sc.p, 0,
+    // local sums -> RCCL all-reduce of <= 5 doubles over xGMI -> identical scalars on every rank
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, st, phase, slot0, nslots, w.grid, w.partials.p, w.sc.p, 0,
                        check_done ? 1 : 0);
-    comm_allreduce_sum_f64(w.sc.p + S_RED0, nslots, st);
+    comm_allreduce_sum_f64(w.sc.p + S_RED0 + slot0, nslots, st);
     hipLaunchKernelGGL(k_derive, dim3(1), dim3(1), 0, st, phase, w.sc.p, check_done ? 1 : 0);
   }
 }
@@ -346,22 +360,21 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
     ++polls;
     for (int it = 0; it < batch; ++it) {
       if (!cg) {
-        halo_exchange(nb, slab, w.p.p, st);
+        if (A.halo_needed) halo_exchange(nb, slab, w.p.p, st);
         timer.begin(st, launched + it);
         launch_spmv(1, A, w.p.p, w.v.p, w.rhat.p, w.partials.p, w.sc.p, G, st);       // v = Â p, (r̂,v)
         timer.end(st);
-        finalize(PH_BICG_1, 1, w, st, true);                                           // α
+        finalize(PH_BICG_1, 2, w, st, true);     // previous iteration's (r,r): convergence / restart; then α
         hipLaunchKernelGGL(k_bicg_s, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p);
-        halo_exchange(nb, slab, w.r.p, st);                                            // r now holds s
+        if (A.halo_needed) halo_exchange(nb, slab, w.r.p, st);                                          // r now holds s
         timer.begin(st, launched + it);
         launch_spmv(3, A, w.r.p, w.t.p, w.rhat.p, w.partials.p, w.sc.p, G, st);       // t = Â s, (t,s), (t,t), (r̂,t)
         timer.end(st);
         finalize(PH_BICG_2, 5, w, st, true);                                           // ω, ρ, β / restart
         hipLaunchKernelGGL(k_bicg_xrp, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.t.p, w.v.p, x, w.r.p, w.p.p, w.rhat.p,
                            w.partials.p);
-        finalize(PH_BICG_3, 1, w, st, true);                                           // (r,r): convergence
       } else {
-        halo_exchange(nb, slab, w.p.p, st);
+        if (A.halo_needed) halo_exchange(nb, slab, w.p.p, st);
         timer.begin(st, launched + it);
         launch_spmv(2, A, w.p.p, w.v.p, nullptr, w.partials.p, w.sc.p, G, st);   // v = A p ; (v.p), (v.v)
         timer.end(st);
@@ -371,6 +384,7 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
         hipLaunchKernelGGL(k_cg_p, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.r.p, w.p.p);
       }
     }
+    if (!cg) finalize(PH_BICG_3, 1, w, st, true, 1);   // the last iteration's (r,r), not yet folded into a next one
     PG_HIP(hipGetLastError());
     launched += batch;
     PG_HIP(hipMemcpyAsync(w.h_sc, w.sc.p, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, st));

@@ -223,6 +223,13 @@ __global__ void k_blk_table(SysParams P, RowSegs seg, i64 Mloc, i64 n_own, const
   }
 }
 
+// number of stored entries that reference a ghost column
+__global__ void k_count_ghost_refs(i64 nnz, i64 n_own, const int* __restrict__ col, unsigned long long* __restrict__ out) {
+  unsigned long long c = 0;
+  for (i64 k = blockIdx.x * (i64)blockDim.x + threadIdx.x; k < nnz; k += (i64)gridDim.x * blockDim.x) c += col[k] >= n_own ? 1 : 0;
+  if (c) atomicAdd(out, c);
+}
+
 __global__ void k_pl_simple(i64 n, const double* __restrict__ ds, const double* __restrict__ in, double* __restrict__ out) {
   for (i64 r = blockIdx.x * (i64)blockDim.x + threadIdx.x; r < n; r += (i64)gridDim.x * blockDim.x) out[r] = ds[r] * in[r];
 }
@@ -271,12 +278,21 @@ void assemble_csr_preconditioned(const SysParams& P, const Slab& s, const Number
   A.rowptr.alloc(n + 1);
   A.ds.alloc(nb.n_vec() > 0 ? nb.n_vec() : 1);
   A.n_blk = 0;
+  A.halo_needed = true;
   RowSegs seg;
   seg.K = nb.K;
   for (int k = 0; k < MAX_KINDS; ++k) seg.off_own[k] = nb.off_own[k];
   if (n == 0) {
     A.rowptr.zero();
     A.nnz = 0;
+    if (ctx().nranks > 1) {   // take part in the collective decision below
+      DevBuf<unsigned long long> nref(1);
+      nref.zero();
+      comm_allreduce_sum_u64(nref.p, 1, st);
+      unsigned long long h = 0;
+      nref.download(&h, 1);
+      A.halo_needed = h != 0;
+    }
     return;
   }
   hipLaunchKernelGGL(k_point_scale, dim3(grid_for((i64)nb.K * nb.Mloc, 256, 256 * 16)), dim3(256), 0, st, P, nb.K, nb.Mloc,
@@ -322,6 +338,19 @@ void assemble_csr_preconditioned(const SysParams& P, const Slab& s, const Number
     PG_HIP(hipGetLastError());
   }
   PG_HIP(hipStreamSynchronize(st));
+  if (ctx().nranks > 1) {
+    DevBuf<unsigned long long> nref(1);
+    nref.zero();
+    hipLaunchKernelGGL(k_count_ghost_refs, dim3(grid_for(nnz, 256, 4096)), dim3(256), 0, st, (i64)nnz, n, A.col.p, nref.p);
+    PG_HIP(hipGetLastError());
+    comm_allreduce_sum_u64(nref.p, 1, st);
+    unsigned long long h = 0;
+    nref.download(&h, 1);
+    A.halo_needed = h != 0;
+    if (getenv("PG_DEBUG"))
+      fprintf(stderr, "[pg_precond] rank %d: %llu ghost-column references over all ranks => halo %s\n", ctx().rank, h,
+              A.halo_needed ? "exchanged" : "skipped");
+  }
   build_spmv_chunks(A);
 }
 

@@ -492,7 +492,7 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
   if (n > 0) {
     if (scheme == PG_SCHEME_CN || warm) {
       hipLaunchKernelGGL(k_scale_state, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, stream, n, A.ds.p, s->x.p, s->z.p, 1);
-      halo_exchange(s->nb, s->slab, s->z.p, stream);
+      if (A.halo_needed) halo_exchange(s->nb, s->slab, s->z.p, stream);
       spmv(A, s->z.p, s->y.p, stream);   // Â S⁻¹ x = S A x : CN right-hand side and/or warm-start residual
     }
     hipLaunchKernelGGL(k_rhs, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, stream, n, scheme, s->x.p, s->y.p, A.ds.p, s->mass.p,

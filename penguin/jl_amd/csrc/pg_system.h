@@ -61,6 +61,9 @@ struct CsrMatrix {
   i64 nslices = 0;
   i64 rows_u = 0, rows_p = 0, rows_g = 0, nnz_p = 0, nnz_g = 0;
   i64 spmv_bytes = 0;        // bytes one launch has to move with this format: records + P/G streams + 16 n (x, y)
+  // false when NO rank's rows reference a ghost column (e.g. one body per slab with fluid away from the slab faces):
+  // the per-SpMV halo exchange is then skipped on every rank (decided collectively at assembly)
+  bool halo_needed = true;
   i64 n_blk = 0;
   i64 nnz_raw = 0;   // entries of the un-preconditioned reduced matrix (what pg_solver_get_system_csr(0/1) returns)
   DevBuf<int> blk_rows, blk_idx;
