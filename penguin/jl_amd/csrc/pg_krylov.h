@@ -30,8 +30,10 @@ void halo_exchange(const Numbering& nb, const Slab& slab, double* vec, hipStream
 void spmv(const CsrMatrix& A, const double* x, double* y, hipStream_t st);
 // x (n_vec, overwritten) = A^{-1} b.  x0 == nullptr: zero initial guess; else start from x0 with Ax0 = A*x0 given
 // (BiCGStab only).  x must not alias x0.
+// preinit (BiCGStab only): the caller has already written x, w.r = w.rhat = w.p = r0 and the partial sums of (r0,r0)
+// / (b,b) in slots 0 / 1 of w.partials with a w.grid-block launch (pg_solver.hip fuses that with the right-hand side).
 void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, const double* b, double* x,
                   KrylovWork& w, const pg_krylov_opts& opts, SolveStats& stats, const double* x0 = nullptr,
-                  const double* Ax0 = nullptr);
+                  const double* Ax0 = nullptr, bool preinit = false);
 
 }  // namespace pg

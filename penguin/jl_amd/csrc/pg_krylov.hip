@@ -316,7 +316,7 @@ void spmv(const CsrMatrix& A, const double* x, double* y, hipStream_t st) {
 }
 
 void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, const double* b, double* x, KrylovWork& w,
-                  const pg_krylov_opts& opts, SolveStats& stats, const double* x0, const double* Ax0) {
+                  const pg_krylov_opts& opts, SolveStats& stats, const double* x0, const double* Ax0, bool preinit) {
   Context& cx = ctx();
   hipStream_t st = cx.stream;
   const i64 n = A.n, nvec = nb.n_vec();
@@ -337,8 +337,10 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
   SpmvTimer timer(cx.profiling);
 
   const bool cg = opts.method == PG_METHOD_CG;
+  PG_REQUIRE(!preinit || !cg, "preinit is a BiCGStab path");
   if (!cg) {
-    hipLaunchKernelGGL(k_bicg_init, dim3(G), dim3(BLOCK), 0, st, n, nvec, b, x0, Ax0, x, w.r.p, w.rhat.p, w.p.p, w.v.p,
+    if (!preinit)
+      hipLaunchKernelGGL(k_bicg_init, dim3(G), dim3(BLOCK), 0, st, n, nvec, b, x0, Ax0, x, w.r.p, w.rhat.p, w.p.p, w.v.p,
                        w.partials.p);
     finalize(PH_INIT, 2, w, st, false);
   } else {

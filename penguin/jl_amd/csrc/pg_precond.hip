@@ -299,7 +299,8 @@ void assemble_csr_preconditioned(const SysParams& P, const Slab& s, const Number
                      nb.red.p, A.ds.p);
   PG_HIP(hipGetLastError());
   DevBuf<int> cnt(n);
-  DevBuf<unsigned char> isblk(n);
+  A.isblk.alloc(n);
+  DevBuf<unsigned char>& isblk = A.isblk;
   DevBuf<unsigned long long> nraw(1);
   nraw.zero();
   const int gr = grid_for(n, 256, 256 * 16);

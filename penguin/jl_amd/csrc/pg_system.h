@@ -68,6 +68,7 @@ struct CsrMatrix {
   i64 nnz_raw = 0;   // entries of the un-preconditioned reduced matrix (what pg_solver_get_system_csr(0/1) returns)
   DevBuf<int> blk_rows, blk_idx;
   DevBuf<double> blk_coef, blk_cn, blk_fw;
+  DevBuf<unsigned char> isblk;   // n: 1 for the rows listed in blk_rows
 };
 constexpr int SPMV_CHUNK_ENTRIES = 508;   // + alignment shift (<= 3) fits the 512-slot LDS slice of a wave
 void build_spmv_chunks(CsrMatrix& A);   // pg_spmv.hip
