@@ -138,7 +138,9 @@ def main() -> None:
     # the kernel in the loop streams the stencil-sliced image of the same matrix: its algorithmic bytes are the
     # bytes of THAT format (records + P/G streams + x and y once) -- pricing it with the CSR figure would credit
     # bytes it never has to move (DESIGN.md "SpMV")
-    b_spmv = int(sysinfo.spmv_bytes) if os.environ.get("PG_SPMV_VARIANT", "70") in ("70", "66") else b_csr
+    # + 8 n: every launch timed in the loop is a fused-dot launch that also reads r-hat (SURVEY's CSR figure leaves the
+    # dot operand out; the CSR number below is kept as SURVEY defines it)
+    b_spmv = int(sysinfo.spmv_bytes) + 8 * n_rows if os.environ.get("PG_SPMV_VARIANT", "70") in ("70", "66") else b_csr
     spmv_ms = run.spmv_ms_total / max(run.spmv_launches, 1)
     achieved = b_spmv / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
     iters = run.total_iters / max(run.steps, 1)
