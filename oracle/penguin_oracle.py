@@ -827,6 +827,33 @@ def solve_DiffusionSteadyDiph(s: Solver, method: str = "\\", **kwargs):
     return s
 
 
+# ---- Darcy: aliases of the diffusion drivers (src/solver/darcy.jl) --------------------
+
+
+def DarcyFlow(phase: Phase, bc_b, bc_i) -> Solver:
+    """src/solver/darcy.jl:1-15."""
+    return DiffusionSteadyMono(phase, bc_b, bc_i)
+
+
+def solve_DarcyFlow(s: Solver, method: str = "\\", **kwargs):
+    """src/solver/darcy.jl:17-24."""
+    solve_DiffusionSteadyMono(s, method=method, **kwargs)
+    s.states.append(s.x)
+    return s
+
+
+def solve_darcy_velocity(solver: Solver, fluide: Phase, state_i: int = 1) -> np.ndarray:
+    """src/solver/darcy.jl:26-41 (state_i 1-based)."""
+    ct = fluide.capacity.cell_types
+    st = np.array(solver.states[state_i - 1], dtype=float)
+    half = st.shape[0] // 2
+    pw, pg = st[:half].copy(), st[half:].copy()
+    pw[ct == 0] = np.nan
+    pg[ct == 0] = np.nan
+    pg[ct == 1] = np.nan
+    return -grad(fluide.operator, np.concatenate([pw, pg]))
+
+
 # ---- unsteady diphasic (config 5) -----------------------------------------------------
 
 

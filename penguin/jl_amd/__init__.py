@@ -7,9 +7,9 @@ call without the shared library or a HIP device raises PenguinHipError.
 """
 from ._lib import PenguinHipError, device_name, finalize, get_unique_id, init, init_distributed, lib  # noqa: F401
 from .api import (  # noqa: F401
-    BorderConditions, Capacity, Circle, DiffusionOps, DiffusionSteadyDiph, DiffusionSteadyMono, DiffusionUnsteadyDiph,
+    BorderConditions, Capacity, Circle, DarcyFlow, DarcyFlowUnsteady, DiffusionOps, DiffusionSteadyDiph, DiffusionSteadyMono, DiffusionUnsteadyDiph,
     DiffusionUnsteadyMono, Dirichlet,
     FluxJump, InterfaceConditions, Mesh, MultiSphere, Neumann, Periodic, Phase, Robin, ScalarJump, Solver, Sphere,
-    check_convergence, div, grad, lp_norm, nC, solve_DiffusionSteadyDiph_b, solve_DiffusionSteadyMono_b,
+    check_convergence, div, grad, lp_norm, nC, solve_DarcyFlow_b, solve_DarcyFlowUnsteady_b, solve_darcy_velocity, solve_DiffusionSteadyDiph_b, solve_DiffusionSteadyMono_b,
     solve_DiffusionUnsteadyDiph_b, solve_DiffusionUnsteadyMono_b,
 )

@@ -975,6 +975,49 @@ def solve_DiffusionSteadyDiph_b(s: Solver, method="bicgstab", algorithm=None, ve
                          verbose)
 
 
+# =============================================================================== Darcy (src/solver/darcy.jl: aliases)
+
+
+def DarcyFlow(phase: Phase, bc_b: BorderConditions, bc_i, verbose: bool = False) -> Solver:
+    """DarcyFlow(phase, bc_b, bc_i) -- src/solver/darcy.jl:1-15: the steady monophasic diffusion system."""
+    if verbose:
+        print("Solver Creation:\n- Darcy Flow\n- Steady problem\n- Monophasic")
+    return DiffusionSteadyMono(phase, bc_b, bc_i)
+
+
+def solve_DarcyFlow_b(s: Solver, method="bicgstab", algorithm=None, **kwargs):
+    """solve_DarcyFlow!(s; ...) -- src/solver/darcy.jl:17-24 (solve_system! + push!(s.states, s.x))."""
+    _solve_steady(s, method, kwargs, "", False)
+    s.states.append(s.x)
+    return s
+
+
+def solve_darcy_velocity(solver: Solver, Fluide: Phase, state_i: int = 1) -> np.ndarray:
+    """solve_darcy_velocity(solver, Fluide; state_i=1) -- src/solver/darcy.jl:26-41: u = -∇(op, p) with p masked to NaN
+    outside the fluid (pω where cell_types == 0; pγ where cell_types is 0 or 1).  state_i is 1-based as in Julia."""
+    ct = Fluide.capacity.cell_types
+    st = np.array(solver.states[state_i - 1], dtype=np.float64)
+    half = st.shape[0] // 2
+    pw, pg = st[:half].copy(), st[half:].copy()
+    pw[ct == 0] = np.nan
+    pg[ct == 0] = np.nan
+    pg[ct == 1] = np.nan
+    return -grad(Fluide.operator, np.concatenate([pw, pg]))
+
+
+def DarcyFlowUnsteady(phase: Phase, bc_b: BorderConditions, bc_i, Δt: float, Tᵢ: np.ndarray, scheme: str,
+                      verbose: bool = False) -> Solver:
+    """DarcyFlowUnsteady(...) -- src/solver/darcy.jl:46-58: the unsteady monophasic diffusion system."""
+    return DiffusionUnsteadyMono(phase, bc_b, bc_i, Δt, Tᵢ, scheme, verbose=verbose)
+
+
+def solve_DarcyFlowUnsteady_b(s: Solver, phase: Phase, Δt: float, Tₑ: float, bc_b: BorderConditions, bc_i, scheme: str,
+                              method="bicgstab", algorithm=None, **kwargs):
+    """solve_DarcyFlowUnsteady!(...) -- src/solver/darcy.jl:60-91: the loop of solve_DiffusionUnsteadyMono! with the
+    matrix rebuilt every step (same matrix: constant data)."""
+    return solve_DiffusionUnsteadyMono_b(s, phase, Δt, Tₑ, bc_b, bc_i, scheme, method=method, algorithm=algorithm, **kwargs)
+
+
 # =============================================================================== convergence metric
 
 

@@ -227,3 +227,36 @@ def test_steady_diphasic_known_answer():
     M = (n + 1) ** 2
     pin = GOLD["known_answers"]["steady_diph_80x80_max_u1o"]
     assert s.x[:M].max() == pytest.approx(pin["value"], abs=pin["atol"])
+
+
+# ---------------------------------------------------------------- test/solver/darcy_test.jl (aliases of the diffusion drivers)
+def _darcy_setup():
+    n = 20
+    mesh = po.Mesh((n, n), (2.0, 2.0), (0.0, 0.0))
+    cap = po.make_capacity(Ball((0.5, 0.5), 0.5), mesh)
+    op = po.make_diffusion_ops(cap)
+    bcb = po.BorderConditions({"left": po.Dirichlet(10.0), "right": po.Dirichlet(20.0)})
+    return n, mesh, cap, op, bcb
+
+
+def test_darcy_known_answers():
+    n, mesh, cap, op, bcb = _darcy_setup()
+    ph = po.Phase(cap, op, lambda x, y, z=0.0: 0.0, lambda x, y, z=0.0: 1.0)
+    s = po.DarcyFlow(ph, bcb, po.Neumann(0.0))
+    po.solve_DarcyFlow(s, method="\\")
+    M = (n + 1) ** 2
+    pin = GOLD["known_answers"]["darcy_20x20_max_uo"]
+    assert s.x[:M].max() == pytest.approx(pin["value"], abs=pin["atol"])
+    u = po.solve_darcy_velocity(s, ph)
+    assert np.nanmax(np.abs(u)) < GOLD["known_answers"]["darcy_velocity_max_abs"]["lt"]
+
+
+def test_darcy_unsteady_known_answer():
+    n, mesh, cap, op, bcb = _darcy_setup()
+    ph = po.Phase(cap, op, lambda x, y, z, t: 0.0, lambda x, y, z=0.0: 1.0)
+    M = (n + 1) ** 2
+    dt = 0.1 * (2.0 / n) ** 2
+    s = po.DiffusionUnsteadyMono(ph, bcb, po.Neumann(0.0), dt, np.full(2 * M, 10.0), "BE")   # DarcyFlowUnsteady (:46-58)
+    po.solve_DiffusionUnsteadyMono(s, ph, dt, 0.2, bcb, po.Neumann(0.0), "BE", method="\\")
+    pin = GOLD["known_answers"]["darcy_unsteady_20x20_max_uo"]
+    assert s.states[-1][:M].max() == pytest.approx(pin["value"], abs=pin["atol"])
