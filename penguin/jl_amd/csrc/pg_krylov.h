@@ -11,6 +11,7 @@ struct KrylovWork {
   DevBuf<double> sc;                    // device scalars (see pg_krylov.hip)
   double* h_sc = nullptr;               // pinned host mirror of sc
   int grid = 1;
+  DevBuf<unsigned> ticket;              // arrival counter of the in-launch scalar phases (pg_spmv.h)
   int last_iters = 0;                   // iterations of the previous solve (sizes the first launch batch)
   void init(i64 n_own, i64 n_vec);
   ~KrylovWork();

@@ -20,7 +20,6 @@ using namespace pg;
 
 namespace {
 
-enum { PH_INIT = 0, PH_BICG_1, PH_BICG_2, PH_BICG_3, PH_CG_INIT, PH_CG_1, PH_CG_2 };
 
 // ---- fused vector kernels ---------------------------------------------------------------------------
 // x0 == nullptr: zero initial guess (IterativeSolvers' default).  Otherwise x = x0 and r = b - Ax0 (warm start with
@@ -144,79 +143,7 @@ __global__ __launch_bounds__(BLOCK) void k_cg_p(i64 n, const double* __restrict_
   for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) p[i] = r[i] + beta * p[i];
 }
 
-// ---- scalar phase: sum block partials (deterministic order), then derive the iteration scalars ----
-// end of a BiCGStab iteration: (r,r) -> convergence, restart bookkeeping.  Its reduction rides with the next
-// iteration's (r̂,v) (PH_BICG_1) -- one scalar kernel and, with several ranks, one all-reduce less per iteration --
-// or stands alone before the host polls (PH_BICG_3).
-__device__ inline void end_of_iteration(double* sc) {
-  const double rr = sc[S_RED1];
-  sc[S_PENDING3] = 0.0;
-  sc[S_RR] = rr;
-  sc[S_ITERS] += 1.0;
-  if (rr <= sc[S_TOL2]) sc[S_DONE] = 1.0;
-  else if (sc[S_RESTART] != 0.0) { sc[S_RHO] = rr; sc[S_RHAT2] = rr; }
-}
-
-__device__ inline void derive(int phase, double* sc) {
-  const double r0 = sc[S_RED0], r1 = sc[S_RED1];
-  switch (phase) {
-    case PH_INIT:
-    case PH_CG_INIT: {
-      const double bb = phase == PH_INIT ? r1 : r0;   // BiCGStab init also reduces b.b (warm start: r0 != b)
-      sc[S_BB] = bb; sc[S_RR] = r0; sc[S_RHO] = r0; sc[S_RHO_OLD] = 1.0;
-      sc[S_ALPHA] = 1.0; sc[S_OMEGA] = 1.0; sc[S_BETA] = 0.0; sc[S_ITERS] = 0.0;
-      sc[S_RESTART] = 0.0; sc[S_RHAT2] = r0; sc[S_FORCE] = 0.0; sc[S_PENDING3] = 0.0;
-      const double t2 = sc[S_RELTOL2] * bb;
-      sc[S_TOL2] = t2 > sc[S_ABSTOL2] ? t2 : sc[S_ABSTOL2];
-      sc[S_DONE] = (r0 <= sc[S_TOL2]) ? 1.0 : 0.0;
-      break;
-    }
-    case PH_BICG_1:
-      if (sc[S_PENDING3] != 0.0) end_of_iteration(sc);
-      if (sc[S_DONE] != 0.0) break;
-      // (r̂, A p) == 0: take a pure minimal-residual half step (alpha = 0) and restart afterwards
-      if (r0 == 0.0) { sc[S_ALPHA] = 0.0; sc[S_FORCE] = 1.0; } else sc[S_ALPHA] = sc[S_RHO] / r0;
-      break;
-    case PH_BICG_2: {
-      // r0 = (t,s), r1 = (t,t), RED2 = (r̂,s), RED3 = (s,s), RED4 = (r̂,t)
-      const double ts = r0, tt = r1, rs = sc[S_RED2], ss = sc[S_RED3], rt = sc[S_RED4];
-      const double omega = tt != 0.0 ? ts / tt : 0.0;
-      const double rho_old = sc[S_RHO], rho_new = rs - omega * rt;
-      double rr_pred = ss - 2.0 * omega * ts + omega * omega * tt;   // (r,r) of the coming update, restart test only
-      rr_pred = rr_pred > 0.0 ? rr_pred : 0.0;
-      sc[S_OMEGA] = omega;
-      sc[S_RHO_OLD] = rho_old;
-      sc[S_RHO] = rho_new;
-      if (omega == 0.0 || sc[S_FORCE] != 0.0 || rho_new * rho_new < 1e-20 * sc[S_RHAT2] * rr_pred) {
-        // (r̂,r) collapsed -- r̂ = b is often supported on a few identity rows (T⁰ = 0) and r leaves that
-        // support: restart with r̂ := r (the remedy Eigen's BiCGSTAB uses, with a relative threshold:
-        // cos(r̂,r) < 1e-10).  k_bicg_xrp copies r into r̂ and p; PH_BICG_3 sets ρ = (r,r).
-        sc[S_FORCE] = 0.0;
-        sc[S_RESTART] = 1.0;
-        sc[S_BETA] = 0.0;
-      } else {
-        sc[S_RESTART] = 0.0;
-        sc[S_BETA] = (rho_new / rho_old) * (sc[S_ALPHA] / omega);
-      }
-      break;
-    }
-    case PH_BICG_3:
-      if (sc[S_PENDING3] != 0.0) end_of_iteration(sc);
-      break;
-    case PH_CG_1:
-      if (r0 == 0.0) sc[S_DONE] = 2.0; else sc[S_ALPHA] = sc[S_RR] / r0;
-      break;
-    case PH_CG_2: {
-      const double rr_old = sc[S_RR];
-      sc[S_RR] = r0;
-      sc[S_ITERS] += 1.0;
-      if (r0 <= sc[S_TOL2]) sc[S_DONE] = 1.0;
-      else sc[S_BETA] = r0 / rr_old;
-      break;
-    }
-  }
-}
-
+// ---- scalar phase: sum block partials (deterministic order), then derive the iteration scalars (pg_spmv.h) ----
 __global__ __launch_bounds__(BLOCK) void k_finalize(int phase, int slot0, int nslots, int grid,
                                                     const double* __restrict__ partials, double* __restrict__ sc,
                                                     int do_derive, int check_done) {
@@ -234,6 +161,14 @@ __global__ __launch_bounds__(BLOCK) void k_finalize(int phase, int slot0, int ns
 __global__ void k_derive(int phase, double* sc, int check_done) {
   if (check_done && sc[S_DONE] != 0.0) return;
   derive(phase, sc);
+}
+
+// after a launch whose last block already summed (and, on one rank, derived) the phase: only what is left to do
+void finalize_folded(int phase, int nslots, KrylovWork& w, hipStream_t st) {
+  Context& cx = ctx();
+  if (cx.nranks == 1 && !cx.comm) return;
+  comm_allreduce_sum_f64(w.sc.p + S_RED0, nslots, st);
+  hipLaunchKernelGGL(k_derive, dim3(1), dim3(1), 0, st, phase, w.sc.p, 1);
 }
 
 void finalize(int phase, int nslots, KrylovWork& w, hipStream_t st, bool check_done, int slot0 = 0) {
@@ -302,6 +237,8 @@ void KrylovWork::init(i64 n_own, i64 n_vec) {
   partials.alloc(5 * (i64)grid);
   sc.alloc(S_COUNT);
   sc.zero();
+  ticket.alloc(1);
+  ticket.zero();
   if (!h_sc) PG_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_sc), sizeof(double) * S_COUNT));
 }
 
@@ -364,15 +301,20 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
       if (!cg) {
         if (A.halo_needed) halo_exchange(nb, slab, w.p.p, st);
         timer.begin(st, launched + it);
-        launch_spmv(1, A, w.p.p, w.v.p, w.rhat.p, w.partials.p, w.sc.p, G, st);       // v = Â p, (r̂,v)
+        // the scalar phase that follows an SpMV is evaluated by the last block of that launch (stencil-slice kernel)
+        const int derive_here = (cx.nranks == 1 && !cx.comm) ? 1 : 0;
+        const FinArgs f1{w.ticket.p, w.sc.p, PH_BICG_1, 2, derive_here};
+        const bool folded1 = launch_spmv(1, A, w.p.p, w.v.p, w.rhat.p, w.partials.p, w.sc.p, G, st, &f1);   // v = Â p, (r̂,v)
         timer.end(st);
-        finalize(PH_BICG_1, 2, w, st, true);     // previous iteration's (r,r): convergence / restart; then α
+        // previous iteration's (r,r): convergence / restart; then α
+        if (folded1) finalize_folded(PH_BICG_1, 2, w, st); else finalize(PH_BICG_1, 2, w, st, true);
         hipLaunchKernelGGL(k_bicg_s, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p);
         if (A.halo_needed) halo_exchange(nb, slab, w.r.p, st);                                          // r now holds s
         timer.begin(st, launched + it);
-        launch_spmv(3, A, w.r.p, w.t.p, w.rhat.p, w.partials.p, w.sc.p, G, st);       // t = Â s, (t,s), (t,t), (r̂,t)
+        const FinArgs f2{w.ticket.p, w.sc.p, PH_BICG_2, 5, derive_here};
+        const bool folded2 = launch_spmv(3, A, w.r.p, w.t.p, w.rhat.p, w.partials.p, w.sc.p, G, st, &f2);   // t = Â s, (t,s), (t,t), (r̂,t)
         timer.end(st);
-        finalize(PH_BICG_2, 5, w, st, true);                                           // ω, ρ, β / restart
+        if (folded2) finalize_folded(PH_BICG_2, 5, w, st); else finalize(PH_BICG_2, 5, w, st, true);   // ω, ρ, β / restart
         hipLaunchKernelGGL(k_bicg_xrp, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.t.p, w.v.p, x, w.r.p, w.p.p, w.rhat.p,
                            w.partials.p);
       } else {

@@ -32,11 +32,143 @@ __device__ inline double block_sum(double v, double* sh /*BLOCK/64*/) {
   return s;
 }
 
+// ---- scalar phases of the Krylov drivers (shared: evaluated by k_finalize / k_derive or by the LAST block of the
+// producing SpMV launch, see last_block_arrives) ------------------------------------------------------------------
+enum { PH_NONE = -1, PH_INIT = 0, PH_BICG_1, PH_BICG_2, PH_BICG_3, PH_CG_INIT, PH_CG_1, PH_CG_2 };
+
+// end of a BiCGStab iteration: (r,r) -> convergence, restart bookkeeping.  Its reduction rides with the next
+// iteration's (r̂,v) (PH_BICG_1) -- one scalar kernel and, with several ranks, one all-reduce less per iteration --
+// or stands alone before the host polls (PH_BICG_3).
+__device__ inline void end_of_iteration(double* sc) {
+  const double rr = sc[S_RED1];
+  sc[S_PENDING3] = 0.0;
+  sc[S_RR] = rr;
+  sc[S_ITERS] += 1.0;
+  if (rr <= sc[S_TOL2]) sc[S_DONE] = 1.0;
+  else if (sc[S_RESTART] != 0.0) { sc[S_RHO] = rr; sc[S_RHAT2] = rr; }
+}
+
+__device__ inline void derive(int phase, double* sc) {
+  const double r0 = sc[S_RED0], r1 = sc[S_RED1];
+  switch (phase) {
+    case PH_INIT:
+    case PH_CG_INIT: {
+      const double bb = phase == PH_INIT ? r1 : r0;   // BiCGStab init also reduces b.b (warm start: r0 != b)
+      sc[S_BB] = bb; sc[S_RR] = r0; sc[S_RHO] = r0; sc[S_RHO_OLD] = 1.0;
+      sc[S_ALPHA] = 1.0; sc[S_OMEGA] = 1.0; sc[S_BETA] = 0.0; sc[S_ITERS] = 0.0;
+      sc[S_RESTART] = 0.0; sc[S_RHAT2] = r0; sc[S_FORCE] = 0.0; sc[S_PENDING3] = 0.0;
+      const double t2 = sc[S_RELTOL2] * bb;
+      sc[S_TOL2] = t2 > sc[S_ABSTOL2] ? t2 : sc[S_ABSTOL2];
+      sc[S_DONE] = (r0 <= sc[S_TOL2]) ? 1.0 : 0.0;
+      break;
+    }
+    case PH_BICG_1:
+      if (sc[S_PENDING3] != 0.0) end_of_iteration(sc);
+      if (sc[S_DONE] != 0.0) break;
+      // (r̂, A p) == 0: take a pure minimal-residual half step (alpha = 0) and restart afterwards
+      if (r0 == 0.0) { sc[S_ALPHA] = 0.0; sc[S_FORCE] = 1.0; } else sc[S_ALPHA] = sc[S_RHO] / r0;
+      break;
+    case PH_BICG_2: {
+      // r0 = (t,s), r1 = (t,t), RED2 = (r̂,s), RED3 = (s,s), RED4 = (r̂,t)
+      const double ts = r0, tt = r1, rs = sc[S_RED2], ss = sc[S_RED3], rt = sc[S_RED4];
+      const double omega = tt != 0.0 ? ts / tt : 0.0;
+      const double rho_old = sc[S_RHO], rho_new = rs - omega * rt;
+      double rr_pred = ss - 2.0 * omega * ts + omega * omega * tt;   // (r,r) of the coming update, restart test only
+      rr_pred = rr_pred > 0.0 ? rr_pred : 0.0;
+      sc[S_OMEGA] = omega;
+      sc[S_RHO_OLD] = rho_old;
+      sc[S_RHO] = rho_new;
+      if (omega == 0.0 || sc[S_FORCE] != 0.0 || rho_new * rho_new < 1e-20 * sc[S_RHAT2] * rr_pred) {
+        // (r̂,r) collapsed -- r̂ = b is often supported on a few identity rows (T⁰ = 0) and r leaves that
+        // support: restart with r̂ := r (the remedy Eigen's BiCGSTAB uses, with a relative threshold:
+        // cos(r̂,r) < 1e-10).  k_bicg_xrp copies r into r̂ and p; PH_BICG_3 sets ρ = (r,r).
+        sc[S_FORCE] = 0.0;
+        sc[S_RESTART] = 1.0;
+        sc[S_BETA] = 0.0;
+      } else {
+        sc[S_RESTART] = 0.0;
+        sc[S_BETA] = (rho_new / rho_old) * (sc[S_ALPHA] / omega);
+      }
+      break;
+    }
+    case PH_BICG_3:
+      if (sc[S_PENDING3] != 0.0) end_of_iteration(sc);
+      break;
+    case PH_CG_1:
+      if (r0 == 0.0) sc[S_DONE] = 2.0; else sc[S_ALPHA] = sc[S_RR] / r0;
+      break;
+    case PH_CG_2: {
+      const double rr_old = sc[S_RR];
+      sc[S_RR] = r0;
+      sc[S_ITERS] += 1.0;
+      if (r0 <= sc[S_TOL2]) sc[S_DONE] = 1.0;
+      else sc[S_BETA] = r0 / rr_old;
+      break;
+    }
+  }
+}
+
+
+// In-launch hand-off to the last-arriving block (cdna_hip_programming.md "In-launch split-K reduction", the write-through
+// form): a block stores its few partials with agent-scope (sc1, write-through) stores -- no release fence, which would
+// write back the XCD's whole dirty L2 (the y vector) once per block: measured +45 us per launch -- all its waves drain
+// their stores, one lane draws a ticket; the block that draws the last ticket reads every block's partials with
+// agent-scope loads.  Correct for any placement of the blocks over XCDs.  The ticket word is reset by the last arriver
+// (it is zeroed once at allocation; launches that return at the done flag never touch it).  Returns the same value in
+// every thread of the block.
+__device__ inline void store_partial(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline double load_partial(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT));
+}
+
+__device__ inline bool last_block_arrives(unsigned* ticket, unsigned nblocks, double* sh /* >= 1 double of LDS */) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = t == nblocks - 1;
+    if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sh[0] = last ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  const bool last = sh[0] != 0.0;
+  __syncthreads();   // sh is reused by the block sums that follow
+  return last;
+}
+
+// scalar phase folded into the producing launch: what to reduce and derive once the last block has arrived
+struct FinArgs {
+  unsigned* ticket;   // nullptr: no in-launch phase
+  double* sc;         // scalar block (read-write)
+  int phase;          // PH_*
+  int nslots;         // partial slots [0, nslots) to sum into S_RED0..
+  int do_derive;      // 0: sums only (several ranks: an all-reduce follows)
+};
+
+// executed by every block at the end of a producing launch (after its partials are stored)
+__device__ inline void fold_scalar_phase(const FinArgs& fin, const double* __restrict__ partials, double* s_red) {
+  if (!fin.ticket) return;
+  if (!last_block_arrives(fin.ticket, gridDim.x, s_red)) return;
+  for (int sl = 0; sl < fin.nslots; ++sl) {
+    double a = 0.0;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += BLOCK) a += load_partial(partials + (size_t)sl * gridDim.x + i);
+    const double t = block_sum(a, s_red);
+    if (threadIdx.x == 0) fin.sc[S_RED0 + sl] = t;
+  }
+  if (threadIdx.x == 0 && fin.do_derive) derive(fin.phase, fin.sc);
+}
+
 // y = A x on rows [0, A.n).  mode 0: plain; 1: partials[0..grid) = aux . y; 2: partials[0..grid) = y . x and
 // partials[grid..2grid) = y . y; 3: mode 2 plus partials[4grid..5grid) = aux . y.  `sc` (may be NULL): kernels return immediately when sc[S_DONE] != 0.
 // `grid` must be the value used to size `partials` (KrylovWork::grid) for modes 1/2.
-void launch_spmv(int mode, const CsrMatrix& A, const double* x, double* y, const double* aux, double* partials,
-                 const double* sc, int grid, hipStream_t st);
+// `fin` (optional): scalar phase evaluated by the last block of the launch; returns true when the launched kernel
+// does that (the stencil-slice kernel), false when the caller still has to launch the scalar kernel itself.
+bool launch_spmv(int mode, const CsrMatrix& A, const double* x, double* y, const double* aux, double* partials,
+                 const double* sc, int grid, hipStream_t st, const FinArgs* fin = nullptr);
 // plain y = A x with an explicit kernel variant (PG_SPMV_VARIANT numbering): kernel-vs-kernel parity checks
 void launch_spmv_variant(int variant, const CsrMatrix& A, const double* x, double* y, hipStream_t st);
 int spmv_default_grid(i64 n);

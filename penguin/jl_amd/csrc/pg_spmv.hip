@@ -526,7 +526,8 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_s(i64 nslices, const int* __rest
                                                   const int* __restrict__ g_rowptr, const int* __restrict__ g_col,
                                                   const double* __restrict__ g_val, const double* __restrict__ x,
                                                   double* __restrict__ y, const double* __restrict__ aux,
-                                                  double* __restrict__ partials, const double* __restrict__ sc, int xcd) {
+                                                  double* __restrict__ partials, const double* __restrict__ sc, int xcd,
+                                                  FinArgs fin) {
   __shared__ __attribute__((aligned(16))) double s_val[BLOCK / 64][512];
   __shared__ __attribute__((aligned(16))) int s_col[BLOCK / 64][512];
   __shared__ double s_red[BLOCK / 64];
@@ -622,18 +623,20 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_s(i64 nslices, const int* __rest
     }
     rec = rec_n;
   }
+  // (write-through stores: the last block of this launch may read them, see fold_scalar_phase)
   if (MODE >= 1) {
     const double t0 = block_sum(acc0, s_red);
-    if (threadIdx.x == 0) partials[blockIdx.x] = t0;
+    if (threadIdx.x == 0) store_partial(partials + blockIdx.x, t0);
   }
   if (MODE >= 2) {
     const double t1 = block_sum(acc1, s_red);
-    if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = t1;
+    if (threadIdx.x == 0) store_partial(partials + gridDim.x + blockIdx.x, t1);
   }
   if (MODE == 3) {
     const double t2 = block_sum(acc2, s_red);
-    if (threadIdx.x == 0) partials[4 * (size_t)gridDim.x + blockIdx.x] = t2;
+    if (threadIdx.x == 0) store_partial(partials + 4 * (size_t)gridDim.x + blockIdx.x, t2);
   }
+  if (MODE >= 1) fold_scalar_phase(fin, partials, s_red);
 }
 
 // flags[r]: bit 0 = row r has the count and (col - row) offsets of row r-1, bit 1 = and bitwise the same values
@@ -717,21 +720,23 @@ int xcd_map() {
                      A.rowptr.p, A.col.p, A.val.p, x, y, aux, partials, sc)
 
 template <int MODE>
-void launch_mode(int v, const CsrMatrix& A, const double* x, double* y, const double* aux, double* partials,
-                 const double* sc, int grid, hipStream_t st) {
+bool launch_mode(int v, const CsrMatrix& A, const double* x, double* y, const double* aux, double* partials,
+                 const double* sc, int grid, hipStream_t st, const FinArgs* fin) {
   if (v & 64) {
+    FinArgs fa{nullptr, nullptr, PH_NONE, 0, 0};
+    if (fin && MODE >= 1) fa = *fin;
     if (v & 4)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_s<MODE, true>), dim3(grid), dim3(BLOCK), 0, st, A.nslices, A.srec.p, A.pval.p,
-                         A.g_rowid.p, A.g_rowptr.p, A.g_col.p, A.g_val.p, x, y, aux, partials, sc, xcd_map());
+                         A.g_rowid.p, A.g_rowptr.p, A.g_col.p, A.g_val.p, x, y, aux, partials, sc, xcd_map(), fa);
     else
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_s<MODE, false>), dim3(grid), dim3(BLOCK), 0, st, A.nslices, A.srec.p, A.pval.p,
-                         A.g_rowid.p, A.g_rowptr.p, A.g_col.p, A.g_val.p, x, y, aux, partials, sc, xcd_map());
-    return;
+                         A.g_rowid.p, A.g_rowptr.p, A.g_col.p, A.g_val.p, x, y, aux, partials, sc, xcd_map(), fa);
+    return fa.ticket != nullptr;
   }
   if (v == 1) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv<MODE>), dim3(grid), dim3(BLOCK), 0, st, A.n, A.rowptr.p, A.col.p, A.val.p, x, y,
                        aux, partials, sc);
-    return;
+    return false;
   }
   const bool nt = (v & 4) != 0, pipe = (v & 16) != 0;
   if (v & 32) {
@@ -739,12 +744,13 @@ void launch_mode(int v, const CsrMatrix& A, const double* x, double* y, const do
     else if (nt) PG_LAUNCH_C((k_spmv_cw<MODE, true, false>));
     else if (pipe) PG_LAUNCH_C((k_spmv_cw<MODE, false, true>));
     else PG_LAUNCH_C((k_spmv_cw<MODE, false, false>));
-    return;
+    return false;
   }
   if (nt && pipe) PG_LAUNCH_C((k_spmv_c<MODE, true, true>));
   else if (nt) PG_LAUNCH_C((k_spmv_c<MODE, true, false>));
   else if (pipe) PG_LAUNCH_C((k_spmv_c<MODE, false, true>));
   else PG_LAUNCH_C((k_spmv_c<MODE, false, false>));
+  return false;
 }
 
 }  // namespace
@@ -919,19 +925,19 @@ int spmv_default_grid(i64 n) {
   return grid_for(n, BLOCK, cus * per_cu);
 }
 
-void launch_spmv(int mode, const CsrMatrix& A, const double* x, double* y, const double* aux, double* partials,
-                 const double* sc, int grid, hipStream_t st) {
-  if (A.n == 0) return;
+bool launch_spmv(int mode, const CsrMatrix& A, const double* x, double* y, const double* aux, double* partials,
+                 const double* sc, int grid, hipStream_t st, const FinArgs* fin) {
+  if (A.n == 0) return false;
   const int v = variant();
-  if (mode == 0) launch_mode<0>(v, A, x, y, aux, partials, sc, grid, st);
-  else if (mode == 1) launch_mode<1>(v, A, x, y, aux, partials, sc, grid, st);
-  else if (mode == 2) launch_mode<2>(v, A, x, y, aux, partials, sc, grid, st);
-  else launch_mode<3>(v, A, x, y, aux, partials, sc, grid, st);
+  if (mode == 0) return launch_mode<0>(v, A, x, y, aux, partials, sc, grid, st, fin);
+  if (mode == 1) return launch_mode<1>(v, A, x, y, aux, partials, sc, grid, st, fin);
+  if (mode == 2) return launch_mode<2>(v, A, x, y, aux, partials, sc, grid, st, fin);
+  return launch_mode<3>(v, A, x, y, aux, partials, sc, grid, st, fin);
 }
 
 void launch_spmv_variant(int v, const CsrMatrix& A, const double* x, double* y, hipStream_t st) {
   if (A.n == 0) return;
-  launch_mode<0>(v, A, x, y, nullptr, nullptr, nullptr, spmv_default_grid(A.n), st);
+  launch_mode<0>(v, A, x, y, nullptr, nullptr, nullptr, spmv_default_grid(A.n), st, nullptr);
 }
 
 }  // namespace pg
