@@ -748,3 +748,27 @@ def test_darcy_reference_tests(pj):
     assert len(su.states) == len(suo.states)
     assert rel_l2(su.states[-1], suo.states[-1]) <= TOL_T
     assert su.states[-1][:M].max() == pytest.approx(20.0, abs=1e-2)
+
+
+# ------------------------------------------------------------------------------------ determinism
+def test_time_loop_is_bitwise_reproducible(pj):
+    """Same problem three times: identical iteration counts and bitwise identical states.  Every reduction is summed in a
+    fixed order (per-block partials, then one block), also the scalar phases folded into the SpMV launches (last-arriving
+    block, write-through partials): a stale or reordered read there would show up as run-to-run differences."""
+    import ctypes as C
+    from penguin.jl_amd import _lib as L
+    n = 64
+    mesh = pj.Mesh((n, n, n), (4.0, 4.0, 4.0))
+    cap = pj.Capacity(pj.Sphere((2.01, 2.01, 2.01), 1.0), mesh)
+    bcb = pj.BorderConditions({k: pj.Dirichlet(1.0) for k in HEAT_BORDERS})
+    dt = 0.75 * (4.0 / n) ** 2
+    runs = []
+    for _ in range(3):
+        s = pj.DiffusionUnsteadyMono(pj.Phase(cap, pj.DiffusionOps(cap), 0.0, 1.0), bcb, pj.Dirichlet(1.0), dt, None, "BE")
+        opts = L.pg_krylov_opts(L.PG_METHOD["bicgstab"], 1e-12, 0.0, 0, 4, 1)
+        run = L.pg_run_info()
+        L.check(L.lib().pg_solver_run(s._h, C.c_double(1e30), C.c_int32(L.PG_SCHEME["CN"]), C.byref(opts), C.c_int32(1),
+                                      C.c_int64(25), C.c_int32(0), C.byref(run)))
+        runs.append((int(run.total_iters), s._fetch_state().copy()))
+    assert runs[0][0] == runs[1][0] == runs[2][0] > 0
+    assert np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][1], runs[2][1])
