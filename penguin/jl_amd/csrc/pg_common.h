@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -121,6 +122,33 @@ struct DevBuf {
       PG_HIP(hipMemcpyAsync(h, p + offset, sizeof(T) * static_cast<size_t>(count), hipMemcpyDeviceToHost, ctx().stream));
       PG_HIP(hipStreamSynchronize(ctx().stream));
     }
+  }
+};
+
+// grow-only pinned host staging buffers (two slots): device -> host copies of tens of MB run at PCIe speed instead of
+// the pageable-memory rate; allocating pinned memory per call would cost more than it saves
+inline void* pinned_scratch(int slot, size_t bytes) {
+  static thread_local void* buf[2] = {nullptr, nullptr};
+  static thread_local size_t cap[2] = {0, 0};
+  if (bytes > cap[slot]) {
+    if (buf[slot]) (void)hipHostFree(buf[slot]);
+    PG_HIP(hipHostMalloc(&buf[slot], bytes + (bytes >> 2)));
+    cap[slot] = bytes + (bytes >> 2);
+  }
+  return buf[slot];
+}
+
+// PG_DEBUG=1: wall-clock laps of the set-up phases on stderr (device synchronised at each lap)
+struct Laps {
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  explicit Laps() : on(getenv("PG_DEBUG") != nullptr), t0(std::chrono::steady_clock::now()) {}
+  void lap(const char* what) {
+    if (!on) return;
+    (void)hipDeviceSynchronize();
+    const auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[pg_laps] %-34s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
   }
 };
 

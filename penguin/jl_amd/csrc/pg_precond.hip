@@ -271,8 +271,10 @@ __global__ void k_point_scale(SysParams P, int K, i64 Mloc, const int* red, doub
 
 namespace pg {
 
-void assemble_csr_preconditioned(const SysParams& P, const Slab& s, const Numbering& nb, CsrMatrix& A) {
+void assemble_csr_preconditioned(const SysParams& P, const Slab& s, const Numbering& nb, CsrMatrix& A,
+                                 const bool* inherit_halo) {
   hipStream_t st = ctx().stream;
+  Laps laps;
   const i64 n = nb.n_own;
   A.n = n;
   A.rowptr.alloc(n + 1);
@@ -285,7 +287,8 @@ void assemble_csr_preconditioned(const SysParams& P, const Slab& s, const Number
   if (n == 0) {
     A.rowptr.zero();
     A.nnz = 0;
-    if (ctx().nranks > 1) {   // take part in the collective decision below
+    if (inherit_halo) A.halo_needed = *inherit_halo;
+    else if (ctx().nranks > 1) {   // take part in the collective decision below
       DevBuf<unsigned long long> nref(1);
       nref.zero();
       comm_allreduce_sum_u64(nref.p, 1, st);
@@ -339,7 +342,8 @@ void assemble_csr_preconditioned(const SysParams& P, const Slab& s, const Number
     PG_HIP(hipGetLastError());
   }
   PG_HIP(hipStreamSynchronize(st));
-  if (ctx().nranks > 1) {
+  if (inherit_halo) A.halo_needed = *inherit_halo;
+  else if (ctx().nranks > 1) {
     DevBuf<unsigned long long> nref(1);
     nref.zero();
     hipLaunchKernelGGL(k_count_ghost_refs, dim3(grid_for(nnz, 256, 4096)), dim3(256), 0, st, (i64)nnz, n, A.col.p, nref.p);
@@ -352,7 +356,83 @@ void assemble_csr_preconditioned(const SysParams& P, const Slab& s, const Number
       fprintf(stderr, "[pg_precond] rank %d: %llu ghost-column references over all ranks => halo %s\n", ctx().rank, h,
               A.halo_needed ? "exchanged" : "skipped");
   }
+  laps.lap("  asm: count/fill/table kernels");
   build_spmv_chunks(A);
+  laps.lap("  asm: SpMV chunks + slices");
+}
+
+__global__ void k_structure_differs(i64 n, const int* __restrict__ cnt, const int* __restrict__ rowptr,
+                                    const unsigned char* __restrict__ blk_a, const unsigned char* __restrict__ blk_b,
+                                    unsigned long long* __restrict__ out) {
+  unsigned long long c = 0;
+  for (i64 r = blockIdx.x * (i64)blockDim.x + threadIdx.x; r < n; r += (i64)gridDim.x * blockDim.x)
+    c += (cnt[r] != rowptr[r + 1] - rowptr[r] || blk_a[r] != blk_b[r]) ? 1 : 0;
+  if (c) atomicAdd(out, c);
+}
+
+void assemble_csr_like(const SysParams& P, const Slab& s, const Numbering& nb, const CsrMatrix& T, CsrMatrix& A) {
+  hipStream_t st = ctx().stream;
+  Laps laps;
+  const i64 n = nb.n_own;
+  const bool halo = T.halo_needed;
+  if (n == 0 || T.n != n || !T.rowptr.p) {
+    assemble_csr_preconditioned(P, s, nb, A, &halo);
+    return;
+  }
+  RowSegs seg;
+  seg.K = nb.K;
+  for (int k = 0; k < MAX_KINDS; ++k) seg.off_own[k] = nb.off_own[k];
+  A.n = n;
+  A.ds.alloc(nb.n_vec() > 0 ? nb.n_vec() : 1);
+  hipLaunchKernelGGL(k_point_scale, dim3(grid_for((i64)nb.K * nb.Mloc, 256, 256 * 16)), dim3(256), 0, st, P, nb.K, nb.Mloc,
+                     nb.red.p, A.ds.p);
+  PG_HIP(hipGetLastError());
+  DevBuf<int> cnt(n);
+  A.isblk.alloc(n);
+  DevBuf<unsigned long long> nraw(2);
+  nraw.zero();
+  const int gr = grid_for(n, 256, 256 * 16);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_asm_p<false>), dim3(gr), dim3(256), 0, st, P, seg, nb.Mloc, n, nb.row_cell.p, nb.red.p,
+                     A.ds.p, cnt.p, A.isblk.p, nraw.p, (const int*)nullptr, (int*)nullptr, (double*)nullptr);
+  hipLaunchKernelGGL(k_structure_differs, dim3(grid_for(n, 256, 4096)), dim3(256), 0, st, n, cnt.p, T.rowptr.p, A.isblk.p,
+                     T.isblk.p, nraw.p + 1);
+  PG_HIP(hipGetLastError());
+  unsigned long long h[2] = {0, 0};
+  nraw.download(h, 2);
+  if (h[1] != 0) {   // a coefficient vanishes under one scheme only: different pattern
+    assemble_csr_preconditioned(P, s, nb, A, &halo);
+    return;
+  }
+  A.nnz = T.nnz;
+  A.nnz_raw = (i64)h[0];
+  A.halo_needed = halo;
+  A.rowptr.alloc(n + 1);
+  PG_HIP(hipMemcpyAsync(A.rowptr.p, T.rowptr.p, sizeof(int) * (n + 1), hipMemcpyDeviceToDevice, st));
+  A.col.alloc(A.nnz + 8);
+  A.val.alloc(A.nnz + 8);
+  A.col.zero();
+  A.val.zero();
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_asm_p<true>), dim3(gr), dim3(256), 0, st, P, seg, nb.Mloc, n, nb.row_cell.p, nb.red.p,
+                     A.ds.p, (int*)nullptr, (unsigned char*)nullptr, (unsigned long long*)nullptr, (const int*)A.rowptr.p, A.col.p, A.val.p);
+  PG_HIP(hipGetLastError());
+  const i64 nblk = T.n_blk, nb1 = nblk > 0 ? nblk : 1;
+  A.n_blk = nblk;
+  A.blk_rows.alloc(nb1);
+  A.blk_idx.alloc((i64)MAX_KINDS * nb1);
+  A.blk_coef.alloc((i64)MAX_KINDS * nb1);
+  A.blk_cn.alloc((i64)MAX_KINDS * nb1);
+  A.blk_fw.alloc((i64)MAX_KINDS * nb1);
+  if (nblk > 0) {
+    DevBuf<int> pos(n), total(1);
+    scan_exclusive<unsigned char>(A.isblk.p, pos.p, n, total.p, st);
+    hipLaunchKernelGGL(k_blk_table, dim3(gr), dim3(256), 0, st, P, seg, nb.Mloc, n, nb.row_cell.p, nb.red.p, A.ds.p, A.isblk.p,
+                       pos.p, A.blk_rows.p, A.blk_idx.p, A.blk_coef.p, A.blk_cn.p, A.blk_fw.p);
+    PG_HIP(hipGetLastError());
+    PG_HIP(hipStreamSynchronize(st));
+  }
+  laps.lap("  asm-like: values on the ctor matrix' pattern");
+  if (!build_slices_like(T, A)) build_spmv_chunks(A);
+  laps.lap("  asm-like: slices");
 }
 
 // out = B⁻¹ S in   (in and out must not alias)

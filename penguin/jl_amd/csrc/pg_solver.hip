@@ -427,8 +427,11 @@ void setup_common(pg_solver* s, const pg_border_desc* borders, int nborders, con
 
   // K10 once, K7/K9 for the constructor scheme
   const SysParams P = make_params(s, s->scheme_ctor);
+  Laps laps;
   build_numbering(P, slab, s->nb);
+  laps.lap("build_numbering");
   assemble_csr_preconditioned(P, slab, s->nb, s->A_ctor);
+  laps.lap("assemble_csr_preconditioned");
   s->A_ctor.scheme = s->scheme_ctor;
 
   const i64 n = s->nb.n_own, nv = s->nb.n_vec();
@@ -445,7 +448,9 @@ void setup_common(pg_solver* s, const pg_border_desc* borders, int nborders, con
                        kv, s->mass.p, s->fixed.p, s->bcv.p);
     PG_HIP(hipGetLastError());
   }
+  laps.lap("row data, vectors");
   build_first_rhs(s);
+  laps.lap("first right-hand side");
   s->t = 0.0;
 }
 
@@ -480,7 +485,7 @@ void ensure_run_matrix(pg_solver* s, int scheme) {
     return;
   }
   const SysParams P = make_params(s, scheme);
-  assemble_csr_preconditioned(P, s->slab, s->nb, s->A_run);
+  assemble_csr_like(P, s->slab, s->nb, s->A_ctor, s->A_run);
   s->A_run.scheme = scheme;
   s->scheme_run = scheme;
   s->have_run = true;

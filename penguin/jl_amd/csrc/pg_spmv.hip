@@ -34,6 +34,7 @@
 //   +32 16-byte (aligned pair / quad) stream loads
 #include <algorithm>
 #include <cstdlib>
+#include <thread>
 #include <vector>
 
 #include "pg_spmv.h"
@@ -715,6 +716,10 @@ int xcd_map() {
   return v;
 }
 
+}  // namespace
+void ensure_csr_chunks(const CsrMatrix& A);
+namespace {
+
 #define PG_LAUNCH_C(KERNEL)                                                                                    \
   hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL), dim3(grid), dim3(BLOCK), 0, st, A.n, A.nchunks, A.chunk_desc.p, \
                      A.rowptr.p, A.col.p, A.val.p, x, y, aux, partials, sc)
@@ -733,6 +738,7 @@ bool launch_mode(int v, const CsrMatrix& A, const double* x, double* y, const do
                          A.g_rowid.p, A.g_rowptr.p, A.g_col.p, A.g_val.p, x, y, aux, partials, sc, xcd_map(), fa);
     return fa.ticket != nullptr;
   }
+  if (v != 1) ensure_csr_chunks(A);
   if (v == 1) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv<MODE>), dim3(grid), dim3(BLOCK), 0, st, A.n, A.rowptr.p, A.col.p, A.val.p, x, y,
                        aux, partials, sc);
@@ -764,60 +770,97 @@ struct Slice {
 };
 
 // stencil-slice image of A (see "stencil slices" above); rp = host copy of A.rowptr
-void build_slices(CsrMatrix& A, const std::vector<int>& rp) {
+void build_slices(CsrMatrix& A, const int* rp) {
   hipStream_t st = ctx().stream;
+  Laps laps;
   const i64 n = A.n;
   static const int minrun = getenv("PG_SPMV_MINRUN") ? atoi(getenv("PG_SPMV_MINRUN")) : 24;
-  std::vector<unsigned char> fl(n);
-  {
-    DevBuf<unsigned char> flags(n);
-    hipLaunchKernelGGL(k_row_same, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, n, A.rowptr.p, A.col.p, A.val.p, flags.p);
-    PG_HIP(hipGetLastError());
-    flags.download(fl.data(), n);
-  }
-  std::vector<Slice> up;       // U and P slices
-  std::vector<int> grows;      // irregular rows, ascending
-  auto emit = [&](int type, i64 a, i64 b, int cnt) {
-    const i64 maxrows = type == SL_U ? SL_MAXROWS_U : SL_MAXROWS_P;
-    for (i64 r = a; r < b; r += maxrows) {
-      const int rows = (int)std::min<i64>(maxrows, b - r);
-      up.push_back(Slice{(int)r, rows | (type << 8) | (cnt << 16), 0, 0, (int)r});
-    }
-    (type == SL_U ? A.rows_u : A.rows_p) += b - a;
-    if (type == SL_P) A.nnz_p += (b - a) * cnt;
+  unsigned char* fl = static_cast<unsigned char*>(pinned_scratch(1, (size_t)n));
+  A.rowflags.alloc(n);
+  hipLaunchKernelGGL(k_row_same, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, n, A.rowptr.p, A.col.p, A.val.p,
+                     A.rowflags.p);
+  PG_HIP(hipGetLastError());
+  A.rowflags.download(fl, n);
+  laps.lap("    slices: row flags");
+  // run classification over [lo, hi) (lo, hi on pattern-run boundaries): independent per range, so the 10^7-row
+  // sweep is split over a few host threads and the pieces are concatenated in row order
+  struct Part {
+    std::vector<Slice> up;      // U and P slices
+    std::vector<int> grows;     // irregular rows, ascending
+    i64 rows_u = 0, rows_p = 0, nnz_p = 0;
   };
-  auto irregular = [&](i64 a, i64 b) {
-    for (i64 r = a; r < b; ++r) grows.push_back((int)r);
-  };
-  A.rows_u = A.rows_p = A.rows_g = A.nnz_p = A.nnz_g = 0;
-  i64 i = 0;
-  while (i < n) {
-    i64 j = i + 1;
-    while (j < n && (fl[j] & 1)) ++j;                 // pattern run [i, j)
-    const int cnt = rp[i + 1] - rp[i];
-    if (j - i >= minrun && cnt >= 1 && cnt <= SL_MAXCNT) {   // rows with more entries than a record holds stay irregular
-      i64 pstart = i, k = i;
-      auto flush_p = [&](i64 a, i64 b) {
-        if (b - a >= minrun) emit(SL_P, a, b, cnt);
-        else irregular(a, b);
-      };
-      while (k < j) {
-        i64 m = k + 1;
-        while (m < j && (fl[m] & 2)) ++m;             // value run [k, m)
-        if (m - k >= minrun) {
-          flush_p(pstart, k);
-          emit(SL_U, k, m, cnt);
-          pstart = m;
-        }
-        k = m;
+  auto classify = [&](i64 lo, i64 hi, Part& out) {
+    auto emit = [&](int type, i64 a, i64 b, int cnt) {
+      const i64 maxrows = type == SL_U ? SL_MAXROWS_U : SL_MAXROWS_P;
+      for (i64 r = a; r < b; r += maxrows) {
+        const int rows = (int)std::min<i64>(maxrows, b - r);
+        out.up.push_back(Slice{(int)r, rows | (type << 8) | (cnt << 16), 0, 0, (int)r});
       }
-      flush_p(pstart, j);
-    } else {
-      irregular(i, j);
+      (type == SL_U ? out.rows_u : out.rows_p) += b - a;
+      if (type == SL_P) out.nnz_p += (b - a) * cnt;
+    };
+    auto irregular = [&](i64 a, i64 b) {
+      for (i64 r = a; r < b; ++r) out.grows.push_back((int)r);
+    };
+    i64 i = lo;
+    while (i < hi) {
+      i64 j = i + 1;
+      while (j < n && (fl[j] & 1)) ++j;                 // pattern run [i, j)
+      const int cnt = rp[i + 1] - rp[i];
+      if (j - i >= minrun && cnt >= 1 && cnt <= SL_MAXCNT) {   // rows with more entries than a record holds stay irregular
+        i64 pstart = i, k = i;
+        auto flush_p = [&](i64 a, i64 b) {
+          if (b - a >= minrun) emit(SL_P, a, b, cnt);
+          else irregular(a, b);
+        };
+        while (k < j) {
+          i64 m = k + 1;
+          while (m < j && (fl[m] & 2)) ++m;             // value run [k, m)
+          if (m - k >= minrun) {
+            flush_p(pstart, k);
+            emit(SL_U, k, m, cnt);
+            pstart = m;
+          }
+          k = m;
+        }
+        flush_p(pstart, j);
+      } else {
+        irregular(i, j);
+      }
+      i = j;
     }
-    i = j;
+  };
+  const int nthreads = n > (i64)1 << 20 ? (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())) : 1;
+  std::vector<i64> cut(nthreads + 1, n);
+  cut[0] = 0;
+  for (int t = 1; t < nthreads; ++t) {
+    i64 c = n * t / nthreads;
+    while (c < n && (fl[c] & 1)) ++c;   // move to the start of a pattern run
+    cut[t] = std::max(c, cut[t - 1]);
   }
-  std::sort(grows.begin(), grows.end());
+  std::vector<Part> parts(nthreads);
+  if (nthreads == 1) {
+    classify(0, n, parts[0]);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t) th.emplace_back([&, t] { classify(cut[t], cut[t + 1], parts[t]); });
+    for (auto& x : th) x.join();
+  }
+  std::vector<Slice> up;
+  std::vector<int> grows;
+  A.rows_u = A.rows_p = A.rows_g = A.nnz_p = A.nnz_g = 0;
+  {
+    size_t nu = 0, ngr = 0;
+    for (auto& pt : parts) { nu += pt.up.size(); ngr += pt.grows.size(); }
+    up.reserve(nu);
+    grows.reserve(ngr);
+    for (auto& pt : parts) {
+      up.insert(up.end(), pt.up.begin(), pt.up.end());
+      grows.insert(grows.end(), pt.grows.begin(), pt.grows.end());
+      A.rows_u += pt.rows_u; A.rows_p += pt.rows_p; A.nnz_p += pt.nnz_p;
+    }
+  }
+  laps.lap("    slices: host classification");
   // P value bases
   {
     i64 pbase = 0;
@@ -878,6 +921,7 @@ void build_slices(CsrMatrix& A, const std::vector<int>& rp) {
     PG_HIP(hipGetLastError());
   }
   PG_HIP(hipStreamSynchronize(st));
+  laps.lap("    slices: packing + records");
   A.spmv_bytes = 4 * SL_REC * A.nslices + 8 * A.nnz_p + 12 * A.nnz_g + 8 * ng + 16 * n;
   if (getenv("PG_DEBUG"))
     fprintf(stderr, "[pg_spmv] slices %lld: rows U %lld P %lld G %lld of %lld; nnz P %lld G %lld of %lld; bytes/launch %lld (CSR %lld)\n",
@@ -888,8 +932,11 @@ void build_slices(CsrMatrix& A, const std::vector<int>& rp) {
 
 }  // namespace
 
-// rows -> chunks of <= 64 rows and <= SPMV_CHUNK_ENTRIES entries (greedy; once per matrix, host side)
-void build_spmv_chunks(CsrMatrix& A) {
+// rows -> chunks of <= 64 rows and <= SPMV_CHUNK_ENTRIES entries for the plain-CSR kernels (greedy, host side).  Only
+// the CSR variants need it: built on first use.
+void ensure_csr_chunks(const CsrMatrix& Ac) {
+  CsrMatrix& A = const_cast<CsrMatrix&>(Ac);
+  if (A.chunk_desc.p || A.n == 0) return;
   std::vector<int> rp(A.n + 1);
   A.rowptr.download(rp.data(), A.n + 1);
   std::vector<int> cd;   // {first row, first entry} per chunk, closed by {n, nnz}; padded for the 4-int descriptor read
@@ -910,7 +957,81 @@ void build_spmv_chunks(CsrMatrix& A) {
   cd.push_back(rp[A.n]);
   A.chunk_desc.alloc((i64)cd.size());
   A.chunk_desc.upload(cd.data(), (i64)cd.size());
+}
+
+// SpMV image of a freshly assembled matrix (once per matrix)
+void build_spmv_chunks(CsrMatrix& A) {
+  Laps laps;
+  int* rp = static_cast<int*>(pinned_scratch(0, sizeof(int) * (size_t)(A.n + 1)));
+  A.rowptr.download(rp, A.n + 1);
+  laps.lap("    chunks: rowptr download");
+  A.chunk_desc.release();
+  A.nchunks = 0;
   build_slices(A, rp);
+}
+
+// do the new row flags still support every slice?  (U: rows 2.. repeat offsets and values; P: offsets.)  More repetition
+// than before is fine -- it is just not exploited; rows outside the slices (G) need nothing.
+__global__ void k_slices_invalid(i64 nslices, const int* __restrict__ srec, const unsigned char* __restrict__ flags,
+                                 unsigned long long* __restrict__ out) {
+  unsigned long long c = 0;
+  for (i64 q = blockIdx.x; q < nslices; q += gridDim.x) {
+    const int r0 = srec[SL_REC * q], meta = srec[SL_REC * q + 1];
+    const int nrows = meta & 255, type = (meta >> 8) & 3;
+    const unsigned char need = type == SL_U ? 3 : 1;
+    for (int l = 1 + threadIdx.x; l < nrows; l += blockDim.x) c += (flags[r0 + l] & need) != need ? 1 : 0;
+  }
+  if (c) atomicAdd(out, c);
+}
+
+template <class T>
+static void clone_buf(DevBuf<T>& dst, const DevBuf<T>& src, hipStream_t st) {
+  dst.alloc(src.n > 0 ? src.n : 1);
+  if (src.n > 0) PG_HIP(hipMemcpyAsync(dst.p, src.p, sizeof(T) * (size_t)src.n, hipMemcpyDeviceToDevice, st));
+}
+
+bool build_slices_like(const CsrMatrix& T, CsrMatrix& A) {
+  hipStream_t st = ctx().stream;
+  const i64 n = A.n;
+  if (!T.rowflags.p || T.n != n || !T.srec.p) return false;
+  A.rowflags.alloc(n);
+  DevBuf<unsigned long long> diff(1);
+  diff.zero();
+  hipLaunchKernelGGL(k_row_same, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, n, A.rowptr.p, A.col.p, A.val.p,
+                     A.rowflags.p);
+  if (T.nslices > 0)
+    hipLaunchKernelGGL(k_slices_invalid, dim3((unsigned)std::min<i64>(T.nslices, 16384)), dim3(64), 0, st, T.nslices, T.srec.p,
+                       A.rowflags.p, diff.p);
+  PG_HIP(hipGetLastError());
+  unsigned long long h = 0;
+  diff.download(&h, 1);
+  if (h != 0) return false;
+  // every slice still holds: copy the structure, refill the values
+  A.chunk_desc.release();
+  A.nchunks = 0;
+  A.nslices = T.nslices;
+  A.rows_u = T.rows_u; A.rows_p = T.rows_p; A.rows_g = T.rows_g; A.nnz_p = T.nnz_p; A.nnz_g = T.nnz_g;
+  A.spmv_bytes = T.spmv_bytes;
+  clone_buf(A.srec, T.srec, st);
+  clone_buf(A.g_rowid, T.g_rowid, st);
+  clone_buf(A.g_rowptr, T.g_rowptr, st);
+  A.pval.alloc(A.nnz_p + 8);
+  A.g_col.alloc(A.nnz_g + 8);
+  A.g_val.alloc(A.nnz_g + 8);
+  A.g_col.zero();
+  A.g_val.zero();
+  if (A.nslices > 0)
+    hipLaunchKernelGGL(k_fill_records, dim3(grid_for(A.nslices, 256)), dim3(256), 0, st, A.nslices, A.srec.p, A.rowptr.p, A.col.p,
+                       A.val.p);
+  if (A.nnz_p > 0)
+    hipLaunchKernelGGL(k_pval_fill, dim3((unsigned)std::min<i64>(A.nslices, 65535)), dim3(256), 0, st, A.nslices, A.srec.p,
+                       A.rowptr.p, A.val.p, A.pval.p);
+  if (A.rows_g > 0)
+    hipLaunchKernelGGL(k_gpack, dim3(grid_for(A.rows_g, 256)), dim3(256), 0, st, A.rows_g, A.g_rowid.p, A.g_rowptr.p, A.rowptr.p,
+                       A.col.p, A.val.p, A.g_col.p, A.g_val.p);
+  PG_HIP(hipGetLastError());
+  PG_HIP(hipStreamSynchronize(st));
+  return true;
 }
 
 int spmv_default_grid(i64 n) {
