@@ -78,19 +78,43 @@ __global__ void k_classify(GeoView g, BallSet bs, i64 Mloc, double* V, double* G
   }
 }
 
-// K1/K5 (expensive part): one thread per cut cell of the compacted list.
+// The cut-cell quadrature is ~10^5 flops of branchy fp64 per box and there are only O(n^(N-1)) boxes: one thread per box
+// leaves ~3 waves per SIMD walking long serial chains (20 + 43 ms at 512^3).  CUT_LANES lanes share a box instead: each
+// takes one Gauss-Legendre node of every z piece and the partial moments are summed with shuffles.
+constexpr int CUT_LANES = 16;   // = NGL
+
+struct LaneGroup {
+  __device__ void operator()(pggeom::Mom& m) const {
+#pragma unroll
+    for (int off = CUT_LANES / 2; off > 0; off >>= 1) {
+      m.vol += __shfl_xor(m.vol, off, CUT_LANES);
+      m.gamma += __shfl_xor(m.gamma, off, CUT_LANES);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        m.m[d] += __shfl_xor(m.m[d], off, CUT_LANES);
+        m.gm[d] += __shfl_xor(m.gm[d], off, CUT_LANES);
+      }
+    }
+  }
+};
+
+// K1/K5 (expensive part): CUT_LANES lanes per cut cell of the compacted list.
 __global__ void k_cut_cells(GeoView g, BallSet bs, const int* cut_list, int ncut, double* V, double* G,
                             double* Cw0, double* Cw1, double* Cw2, double* Cg0, double* Cg1, double* Cg2) {
   double* Cw[3] = {Cw0, Cw1, Cw2};
   double* Cg[3] = {Cg0, Cg1, Cg2};
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= ncut) return;
+  const i64 gt = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+  const int ql = (int)(gt % CUT_LANES);
+  i64 k = gt / CUT_LANES;
+  const bool live = k < ncut;
+  if (!live) k = ncut - 1;          // whole groups stay in the shuffles
   const i64 lc = cut_list[k];
   i64 idx[3];
   decode_cell(g.N, g.ext, g.plane, g.s0, lc, idx);
   double lo[3], hi[3];
   cell_box(g, idx, lo, hi);
-  const BoxMeasure m = box_measure(bs, lo, hi, true, c_gl);
+  const BoxMeasure m = box_measure(bs, lo, hi, true, c_gl, ql, CUT_LANES, LaneGroup());
+  if (!live || ql != 0) return;
   V[lc] = m.vol;
   G[lc] = m.gamma;
   for (int d = 0; d < g.N; ++d) {
@@ -190,8 +214,11 @@ __global__ void k_stagger_cut(GeoView g, BallSet bs, const int* wlist, int nw, c
                               const double* Cw1, const double* Cw2, double* W0, double* W1, double* W2) {
   const double* Cw[3] = {Cw0, Cw1, Cw2};
   double* W[3] = {W0, W1, W2};
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= nw) return;
+  const i64 gt = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+  const int ql = (int)(gt % CUT_LANES);
+  i64 k = gt / CUT_LANES;
+  const bool live = k < nw;
+  if (!live) k = nw - 1;
   const i64 lc = wlist[2 * k];
   const int d = wlist[2 * k + 1];
   i64 idx[3];
@@ -208,7 +235,8 @@ __global__ void k_stagger_cut(GeoView g, BallSet bs, const int* wlist, int nw, c
   }
   lo[d] = Cw[d][lp];
   hi[d] = Cw[d][ln];
-  W[d][lc] = box_measure(bs, lo, hi, false, c_gl).vol;
+  const double w = box_measure(bs, lo, hi, false, c_gl, ql, CUT_LANES, LaneGroup()).vol;
+  if (live && ql == 0) W[d][lc] = w;
 }
 
 // per-plane count of non-empty cells (slab balancing weights)
@@ -377,7 +405,7 @@ int32_t pg_capacity_create_levelset(pg_mesh* m, int32_t body_kind, const double*
   const int ncut = hc[0];
   c->n_cut_local = ncut;
   if (ncut > 0) {
-    hipLaunchKernelGGL(k_cut_cells, dim3((ncut + 63) / 64), dim3(64), 0, st, g, bs, cut_list.p, ncut, c->V.p, c->G.p,
+    hipLaunchKernelGGL(k_cut_cells, dim3((unsigned)(((i64)ncut * CUT_LANES + 255) / 256)), dim3(256), 0, st, g, bs, cut_list.p, ncut, c->V.p, c->G.p,
                        c->Cw[0].p, c->Cw[1].p, c->Cw[2].p, c->Cg[0].p, c->Cg[1].p, c->Cg[2].p);
     PG_HIP(hipGetLastError());
   }
@@ -394,7 +422,7 @@ int32_t pg_capacity_create_levelset(pg_mesh* m, int32_t body_kind, const double*
   const int nw = hc[1];
   PG_REQUIRE(nw <= wcap, "internal: staggered-volume work list overflow");
   if (nw > 0) {
-    hipLaunchKernelGGL(k_stagger_cut, dim3((nw + 63) / 64), dim3(64), 0, st, g, bs, wlist.p, nw, c->Cw[0].p, c->Cw[1].p,
+    hipLaunchKernelGGL(k_stagger_cut, dim3((unsigned)(((i64)nw * CUT_LANES + 255) / 256)), dim3(256), 0, st, g, bs, wlist.p, nw, c->Cw[0].p, c->Cw[1].p,
                        c->Cw[2].p, c->W[0].p, c->W[1].p, c->W[2].p);
     PG_HIP(hipGetLastError());
   }

@@ -168,12 +168,17 @@ struct Mom {
   double vol, m[3], gamma, gm[3];
 };
 
-// ball(c,r) ∩ box moments about the ball centre (box assumed CUT)
+// ball(c,r) ∩ box moments about the ball centre (box assumed CUT).
+// qlane / qstride: this caller evaluates only the Gauss-Legendre nodes q = qlane, qlane + qstride, ... of every z piece
+// (the piece structure is a function of the box alone, so cooperating lanes walk it identically); the returned moments
+// are then PARTIAL sums that the caller adds up over its group.  The closed-form 1-D / 2-D cases have no quadrature:
+// lane 0 returns the whole result, the others zero.  (0, 1) = everything, the host / oracle-checked form.
 PG_HD Mom ball_box_moments(const double* c, double r, const double* lo, const double* hi, int N,
-                           bool want_surface, const GLTable& gl) {
+                           bool want_surface, const GLTable& gl, int qlane = 0, int qstride = 1) {
   Mom o;
   o.vol = o.gamma = 0.0;
   for (int d = 0; d < 3; ++d) o.m[d] = o.gm[d] = 0.0;
+  if (N < 3 && qlane != 0) return o;
   double a[3], b[3];
   for (int d = 0; d < N; ++d) { a[d] = lo[d] - c[d]; b[d] = hi[d] - c[d]; }
   if (N == 1) {
@@ -255,7 +260,7 @@ PG_HD Mom ball_box_moments(const double* c, double r, const double* lo, const do
         continue;
       }
       const double zm = 0.5 * (za + zb), zh = 0.5 * len;
-      for (int q = 0; q < NGL; ++q) {
+      for (int q = qlane; q < NGL; q += qstride) {
         const double t = gl.x[q];
         const double g = 0.5 * t * (3.0 - t * t);
         const double jw = gl.w[q] * zh * 1.5 * (1.0 - t * t);
@@ -304,8 +309,14 @@ PG_HD int pick_ball(const BallSet& bs, const double* lo, const double* hi, int& 
   return bs.nballs - 1;
 }
 
+struct NoGroup {     // single caller: nothing to add up
+  PG_HD void operator()(Mom&) const {}
+};
+
+// group = functor that sums a partial Mom over the cooperating lanes (device: shuffles), see ball_box_moments
+template <class Group = NoGroup>
 PG_HD BoxMeasure box_measure(const BallSet& bs, const double* lo, const double* hi, bool want_surface,
-                             const GLTable& gl) {
+                             const GLTable& gl, int qlane = 0, int qstride = 1, Group group = Group()) {
   const int N = bs.N;
   BoxMeasure o;
   o.vol = 0.0; o.gamma = 0.0;
@@ -325,7 +336,8 @@ PG_HD BoxMeasure box_measure(const BallSet& bs, const double* lo, const double* 
   }
   const double* c = bs.c[s];
   const double full = prod_ext(lo, hi, N, -1);
-  Mom m = ball_box_moments(c, bs.r, lo, hi, N, want_surface, gl);
+  Mom m = ball_box_moments(c, bs.r, lo, hi, N, want_surface, gl, qlane, qstride);
+  group(m);
   if (bs.complement) {
     m.vol = full - m.vol;
     for (int d = 0; d < N; ++d) m.m[d] = full * (o.cen[d] - c[d]) - m.m[d];
