@@ -124,7 +124,10 @@ __global__ void k_cut_cells(GeoView g, BallSet bs, const int* cut_list, int ncut
 }
 
 // K2 + K4: A_d (face x_d = nodes_d[i_d], i_d <= n_d, other dims real) and B_d (section through C_w[d]).
-__global__ void k_sections(GeoView g, BallSet bs, i64 Mloc, const double* Cw0, const double* Cw1,
+// A face or a centroid section of cell i lies inside the closed cell: if the cell is FULL (EMPTY) the section is FULL
+// (EMPTY) by the same monotone far / near tests that classified the cell, with the same value prod_ext(...) (0) the
+// geometric path returns -- so only cut cells (and the padding faces next to them) evaluate geometry: 17 -> 3 ms at 512^3.
+__global__ void k_sections(GeoView g, BallSet bs, i64 Mloc, const double* ct, const double* Cw0, const double* Cw1,
                            const double* Cw2, double* A0, double* A1, double* A2, double* B0, double* B1,
                            double* B2) {
   const double* Cw[3] = {Cw0, Cw1, Cw2};
@@ -147,8 +150,21 @@ __global__ void k_sections(GeoView g, BallSet bs, i64 Mloc, const double* Cw0, c
           lo[k] = g.nodes[k][ik];
           hi[k] = g.nodes[k][ik + 1];
         }
-        a = section_measure(bs, d, g.nodes[d][idx[d]], lo, hi);
-        if (real) b = section_measure(bs, d, Cw[d][lc], lo, hi);
+        // type of the real cell that contains the face: cell i, or cell i - e_d for the padding face i_d = n_d
+        double t = (double)PG_CUT;
+        if (real) t = ct[lc];
+        else if (idx[d] >= g.n[d] && lc - g.stride[d] >= 0) t = ct[lc - g.stride[d]];
+        if (t == (double)PG_FULL) {
+          a = prod_ext(lo, hi, g.N, d);
+          if (g.N == 1) a = 1.0;
+          b = real ? a : 0.0;
+        } else if (t == (double)PG_EMPTY) {
+          a = 0.0;
+          b = 0.0;
+        } else {
+          a = section_measure(bs, d, g.nodes[d][idx[d]], lo, hi);
+          if (real) b = section_measure(bs, d, Cw[d][lc], lo, hi);
+        }
       }
       A[d][lc] = a;
       B[d][lc] = b;
@@ -409,7 +425,7 @@ int32_t pg_capacity_create_levelset(pg_mesh* m, int32_t body_kind, const double*
                        c->Cw[0].p, c->Cw[1].p, c->Cw[2].p, c->Cg[0].p, c->Cg[1].p, c->Cg[2].p);
     PG_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(k_sections, dim3(gr), dim3(256), 0, st, g, bs, Ml, c->Cw[0].p, c->Cw[1].p, c->Cw[2].p, c->A[0].p,
+  hipLaunchKernelGGL(k_sections, dim3(gr), dim3(256), 0, st, g, bs, Ml, c->ct.p, c->Cw[0].p, c->Cw[1].p, c->Cw[2].p, c->A[0].p,
                      c->A[1].p, c->A[2].p, c->B[0].p, c->B[1].p, c->B[2].p);
   PG_HIP(hipGetLastError());
   // W work list: at most N entries per cut-adjacent cell; bound by 2*N*ncut + slack
