@@ -13,3 +13,4 @@ from .api import (  # noqa: F401
     check_convergence, div, grad, lp_norm, nC, solve_DarcyFlow_b, solve_DarcyFlowUnsteady_b, solve_darcy_velocity, solve_DiffusionSteadyDiph_b, solve_DiffusionSteadyMono_b,
     solve_DiffusionUnsteadyDiph_b, solve_DiffusionUnsteadyMono_b,
 )
+from .vtk import write_vtk  # noqa: F401,E402
