@@ -41,7 +41,8 @@ enum { PG_FLAG_COMPLEMENT = 1, PG_FLAG_NO_CENTROIDS = 2 };
 /* capacity fields for pg_capacity_get (d = dimension for A,B,W,C_omega,C_gamma) */
 enum { PG_CAP_V = 0, PG_CAP_GAMMA = 1, PG_CAP_CELL_TYPES = 2, PG_CAP_A = 3, PG_CAP_B = 4,
        PG_CAP_W = 5, PG_CAP_C_OMEGA = 6, PG_CAP_C_GAMMA = 7 };
-enum { PG_OP_G = 0, PG_OP_H = 1, PG_OP_WINV = 2 };
+enum { PG_OP_G = 0, PG_OP_H = 1, PG_OP_WINV = 2,
+       PG_OP_C0 = 3 /* C_d: PG_OP_C0 + d */, PG_OP_K0 = 6 /* K_d: PG_OP_K0 + d */ };   /* ConvectionOps */
 /* interface / border condition kinds                         src/boundary.jl:12-50 */
 enum { PG_BC_NONE = 0, PG_BC_DIRICHLET = 1, PG_BC_NEUMANN = 2, PG_BC_ROBIN = 3, PG_BC_PERIODIC = 4 };
 /* border keys, in the reference's (unusual) naming           src/solver.jl:379-409 */
@@ -163,6 +164,11 @@ int32_t pg_diffops_destroy(pg_diffops* o);
    0-based colptr (ncols+1) / rowval, single rank only. */
 int32_t pg_diffops_export_csc(const pg_diffops* o, int32_t which, int64_t* colptr, int64_t* rowval,
                               double* nzval, int64_t* nnz);
+/* ConvectionOps(capacity, uₒ, uᵧ), operators.jl:194-210: C_d = δ_p[d]·diag(Σ_m[d] A_d uₒ_d)·Σ_m[d], K_d = diag(Σ_p[d] Hᵀuᵧ).
+   u_omega: N pointers to M doubles, u_gamma: N*M doubles (block d = component d).  A solver created from an operator
+   with a velocity assembles the advection-diffusion blocks (advectiondiffusion.jl:29-44,180-213: conv_bulk = ΣC_d and
+   conv_iface = ½ΣK_d on the bulk rows); pg_diffops_export_csc(PG_OP_C0 + d / PG_OP_K0 + d) returns C_d / K_d. */
+int32_t pg_diffops_set_velocity(pg_diffops* o, const double* const* u_omega, const double* u_gamma);
 int32_t pg_diffops_grad(const pg_diffops* o, const double* p /*2M*/, double* out /*N*M*/);      /* ∇  :20-23 */
 int32_t pg_diffops_div(const pg_diffops* o, const double* qw /*N*M*/, const double* qg /*N*M*/,
                        double* out /*M*/);                                                     /* ∇₋ :30-34 */

@@ -272,6 +272,34 @@ def make_diffusion_ops(cap: Capacity) -> DiffusionOps:
     return DiffusionOps(G, H, Winv, sp.diags(cap.V, format="csr"), mesh.ext)
 
 
+@dataclass
+class ConvectionOps:
+    """src/operators.jl:69-77."""
+
+    C: Tuple[sp.csr_matrix, ...]
+    K: Tuple[sp.csr_matrix, ...]
+    G: sp.csr_matrix
+    H: sp.csr_matrix
+    Winv: sp.csr_matrix
+    V: sp.csr_matrix
+    size: Tuple[int, ...]
+
+
+def make_convection_ops(cap: Capacity, u_omega: Sequence[np.ndarray], u_gamma: np.ndarray) -> ConvectionOps:
+    """ConvectionOps(Capacity, uₒ, uᵧ), src/operators.jl:194-210:
+    C_d = D_p[d] * spdiagm(S_m[d] * A[d] * uₒ[d]) * S_m[d],  K_d = spdiagm(S_p[d] * H' * uᵧ)."""
+    mesh = cap.mesh
+    N = mesh.N
+    base = make_diffusion_ops(cap)
+    D_p = [build_differential_operator(delta_p, mesh, d) for d in range(N)]
+    S_m = [build_differential_operator(sigma_m, mesh, d) for d in range(N)]
+    S_p = [build_differential_operator(sigma_p, mesh, d) for d in range(N)]
+    C = tuple((D_p[d] @ sp.diags(S_m[d] @ (cap.A[d] * np.asarray(u_omega[d], dtype=float))) @ S_m[d]).tocsr() for d in range(N))
+    h = base.H.T @ np.asarray(u_gamma, dtype=float)
+    K = tuple(sp.diags(S_p[d] @ h, format="csr") for d in range(N))
+    return ConvectionOps(C, K, base.G, base.H, base.Winv, base.V, mesh.ext)
+
+
 def grad(op: DiffusionOps, p: np.ndarray) -> np.ndarray:
     """∇, src/operators.jl:20-23."""
     h = len(p) // 2
@@ -824,6 +852,138 @@ def solve_DiffusionSteadyDiph(s: Solver, method: str = "\\", **kwargs):
     if s.A is None:
         raise RuntimeError("Solver is not initialized. Call a solver constructor first.")
     solve_system(s, method=method, **kwargs)
+    return s
+
+
+# ---- advection-diffusion, monophasic (next row f.2; src/solver/advectiondiffusion.jl) ----------------
+# The reference has no test for these drivers, and the loop of its unsteady monophasic driver calls
+# b_mono_unstead_advdiff with 8 arguments for a 9-parameter method (:272 vs :215): it raises a MethodError
+# after the first solve.  Restated here is the evident intent (the same loop as solve_DiffusionUnsteadyMono!
+# with the advection-diffusion blocks); parity for this row is UNPINNED.
+
+
+def _conv(op: ConvectionOps):
+    n = int(np.prod(op.size))
+    conv_bulk = sum(op.C[1:], op.C[0])
+    conv_iface = 0.5 * sum(op.K[1:], op.K[0])
+    return conv_bulk.tocsr(), conv_iface.tocsr(), n
+
+
+def A_mono_stead_advdiff(op: ConvectionOps, cap, D, bc):
+    """src/solver/advectiondiffusion.jl:29-44."""
+    Ia, Ib = build_I_bc(op, bc)
+    Ig = sp.diags(cap.G)
+    Id = sp.diags(build_I_D(op, D, cap))
+    L, Mx, P, Q = _blocks(op)
+    cb, ci, _ = _conv(op)
+    return sp.bmat([[cb + ci + Id @ L, ci + Id @ Mx], [Ib * P, Ib * Q + Ia * Ig]], format="csr")
+
+
+def AdvectionDiffusionSteadyMono(phase: Phase, bc_b, bc_i) -> Solver:
+    """src/solver/advectiondiffusion.jl:13-27."""
+    s = Solver("Steady", "Monophasic", "DiffusionAdvection")
+    s.A = A_mono_stead_advdiff(phase.operator, phase.capacity, phase.Diffusion_coeff, bc_i)
+    s.b = b_mono_stead_diff(phase.operator, phase.source, phase.capacity, bc_i)      # :46-58 is the diffusion b
+    s.A, s.b = BC_border_mono(s.A, s.b, bc_b, phase.capacity.mesh)
+    return s
+
+
+def A_diph_stead_advdiff(op1: ConvectionOps, op2: ConvectionOps, cap1, cap2, D1, D2, ic):
+    """src/solver/advectiondiffusion.jl:95-126."""
+    n = int(np.prod(op1.size))
+    jump, flux = ic.scalar, ic.flux
+    I_n = sp.identity(n, format="csr")
+    Id1 = sp.diags(build_I_D(op1, D1, cap1))
+    Id2 = sp.diags(build_I_D(op2, D2, cap2))
+    L1, M1, P1, Q1 = _blocks(op1)
+    L2, M2, P2, Q2 = _blocks(op2)
+    cb1, ci1, _ = _conv(op1)
+    cb2, ci2, _ = _conv(op2)
+    return sp.bmat(
+        [[Id1 @ L1 + (cb1 + ci1), Id1 @ M1 + ci1, None, None],
+         [None, jump.alpha1 * I_n, None, -jump.alpha2 * I_n],
+         [None, None, Id2 @ L2 + (cb2 + ci2), Id2 @ M2 + ci2],
+         [flux.beta1 * P1, flux.beta1 * Q1, flux.beta2 * P2, flux.beta2 * Q2]], format="csr")
+
+
+def AdvectionDiffusionSteadyDiph(phase1: Phase, phase2: Phase, bc_b, ic) -> Solver:
+    """src/solver/advectiondiffusion.jl:80-93."""
+    s = Solver("Steady", "Diphasic", "DiffusionAdvection")
+    s.A = A_diph_stead_advdiff(phase1.operator, phase2.operator, phase1.capacity, phase2.capacity,
+                               phase1.Diffusion_coeff, phase2.Diffusion_coeff, ic)
+    s.b = b_diph_stead_diff(phase1.operator, phase2.operator, phase1.source, phase2.source, phase1.capacity,
+                            phase2.capacity, ic)                     # :128-139 is the diffusion b
+    s.A, s.b = BC_border_diph(s.A, s.b, bc_b, phase1.capacity, phase2.capacity)
+    return s
+
+
+def A_mono_unstead_advdiff(op: ConvectionOps, cap, D, bc, dt: float, scheme: str):
+    """src/solver/advectiondiffusion.jl:180-213."""
+    Ia, Ib = build_I_bc(op, bc)
+    Ig = sp.diags(cap.G)
+    Id = sp.diags(build_I_D(op, D, cap))
+    L, Mx, P, Q = _blocks(op)
+    cb, ci, _ = _conv(op)
+    tie = Ib * Q + Ia * Ig
+    if scheme == "CN":
+        return sp.bmat([[op.V + dt / 2 * (cb + ci + Id @ L), dt / 2 * (ci + Id @ Mx)],
+                        [dt / 2 * Ib * P, dt / 2 * tie]], format="csr")
+    return sp.bmat([[op.V + dt * (cb + ci + Id @ L), dt * (ci + Id @ Mx)], [Ib * P, tie]], format="csr")
+
+
+def b_mono_unstead_advdiff(op: ConvectionOps, f, cap, D, bc, Ti, dt, t, scheme):
+    """src/solver/advectiondiffusion.jl:215-254."""
+    N = int(np.prod(op.size))
+    Ig = cap.G
+    Ia, Ib = build_I_bc(op, bc)
+    fn, fn1 = build_source(op, f, t, cap), build_source(op, f, t + dt, cap)
+    gn, gn1 = build_g_g(op, bc, cap, t), build_g_g(op, bc, cap, t + dt)
+    Tw, Tg = Ti[:N], Ti[N:]
+    V = cap.V
+    if scheme == "CN":
+        Id = sp.diags(build_I_D(op, D, cap))
+        L, Mx, P, Q = _blocks(op)
+        cb, ci, _ = _conv(op)
+        b1 = V * Tw - dt / 2 * ((cb + ci + Id @ L) @ Tw) - dt / 2 * ((ci + Id @ Mx) @ Tg) + dt / 2 * V * (fn + fn1)
+        b2 = dt / 2 * Ig * (gn + gn1) - dt / 2 * Ib * (P @ Tw) - dt / 2 * ((Ib * Q + Ia * sp.diags(Ig)) @ Tg)
+    else:
+        b1 = V * Tw + dt * V * fn1
+        b2 = Ig * gn1
+    return np.concatenate([b1, b2])
+
+
+def AdvectionDiffusionUnsteadyMono(phase: Phase, bc_b, bc_i, dt, Ti, scheme) -> Solver:
+    """src/solver/advectiondiffusion.jl:163-178, with the border rows applied as DiffusionUnsteadyMono does (the
+    reference's constructor leaves them out and only its -- broken -- loop applies them)."""
+    s = Solver("Unsteady", "Monophasic", "DiffusionAdvection")
+    sch = "CN" if scheme == "CN" else "BE"
+    s.A = A_mono_unstead_advdiff(phase.operator, phase.capacity, phase.Diffusion_coeff, bc_i, dt, sch)
+    s.b = b_mono_unstead_advdiff(phase.operator, phase.source, phase.capacity, phase.Diffusion_coeff, bc_i, Ti, dt, 0.0, sch)
+    s.A, s.b = BC_border_mono(s.A, s.b, bc_b, phase.capacity.mesh, t=0.0)
+    return s
+
+
+def solve_AdvectionDiffusionUnsteadyMono(s: Solver, phase: Phase, dt, Tend, bc_b, bc, scheme, method="\\",
+                                         max_steps: Optional[int] = None, **kwargs):
+    """src/solver/advectiondiffusion.jl:256-282 (intended loop, see the note above)."""
+    if s.A is None:
+        raise RuntimeError("Solver is not initialized. Call a solver constructor first.")
+    t = 0.0
+    solve_system(s, method=method, **kwargs)
+    s.states.append(s.x)
+    Ti = s.x
+    steps = 0
+    while t < Tend:
+        if max_steps is not None and steps >= max_steps:
+            break
+        t += dt
+        s.A = A_mono_unstead_advdiff(phase.operator, phase.capacity, phase.Diffusion_coeff, bc, dt, scheme)
+        s.b = b_mono_unstead_advdiff(phase.operator, phase.source, phase.capacity, phase.Diffusion_coeff, bc, Ti, dt, t, scheme)
+        s.A, s.b = BC_border_mono(s.A, s.b, bc_b, phase.capacity.mesh, t=t)
+        solve_system(s, method=method, **kwargs)
+        s.states.append(s.x)
+        Ti = s.x
+        steps += 1
     return s
 
 

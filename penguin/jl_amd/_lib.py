@@ -26,6 +26,7 @@ PG_BODY_BALL, PG_BODY_MULTIBALL = 1, 2
 PG_FLAG_COMPLEMENT, PG_FLAG_NO_CENTROIDS = 1, 2
 PG_CAP_V, PG_CAP_GAMMA, PG_CAP_CELL_TYPES, PG_CAP_A, PG_CAP_B, PG_CAP_W, PG_CAP_C_OMEGA, PG_CAP_C_GAMMA = range(8)
 PG_OP_G, PG_OP_H, PG_OP_WINV = 0, 1, 2
+PG_OP_C0, PG_OP_K0 = 3, 6            # ConvectionOps: C_d = PG_OP_C0 + d, K_d = PG_OP_K0 + d
 PG_BC_NONE, PG_BC_DIRICHLET, PG_BC_NEUMANN, PG_BC_ROBIN, PG_BC_PERIODIC = 0, 1, 2, 3, 4
 PG_KEY = {"left": 0, "right": 1, "bottom": 2, "top": 3, "backward": 4, "forward": 5}
 PG_SCHEME = {"BE": 0, "CN": 1, "STEADY": 2}

@@ -300,12 +300,13 @@ class DiffusionOps:
             nnz = C.c_int64()
             L.check(L.lib().pg_diffops_export_csc(self._h, C.c_int32(which), None, None, None, C.byref(nnz)))
             ncols = N * M if which == L.PG_OP_WINV else M
+            nrows = M if which >= L.PG_OP_C0 else N * M
             colptr = np.empty(ncols + 1, dtype=np.int64)
             rowval = np.empty(nnz.value, dtype=np.int64)
             nzval = np.empty(nnz.value)
             L.check(L.lib().pg_diffops_export_csc(self._h, C.c_int32(which), L.iptr(colptr), L.iptr(rowval), L.dptr(nzval),
                                                   C.byref(nnz)))
-            self._mats[which] = sp.csc_matrix((nzval, rowval, colptr), shape=(N * M, ncols))
+            self._mats[which] = sp.csc_matrix((nzval, rowval, colptr), shape=(nrows, ncols))
         return self._mats[which]
 
     @property
@@ -335,6 +336,29 @@ class DiffusionOps:
                 L.lib().pg_diffops_destroy(self._h)
         except Exception:
             pass
+
+
+class ConvectionOps(DiffusionOps):
+    """ConvectionOps(capacity, uₒ, uᵧ) -- src/operators.jl:194-210: C_d = δ_p[d]·diag(Σ_m[d] A_d uₒ_d)·Σ_m[d],
+    K_d = diag(Σ_p[d] Hᵀuᵧ), plus G, H, Wꜝ, V, size as DiffusionOps.  uₒ: N arrays of length M, uᵧ: length N·M."""
+
+    def __init__(self, capacity: Capacity, uₒ, uᵧ):
+        super().__init__(capacity)
+        N, M = capacity.N, int(np.prod(capacity.mesh.ext))
+        us = [np.ascontiguousarray(u, dtype=np.float64) for u in uₒ]
+        ug = np.ascontiguousarray(uᵧ, dtype=np.float64)
+        if len(us) != N or any(u.shape != (M,) for u in us) or ug.shape != (N * M,):
+            raise ValueError(f"ConvectionOps: uₒ must be {N} vectors of length {M}, uᵧ a vector of length {N * M}")
+        ptrs = (C.POINTER(C.c_double) * N)(*[L.dptr(u) for u in us])
+        L.check(L.lib().pg_diffops_set_velocity(self._h, ptrs, L.dptr(ug)))
+
+    @property
+    def C(self):
+        return tuple(self._export(L.PG_OP_C0 + d) for d in range(self.capacity.N))
+
+    @property
+    def K(self):
+        return tuple(self._export(L.PG_OP_K0 + d) for d in range(self.capacity.N))
 
 
 def grad(operator: DiffusionOps, p: np.ndarray) -> np.ndarray:
@@ -604,8 +628,9 @@ def _krylov_opts(method, kwargs) -> L.pg_krylov_opts:
 
 
 def DiffusionUnsteadyMono(phase: Phase, bc_b: BorderConditions, bc_i, Δt: float, Tᵢ: np.ndarray, scheme: str,
-                          verbose: bool = False) -> Solver:
+                          verbose: bool = False, _ops_kind=None) -> Solver:
     """DiffusionUnsteadyMono(phase, bc_b, bc_i, Δt, Tᵢ, scheme) -- src/solver/diffusion.jl:192-210."""
+    _require_ops(phase, _ops_kind or DiffusionOps)
     if verbose:
         print("Solver creation:\n- Monophasic problem\n- Unsteady problem\n- Diffusion problem")
     s = Solver("Unsteady", "Monophasic", "Diffusion")
@@ -894,8 +919,9 @@ def _dcoef(ph: Phase, M: int):
     return D
 
 
-def DiffusionSteadyMono(phase: Phase, bc_b: BorderConditions, bc_i, verbose: bool = False) -> Solver:
+def DiffusionSteadyMono(phase: Phase, bc_b: BorderConditions, bc_i, verbose: bool = False, _ops_kind=None) -> Solver:
     """DiffusionSteadyMono(phase, bc_b, bc_i) -- src/solver/diffusion.jl:14-28."""
+    _require_ops(phase, _ops_kind or DiffusionOps)
     if verbose:
         print("Solver creation:\n- Monophasic problem\n- Steady problem\n- Diffusion problem")
     s = Solver("Steady", "Monophasic", "Diffusion")
@@ -939,8 +965,10 @@ def solve_DiffusionSteadyMono_b(s: Solver, method="bicgstab", algorithm=None, ve
 
 
 def DiffusionSteadyDiph(phase1: Phase, phase2: Phase, bc_b: BorderConditions, ic: InterfaceConditions,
-                        verbose: bool = False) -> Solver:
+                        verbose: bool = False, _ops_kind=None) -> Solver:
     """DiffusionSteadyDiph(phase1, phase2, bc_b, ic) -- src/solver/diffusion.jl:88-101."""
+    _require_ops(phase1, _ops_kind or DiffusionOps)
+    _require_ops(phase2, _ops_kind or DiffusionOps)
     if verbose:
         print("Solver creation:\n- Diphasic problem\n- Steady problem\n- Diffusion problem")
     s = Solver("Steady", "Diphasic", "Diffusion")
@@ -973,6 +1001,64 @@ def solve_DiffusionSteadyDiph_b(s: Solver, method="bicgstab", algorithm=None, ve
     """solve_DiffusionSteadyDiph!(s; method, algorithm, kwargs...) -- src/solver/diffusion.jl:164-175."""
     return _solve_steady(s, method, kwargs, "Solving the system:\n- Diphasic problem\n- Steady problem\n- Diffusion problem",
                          verbose)
+
+
+# =============================================================================== advection-diffusion (SURVEY §8f.2)
+# src/solver/advectiondiffusion.jl: the diffusion drivers with conv_bulk = ΣC_d and conv_iface = ½ΣK_d added to the
+# bulk rows; the library assembles them whenever the phase's operator is a ConvectionOps.  The reference's unsteady
+# monophasic loop raises a MethodError after the first solve (8 arguments for the 9-parameter b_mono_unstead_advdiff,
+# :272 vs :215) and its constructor leaves the border rows out; what runs here is the evident intent: the loop and the
+# constructor of DiffusionUnsteadyMono with the advection-diffusion blocks.
+
+
+def _require_ops(phase: Phase, kind):
+    if not isinstance(phase.operator, kind) or (kind is DiffusionOps and isinstance(phase.operator, ConvectionOps)):
+        raise TypeError(f"phase.operator must be a {kind.__name__}")   # Julia: MethodError on the ::{kind} argument
+
+
+def AdvectionDiffusionSteadyMono(phase: Phase, bc_b: BorderConditions, bc_i, verbose: bool = False) -> Solver:
+    """AdvectionDiffusionSteadyMono(phase, bc_b, bc_i) -- src/solver/advectiondiffusion.jl:13-27."""
+    _require_ops(phase, ConvectionOps)
+    s = DiffusionSteadyMono(phase, bc_b, bc_i, verbose=verbose, _ops_kind=ConvectionOps)
+    s.equation_type = "DiffusionAdvection"
+    return s
+
+
+def solve_AdvectionDiffusionSteadyMono_b(s: Solver, method="bicgstab", algorithm=None, **kwargs):
+    """solve_AdvectionDiffusionSteadyMono!(s; ...) -- src/solver/advectiondiffusion.jl:60-66."""
+    return _solve_steady(s, method, kwargs, "", False)
+
+
+def AdvectionDiffusionSteadyDiph(phase1: Phase, phase2: Phase, bc_b: BorderConditions, ic: InterfaceConditions,
+                                 verbose: bool = False) -> Solver:
+    """AdvectionDiffusionSteadyDiph(phase1, phase2, bc_b, ic) -- src/solver/advectiondiffusion.jl:80-93."""
+    _require_ops(phase1, ConvectionOps)
+    _require_ops(phase2, ConvectionOps)
+    s = DiffusionSteadyDiph(phase1, phase2, bc_b, ic, verbose=verbose, _ops_kind=ConvectionOps)
+    s.equation_type = "DiffusionAdvection"
+    return s
+
+
+def solve_AdvectionDiffusionSteadyDiph_b(s: Solver, method="bicgstab", algorithm=None, **kwargs):
+    """solve_AdvectionDiffusionSteadyDiph!(s; ...) -- src/solver/advectiondiffusion.jl:141-147."""
+    return _solve_steady(s, method, kwargs, "", False)
+
+
+def AdvectionDiffusionUnsteadyMono(phase: Phase, bc_b: BorderConditions, bc_i, Δt: float, Tᵢ: np.ndarray, scheme: str,
+                                   verbose: bool = False) -> Solver:
+    """AdvectionDiffusionUnsteadyMono(phase, bc_b, bc_i, Δt, Tᵢ, scheme) -- src/solver/advectiondiffusion.jl:163-178."""
+    _require_ops(phase, ConvectionOps)
+    if scheme not in ("BE", "CN"):
+        raise ValueError("Unknown scheme.")                       # :203-205
+    s = DiffusionUnsteadyMono(phase, bc_b, bc_i, Δt, Tᵢ, scheme, verbose=verbose, _ops_kind=ConvectionOps)
+    s.equation_type = "DiffusionAdvection"
+    return s
+
+
+def solve_AdvectionDiffusionUnsteadyMono_b(s: Solver, phase: Phase, Δt: float, Tₑ: float, bc_b: BorderConditions, bc,
+                                           scheme: str, method="bicgstab", algorithm=None, **kwargs):
+    """solve_AdvectionDiffusionUnsteadyMono!(...) -- src/solver/advectiondiffusion.jl:256-282 (intended loop)."""
+    return solve_DiffusionUnsteadyMono_b(s, phase, Δt, Tₑ, bc_b, bc, scheme, method=method, algorithm=algorithm, **kwargs)
 
 
 # =============================================================================== Darcy (src/solver/darcy.jl: aliases)

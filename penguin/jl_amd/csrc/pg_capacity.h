@@ -19,6 +19,11 @@ struct pg_capacity {
 
 struct pg_diffops {
   pg_capacity* cap = nullptr;
+  // ConvectionOps (src/operators.jl:194-210), set by pg_diffops_set_velocity; local (stored planes) arrays
+  bool has_velocity = false;
+  pg::DevBuf<double> conv_a[3];   // a_d = Σ_m[d] (A_d ∘ uω_d): C_d = δ_p[d] diag(a_d) Σ_m[d]
+  pg::DevBuf<double> conv_h;      // Hᵀ uγ
+  pg::DevBuf<double> conv_k;      // ½ Σ_d Σ_p[d] Hᵀuγ = the diagonal of 0.5 * sum(K)
 };
 
 namespace pg {

@@ -21,6 +21,7 @@ using namespace pg;
 struct pg_solver {
   int nphase = 1;
   pg_capacity* cap[2] = {nullptr, nullptr};
+  pg_diffops* ops[2] = {nullptr, nullptr};   // (their convection data, if any, enters the bulk rows)
   Slab slab;
   int K = 2;
   i64 Mloc = 0, M = 0;
@@ -140,7 +141,8 @@ __global__ void k_bconst(SysParams P, RowSegs seg, i64 n_own, const int* row_cel
         const double V = P.cap[ph].V[lc];
         const double f1 = s.f_np1[ph] ? s.f_np1[ph][lc] : 0.0;
         if (scheme == PG_SCHEME_CN) {
-          const double f0 = s.f_n[ph] ? s.f_n[ph][lc] : 0.0;
+          // f(t) not supplied separately (BE constructor, constant-in-time source): f(t) = f(t+Δt)
+          const double f0 = s.f_n[ph] ? s.f_n[ph][lc] : f1;
           v = dt / 2 * V * (f0 + f1);
         } else {
           v = dt * V * f1;
@@ -314,6 +316,10 @@ SysParams make_params(const pg_solver* s, int scheme) {
     P.cap[q] = cap_view(s->cap[q]);
     P.ct[q] = s->cap[q]->ct.p;
     P.Id[q] = s->Id[q].p;
+    if (s->ops[q] && s->ops[q]->has_velocity) {
+      for (int d = 0; d < s->cap[q]->N; ++d) P.conv_a[q][d] = s->ops[q]->conv_a[d].p;
+      P.conv_k[q] = s->ops[q]->conv_k.p;
+    }
   }
   if (s->nphase == 1) { P.cap[1] = P.cap[0]; P.ct[1] = P.ct[0]; P.Id[1] = nullptr; }
   // steady (diffusion.jl:30-43): the unsteady BE blocks with Δt = 1 and without the V term
@@ -615,6 +621,7 @@ static void create_mono(pg_capacity* c, pg_diffops* o, const pg_bc_desc* bc_inte
   std::unique_ptr<pg_solver> guard(s);
   s->nphase = 1;
   s->cap[0] = c;
+  s->ops[0] = o;
   s->slab = c->slab;
   s->dt = dt;
   s->scheme_ctor = scheme;
@@ -661,7 +668,9 @@ static void create_diph(pg_capacity* c1, pg_diffops* o1, pg_capacity* c2, pg_dif
   std::unique_ptr<pg_solver> guard(s);
   s->nphase = 2;
   s->cap[0] = c1;
+  s->ops[0] = o1;
   s->cap[1] = c2;
+  s->ops[1] = o2;
   s->slab = c1->slab;
   s->dt = dt;
   s->scheme_ctor = scheme;

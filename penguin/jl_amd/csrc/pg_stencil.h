@@ -24,6 +24,9 @@ struct SysParams {
   double a1, a2, b1, b2; // diph jump coefficients α₁ α₂ β₁ β₂
   double theta;          // Δt (BE) or Δt/2 (CN): multiplies the diffusion part of bulk rows
   double gscale;         // mono interface rows: 1 (BE) or Δt/2 (CN)
+  // convection (advection-diffusion, src/solver/advectiondiffusion.jl:180-213): per phase, or nullptr
+  const double* conv_a[2][3];   // a_d of C_d = δ_p diag(a_d) Σ_m
+  const double* conv_k[2];      // diagonal of 0.5 * sum(K): added to the ω-ω and ω-γ diagonals of bulk rows
   double mass;           // coefficient of V in the bulk rows: 1 (unsteady), 0 (steady: A_mono_stead_diff, diffusion.jl:30-43)
   int border_kind[6];    // per PG_KEY_*
   double inv_dx;         // 1/Δx for the 1-D Neumann border row
@@ -140,6 +143,7 @@ __device__ inline void eval_row(const SysParams& P, int kind, i64 lc, const i64*
     const CapView& c = P.cap[q];
     const int kw = 2 * q, kg = 2 * q + 1;   // column kinds ω_q, γ_q
     double dW = 0.0, dG = 0.0;              // diagonal sums over dimensions
+    double dC = 0.0;                        // diagonal of sum(C) (convection)
     double scale;                           // what multiplies the stencil sums
     if (bulk) scale = P.theta * (P.Id[q] ? P.Id[q][lc] : 1.0);     // θ·Id   (row scaling)
     else if (P.nphase == 1) scale = P.gscale * P.Ib;               // (Δt/2)·Iᵦ
@@ -153,12 +157,22 @@ __device__ inline void eval_row(const SysParams& P, int kind, i64 lc, const i64*
           // GᵀWꜝG and GᵀWꜝH rows
           dW += L.gd_j * L.gd_j * L.w_j + L.gl_p * L.gl_p * L.w_p;
           dG += L.gd_j * L.w_j * L.hd_j + L.gl_p * L.w_p * L.hl_p;
+          // row k of C_d = δ_p diag(a) Σ_m (k < m; row m is empty: δ_p[m,m] = 0):
+          //   T[k+1]: ½a[k+1] (if k+1 < m: (Σ_m T)[m] = ½T[m-1] has no T[m]),  T[k]: ½(a[k+1] - a[k]),  T[k-1]: -½a[k]
+          double cp = 0.0, cm = 0.0;
+          const double* ca = P.conv_a[q][d];
+          if (ca && idx[d] < c.ext[d] - 1) {
+            const double a0 = ca[lc], a1 = ca[lc + st];
+            if (idx[d] + 1 < c.ext[d] - 1) cp = 0.5 * a1;
+            cm = -0.5 * a0;
+            dC += 0.5 * (a1 - a0);
+          }
           if (L.has_p) {
-            emit(kw, lc + st, scale * (L.gl_p * L.w_p * L.gd_p));
+            emit(kw, lc + st, scale * (L.gl_p * L.w_p * L.gd_p) + P.theta * cp);
             emit(kg, lc + st, scale * (L.gl_p * L.w_p * L.hd_p));
           }
           if (L.has_m) {
-            emit(kw, lc - st, scale * (L.gd_j * L.w_j * L.gl_j));
+            emit(kw, lc - st, scale * (L.gd_j * L.w_j * L.gl_j) + P.theta * cm);
             emit(kg, lc - st, scale * (L.gd_j * L.w_j * L.hl_j));
           }
         } else {
@@ -177,8 +191,9 @@ __device__ inline void eval_row(const SysParams& P, int kind, i64 lc, const i64*
       }
     }
     if (bulk) {
-      emit(kw, lc, P.mass * c.V[lc] + scale * dW);          // V + θ·Id·(GᵀWꜝG)_jj  (steady: no V)
-      emit(kg, lc, scale * dG);
+      const double ck = P.conv_k[q] ? P.conv_k[q][lc] : 0.0;          // 0.5 sum(K): on both diagonals (A11 and A12)
+      emit(kw, lc, P.mass * c.V[lc] + scale * dW + P.theta * (dC + ck));   // V + θ(Id·GᵀWꜝG + ΣC + ½ΣK)_jj  (steady: no V)
+      emit(kg, lc, scale * dG + P.theta * ck);
     } else if (P.nphase == 1) {
       emit(kw, lc, scale * dW);
       emit(kg, lc, scale * dG + P.gscale * (P.Ia * c.G[lc]));   // + (Δt/2)·Iₐ·Γ

@@ -772,3 +772,94 @@ def test_time_loop_is_bitwise_reproducible(pj):
         runs.append((int(run.total_iters), s._fetch_state().copy()))
     assert runs[0][0] == runs[1][0] == runs[2][0] > 0
     assert np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][1], runs[2][1])
+
+
+# ------------------------------------------------------------------------------------ advection-diffusion
+def _velocity_fields(cap, N, M):
+    """A smooth, non-uniform bulk velocity at the cell centroids and an interface velocity (any values: operator parity)."""
+    Cw = cap.C_ω
+    x = [Cw[:, d] for d in range(N)]
+    u = [1.0 + 0.5 * np.sin(1.3 * x[d] + 0.7 * d) + 0.25 * x[(d + 1) % N] for d in range(N)]
+    ug = np.concatenate([0.3 * np.cos(0.9 * x[d]) - 0.1 * d for d in range(N)])
+    return [np.ascontiguousarray(a) for a in u], np.ascontiguousarray(ug)
+
+
+@pytest.mark.parametrize("N,n,c,r", [(1, 24, (0.5,), 0.3), (2, 16, (2.01, 2.01), 1.0), (3, 10, (2.01, 2.01, 2.01), 1.0)])
+def test_convection_operators_match_oracle(pj, N, n, c, r):
+    """ConvectionOps(capacity, uₒ, uᵧ): C_d = δ_p diag(Σ_m A_d uₒ_d) Σ_m and K_d = diag(Σ_p Hᵀuᵧ) against the Kronecker
+    construction of the oracle on the SAME capacities (src/operators.jl:194-210)."""
+    Lx = 1.0 if N == 1 else 4.0
+    mesh, omesh = pj.Mesh((n,) * N, (Lx,) * N), po.Mesh((n,) * N, (Lx,) * N, (0.0,) * N)
+    cap = pj.Capacity(pj.Sphere(c, r), mesh)
+    ocap = oracle_capacity_from_product(cap, omesh)
+    M = (n + 1) ** N
+    u, ug = _velocity_fields(cap, N, M)
+    op, oop = pj.ConvectionOps(cap, u, ug), po.make_convection_ops(ocap, u, ug)
+    assert op.size == (n + 1,) * N
+    for d in range(N):
+        Cs, Ks = abs(oop.C[d]).max(), abs(oop.K[d]).max()
+        assert abs(op.C[d] - oop.C[d].tocsc()).max() <= 1e-15 * max(Cs, 1e-300)
+        assert abs(op.K[d] - oop.K[d].tocsc()).max() <= 1e-14 * max(Ks, 1e-300)
+    assert abs(op.G - oop.G.tocsc()).max() == 0.0
+    with pytest.raises(TypeError):                        # the diffusion constructors take DiffusionOps only
+        pj.DiffusionSteadyMono(pj.Phase(cap, op, 0.0, 1.0), pj.BorderConditions({}), pj.Dirichlet(0.0))
+
+
+def test_advection_diffusion_mono_matches_oracle(pj):
+    """Steady and unsteady (BE first solve, CN steps) monophasic advection-diffusion in 2-D: system and solution."""
+    n, N = 24, 2
+    M = (n + 1) ** 2
+    mesh, omesh = pj.Mesh((n, n), (4.0, 4.0)), po.Mesh((n, n), (4.0, 4.0), (0.0, 0.0))
+    cap = pj.Capacity(pj.Sphere((2.01, 2.01), 1.0), mesh)
+    ocap = oracle_capacity_from_product(cap, omesh)
+    u, ug = _velocity_fields(cap, N, M)
+    op, oop = pj.ConvectionOps(cap, u, ug), po.make_convection_ops(ocap, u, ug)
+    f, D = (lambda x, y, z=0.0: 1.0 + 0.2 * x), (lambda x, y, z=0.0: 0.5 + 0.1 * y)
+    ph, oph = pj.Phase(cap, op, f, D), po.Phase(ocap, oop, f, D)
+    bcb = pj.BorderConditions({k: pj.Dirichlet(0.0) for k in HEAT_BORDERS})
+    obcb = po.BorderConditions({k: po.Dirichlet(0.0) for k in HEAT_BORDERS})
+    s, so = pj.AdvectionDiffusionSteadyMono(ph, bcb, pj.Dirichlet(1.0)), po.AdvectionDiffusionSteadyMono(oph, obcb, po.Dirichlet(1.0))
+    assert s.equation_type == "DiffusionAdvection"
+    _check_system(s, so)
+    pj.solve_AdvectionDiffusionSteadyMono_b(s, reltol=1e-13)
+    po.solve_system(so, method="\\")
+    assert s.ch[-1]["converged"] and rel_l2(s.x, so.x) <= TOL_T
+    # unsteady
+    ft = lambda x, y, z, t: 1.0 + 0.2 * x
+    pht, opht = pj.Phase(cap, op, ft, D), po.Phase(ocap, oop, ft, D)
+    dt = 0.25 * (4.0 / n) ** 2
+    u0 = np.concatenate([np.zeros(M), np.ones(M)])
+    for sch0, sch in (("BE", "CN"), ("CN", "BE")):
+        su = pj.AdvectionDiffusionUnsteadyMono(pht, bcb, pj.Robin(1.0, 0.5, 1.0), dt, u0, sch0)
+        suo = po.AdvectionDiffusionUnsteadyMono(opht, obcb, po.Robin(1.0, 0.5, 1.0), dt, u0, sch0)
+        _check_system(su, suo)
+        pj.solve_AdvectionDiffusionUnsteadyMono_b(su, pht, dt, 5 * dt, bcb, pj.Robin(1.0, 0.5, 1.0), sch, reltol=1e-13)
+        po.solve_AdvectionDiffusionUnsteadyMono(suo, opht, dt, 5 * dt, obcb, po.Robin(1.0, 0.5, 1.0), sch, method="\\")
+        assert len(su.states) == len(suo.states)
+        for a, b in zip(su.states, suo.states):
+            assert rel_l2(a, b) <= TOL_T
+    with pytest.raises(ValueError):
+        pj.AdvectionDiffusionUnsteadyMono(pht, bcb, pj.Dirichlet(1.0), dt, u0, "RK4")
+
+
+def test_advection_diffusion_diphasic_steady_matches_oracle(pj):
+    n = 32
+    mesh, omesh = pj.Mesh((n, n), (4.0, 4.0)), po.Mesh((n, n), (4.0, 4.0), (0.0, 0.0))
+    c1, c2 = pj.Capacity(pj.Sphere((2.0, 2.0), 1.0), mesh), pj.Capacity(pj.Sphere((2.0, 2.0), 1.0, complement=True), mesh)
+    oc1, oc2 = oracle_capacity_from_product(c1, omesh), oracle_capacity_from_product(c2, omesh)
+    M = (n + 1) ** 2
+    u1, ug1 = _velocity_fields(c1, 2, M)
+    u2, ug2 = _velocity_fields(c2, 2, M)
+    one = lambda x, y, z=0.0: 1.0
+    p1, p2 = pj.Phase(c1, pj.ConvectionOps(c1, u1, ug1), one, one), pj.Phase(c2, pj.ConvectionOps(c2, u2, ug2), one, one)
+    q1 = po.Phase(oc1, po.make_convection_ops(oc1, u1, ug1), one, one)
+    q2 = po.Phase(oc2, po.make_convection_ops(oc2, u2, ug2), one, one)
+    bcb = pj.BorderConditions({k: pj.Dirichlet(0.0) for k in HEAT_BORDERS})
+    obcb = po.BorderConditions({k: po.Dirichlet(0.0) for k in HEAT_BORDERS})
+    ic = pj.InterfaceConditions(pj.ScalarJump(1.0, 0.8, 0.1), pj.FluxJump(1.0, 2.0, 0.0))
+    oic = po.InterfaceConditions(po.ScalarJump(1.0, 0.8, 0.1), po.FluxJump(1.0, 2.0, 0.0))
+    s, so = pj.AdvectionDiffusionSteadyDiph(p1, p2, bcb, ic), po.AdvectionDiffusionSteadyDiph(q1, q2, obcb, oic)
+    _check_system(s, so)
+    pj.solve_AdvectionDiffusionSteadyDiph_b(s, reltol=1e-13)
+    po.solve_system(so, method="\\")
+    assert s.ch[-1]["converged"] and rel_l2(s.x, so.x) <= 1e-9

@@ -260,3 +260,22 @@ def test_darcy_unsteady_known_answer():
     po.solve_DiffusionUnsteadyMono(s, ph, dt, 0.2, bcb, po.Neumann(0.0), "BE", method="\\")
     pin = GOLD["known_answers"]["darcy_unsteady_20x20_max_uo"]
     assert s.states[-1][:M].max() == pytest.approx(pin["value"], abs=pin["atol"])
+
+
+# ---------------------------------------------------------------- advection-diffusion (no reference test: analytic known answer)
+def test_advection_diffusion_1d_exponential_profile():
+    """Steady u T' = T'' on the whole line segment, T = 0 / 1 at the ends: T = (exp(Pe x) - 1) / (exp(Pe L) - 1) between the
+    border cell centres.  Pins the oracle's ConvectionOps / A_mono_stead_advdiff restatement on an analytic solution
+    (the reference ships no test for its advection-diffusion drivers)."""
+    n, Pe = 80, 5.0
+    mesh = po.Mesh((n,), (1.0,), (0.0,))
+    cap = po.make_capacity(Ball((10.0,), 20.0), mesh)                # the whole domain is fluid
+    M = n + 1
+    op = po.make_convection_ops(cap, [np.full(M, Pe)], np.zeros(M))
+    ph = po.Phase(cap, op, lambda x, y=0.0, z=0.0: 0.0, lambda x, y=0.0, z=0.0: 1.0)
+    bcb = po.BorderConditions({"bottom": po.Dirichlet(0.0), "top": po.Dirichlet(1.0)})
+    s = po.AdvectionDiffusionSteadyMono(ph, bcb, po.Dirichlet(0.0))
+    po.solve_system(s, method="\\")
+    xc = np.array(mesh.centers[0])
+    exact = (np.exp(Pe * (xc - xc[0])) - 1.0) / (np.exp(Pe * (xc[-1] - xc[0])) - 1.0)
+    assert np.abs(s.x[:n] - exact).max() < 5e-4
