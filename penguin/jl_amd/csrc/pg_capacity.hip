@@ -28,7 +28,24 @@ struct GeoView {
   i64 ext[3], n[3], stride[3];
   i64 plane, s0, s1;
   const double* nodes[3];
+  double h[3];     // mesh spacing L_d / n_d, the number Mesh() builds the nodes from (src/mesh.jl:49-50)
 };
+
+// Measures of FULL cells / faces / staggered volumes come from the mesh spacing h, not from differences of node
+// coordinates: x0 + (j+½)h carries rounding noise, so nodes[i+1] - nodes[i] varies in the last bits from cell to cell
+// unless h is a binary fraction.  With h every full cell of a uniform mesh has bitwise the same capacities, hence the
+// same matrix rows, and the SpMV's uniform slices work on ANY mesh Mesh() can build (768^3 over [0,4]^3: h = 1/192).
+// The difference to the node-difference value is ~1e-16 relative -- the noise level of the reference's own VOFI sums.
+__device__ inline double full_measure(const GeoView& g, int skip) {
+  double p = 0.0;
+  bool first = true;
+  for (int d = 0; d < g.N; ++d) {
+    if (d == skip) continue;
+    p = first ? g.h[d] : p * g.h[d];
+    first = false;
+  }
+  return first ? 1.0 : p;
+}
 
 __device__ inline bool is_real_cell(const GeoView& g, const i64* idx) {
   for (int d = 0; d < g.N; ++d)
@@ -61,7 +78,7 @@ __global__ void k_classify(GeoView g, BallSet bs, i64 Mloc, double* V, double* G
       pick_ball(bs, lo, hi, type);
       if (type != PG_CUT && bs.complement) type = 1 - type;
       for (int d = 0; d < g.N; ++d) cw[d] = 0.5 * (lo[d] + hi[d]);
-      if (type == PG_FULL) v = prod_ext(lo, hi, g.N, -1);
+      if (type == PG_FULL) v = full_measure(g, -1);
       if (type == PG_CUT) {
         const int slot = atomicAdd(cut_count, 1);
         cut_list[slot] = (int)lc;
@@ -155,15 +172,14 @@ __global__ void k_sections(GeoView g, BallSet bs, i64 Mloc, const double* ct, co
         if (real) t = ct[lc];
         else if (idx[d] >= g.n[d] && lc - g.stride[d] >= 0) t = ct[lc - g.stride[d]];
         if (t == (double)PG_FULL) {
-          a = prod_ext(lo, hi, g.N, d);
-          if (g.N == 1) a = 1.0;
+          a = full_measure(g, d);
           b = real ? a : 0.0;
         } else if (t == (double)PG_EMPTY) {
           a = 0.0;
           b = 0.0;
         } else {
-          a = section_measure(bs, d, g.nodes[d][idx[d]], lo, hi);
-          if (real) b = section_measure(bs, d, Cw[d][lc], lo, hi);
+          a = section_measure(bs, d, g.nodes[d][idx[d]], lo, hi, full_measure(g, d));
+          if (real) b = section_measure(bs, d, Cw[d][lc], lo, hi, full_measure(g, d));
         }
       }
       A[d][lc] = a;
@@ -210,7 +226,8 @@ __global__ void k_stagger(GeoView g, BallSet bs, i64 Mloc, const double* ct, con
           for (int k = 0; k < g.N; ++k)
             if (!(hi[k] - lo[k] > 0.0)) degenerate = true;
           if (!degenerate) {
-            if (type == PG_FULL) w = prod_ext(lo, hi, g.N, -1);
+            // between the centres of two full cells: exactly one cell volume
+            if (type == PG_FULL) w = (tp == 1.0 && tn == 1.0) ? full_measure(g, -1) : prod_ext(lo, hi, g.N, -1);
             else if (type == PG_CUT) {
               const int slot = atomicAdd(wcount, 1);
               if (slot < wcap) {
@@ -293,6 +310,7 @@ GeoView geo_view(pg_mesh* m, const Slab& s) {
     }
     g.nodes[d] = m->d_nodes[d].p;
   }
+  for (int d = 0; d < 3; ++d) g.h[d] = d < s.N ? m->L[d] / (double)m->n[d] : 1.0;
   return g;
 }
 

@@ -353,7 +353,11 @@ PG_HD BoxMeasure box_measure(const BallSet& bs, const double* lo, const double* 
 }
 
 // fluid measure of {x_d = s} ∩ box  (A_d with s = node, B_d with s = centroid coordinate)
-PG_HD double section_measure(const BallSet& bs, int d, double s, const double* lo, const double* hi) {
+// full_measure >= 0: the measure of a FULL section supplied by the caller (the kernels pass the product of the mesh
+// spacings so that every full face / section of a uniform mesh has bitwise the same measure: A_d - B_d must be an exact
+// zero between full neighbours, or a spurious 1e-17 coupling activates the γ unknown of a full cell)
+PG_HD double section_measure(const BallSet& bs, int d, double s, const double* lo, const double* hi,
+                             double full_measure = -1.0) {
   const int N = bs.N;
   double plo[3], phi[3];
   for (int k = 0; k < N; ++k) { plo[k] = lo[k]; phi[k] = hi[k]; }
@@ -366,7 +370,7 @@ PG_HD double section_measure(const BallSet& bs, int d, double s, const double* l
     if (bs.complement) f = -f;
     return f <= 0.0 ? 1.0 : 0.0;
   }
-  const double full = prod_ext(lo, hi, N, d);
+  const double full = full_measure >= 0.0 ? full_measure : prod_ext(lo, hi, N, d);
   if (t != PG_CUT) {
     if (bs.complement) t = 1 - t;
     return t == PG_FULL ? full : 0.0;
