@@ -292,4 +292,19 @@ end
 # DiffusionSteadyDiph / solve_DiffusionSteadyDiph! (:88-175) bind pg_solver_create_steady_diph the same way (two
 # capacities / operators, pg_jump_desc as in DiffusionUnsteadyDiph).
 
+# ---- ConvectionOps (src/operators.jl:194-210) and the advection-diffusion drivers ---------------------------------------
+# struct ConvectionOps{N}: same handle type as DiffusionOps plus the velocity; C[d] / K[d] are exported on demand with
+# pg_diffops_export_csc(handle, 3 + (d-1) | 6 + (d-1), ...).  A solver constructor that receives such an operator
+# assembles the advection-diffusion blocks (advectiondiffusion.jl:29-44, 95-126, 180-213).
+function ConvectionOps(capacity::Capacity{N}, uₒ::NTuple{N,Vector{Float64}}, uᵧ::Vector{Float64}) where N
+    op = DiffusionOps(capacity)
+    GC.@preserve uₒ uᵧ begin
+        ptrs = [pointer(u) for u in uₒ]
+        check(ccall((:pg_diffops_set_velocity, libpg), Int32, (Ptr{Cvoid}, Ptr{Ptr{Float64}}, Ptr{Float64}), op.handle, ptrs, uᵧ))
+    end
+    op
+end
+# AdvectionDiffusionSteadyMono / SteadyDiph / UnsteadyMono and their solve_...! functions are the diffusion constructors
+# and loops above called with such an operator (DarcyFlow / DarcyFlowUnsteady likewise alias the diffusion drivers).
+
 end # module
