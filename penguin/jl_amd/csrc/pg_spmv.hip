@@ -1,47 +1,31 @@
-// pg_spmv.hip -- the dominant kernel of the path: y = A x for the reduced cut-cell system in CSR
-// (fp64 values, int32 column indices, int32 row pointers; rows in box order, 1 / 2N+1 / up to 2(2N+1) entries).
-// Replaces the single-threaded CSC mul! inside IterativeSolvers (src/solver.jl:178-181).
+// pg_spmv.hip -- the dominant kernel of the path: y = A x for the reduced cut-cell system
+// (fp64 values, int32 column indices; rows in box order, 1 / 2N+1 / up to 2(2N+1) entries).
+// Replaces the single-threaded CSC mul! inside IterativeSolvers (src/solver.jl:178-181).  Roofline: HBM.
 //
-// Roofline: HBM.  Algorithmic bytes per launch = 12 nnz + 20 n; x (8 n bytes, 82 MB at 512^3)
-// is gathered out of L2 / Infinity Cache.
+// Three kernels, in the order they were written (PG_SPMV_VARIANT; profiles/r01_spmv_sweeps.txt, r01_spmv_slices.txt):
 //
-// Design (CDNA4): the rows are cut once per matrix into CHUNKS of <= 64 consecutive rows and <= 512 entries
-// (CsrMatrix::chunk_desc = {first row, first entry} per chunk, the row-block idea of CSR-Adaptive).  One WAVE
-// owns one chunk per iteration.  The chunk's val/col entries are one contiguous range of the CSR arrays; the wave
-// streams it with fully coalesced loads into its PRIVATE slice of LDS -- no block barrier anywhere, a wave
-// stalls only on its own loads -- and then lane l walks row l out of LDS: column indices, all x gathers issued
-// together, FMAs.  For a fixed stencil slot consecutive lanes gather consecutive x entries, so the gathers
-// coalesce too.
+//   1    k_spmv      plain CSR, a block of 256 rows staged through LDS, two block barriers per chunk (2.0 TB/s).
 //
-// Everything inside an iteration is branch-free with a FIXED number of vector-memory operations (clamped
-// indices + selects).  Reasons, all seen in the ISA / PMC (profiles/):
-//   (1) hipcc puts every predicated load in its own basic block behind `s_waitcnt vmcnt(0)`: the gathers serialise;
-//   (2) vector-memory operations retire in order, so overlapping the stream of chunk i+1 with the gathers of chunk
-//       i needs a COUNTED wait -- `s_waitcnt vmcnt(N)` lets the gathers complete while the N younger stream loads
-//       stay in flight -- and the compiler can only count when every path issues the same number of loads;
-//   (3) the chunk descriptor is a scalar load the stream addresses depend on: it is fetched TWO chunks ahead
-//       (3-stage software pipeline: descriptor(i+2) | stream(i+1) | gathers+FMA(i)), otherwise its latency sits in
-//       front of every stream (ablation: the kernel ran at the same 0.20 ms with the gathers removed).
+//   2|38 k_spmv_cw   plain CSR (12 nnz + 20 n bytes), the best a CSR stream can do here: 61 % of 8 TB/s back-to-back.
+//        The rows are cut once per matrix into CHUNKS of <= 64 consecutive rows and <= 508 entries (chunk_desc, the
+//        row-block idea of CSR-Adaptive).  One WAVE owns one chunk per iteration: it streams the chunk's contiguous
+//        val/col range with coalesced 16-byte loads into its PRIVATE slice of LDS -- no block barrier anywhere -- and
+//        lane l walks row l out of LDS: column indices, all x gathers issued together, FMAs.  Everything inside an
+//        iteration is branch-free with a FIXED number of vector-memory operations (clamped indices + selects):
+//        hipcc puts every predicated load in its own basic block behind `s_waitcnt vmcnt(0)`, and only when every
+//        path issues the same number of loads can it emit counted waits.  The chunk descriptor (a scalar load the
+//        stream addresses depend on) is fetched two chunks ahead.  +4 = non-temporal hint on the matrix stream.
 //
-// The dots that follow an SpMV in BiCGStab / CG are fused into the epilogue (one partial per block, summed in
-// fixed order by k_finalize: deterministic).
+//   70   k_spmv_s    stencil slices (default): see "stencil slices" below.  0.25 GB instead of 0.99 GB at 512^3.
 //
-// Variants (PG_SPMV_VARIANT; default = best measured, see profiles/):
-//   1   block of 256 rows staged through LDS, two block barriers per chunk     (first version, 2.0 TB/s)
-//   2   chunked, wave-private LDS slices, branch-free, no pipelining           (bit 1)
-//   +4  non-temporal hint on the matrix stream (read once; keeps x in L2 / Infinity Cache)
-//   +16 3-stage software pipeline inside the wave
-//   +32 16-byte (aligned pair / quad) stream loads
+// The dots that follow an SpMV in BiCGStab / CG are fused into the epilogue (one partial per block, summed in a fixed
+// order: deterministic); the slice kernel's last-arriving block can also evaluate the scalar phase (pg_spmv.h).
 #include <algorithm>
 #include <cstdlib>
 #include <thread>
 #include <vector>
 
 #include "pg_spmv.h"
-
-#ifndef PG_SPMV_ABLATE
-#define PG_SPMV_ABLATE 0   // diagnostics builds only (scripts/spmv_ablate.sh)
-#endif
 
 namespace pg {
 namespace {
@@ -109,7 +93,6 @@ __global__ __launch_bounds__(BLOCK) void k_spmv(i64 n, const int* __restrict__ r
 }
 
 // ---- chunked wave kernel ---------------------------------------------------------------------------------------
-constexpr int WITER = 8;                         // staging loads per lane: 512 slots >= SPMV_CHUNK_ENTRIES
 constexpr int WUNR = 8;                          // gathers issued together per row (bulk rows: 2N+1 <= 7)
 
 template <bool NT, class T>
@@ -130,134 +113,7 @@ __device__ inline Desc load_desc(const int* __restrict__ cd, i64 ch) {
   return d;
 }
 
-struct Stream {        // registers holding one chunk's raw loads
-  int ra, rb;          // this lane's row bounds, ABSOLUTE: nothing consumes them in the issue phase
-  double tv[WITER];
-  int tc[WITER];
-};
-
-// issue every vector load of a chunk -- always 2 + 2*WITER loads, branch-free, no dependent scalar load
-template <bool NT>
-__device__ inline void stream_issue(Stream& q, const Desc& d, const int* __restrict__ rowptr, const int* __restrict__ col,
-                                    const double* __restrict__ val, int lane) {
-  const int r = d.r0 + lane;
-  q.ra = stream_load<NT>(rowptr + (r < d.r1 ? r : d.r1));
-  q.rb = stream_load<NT>(rowptr + (r + 1 < d.r1 ? r + 1 : d.r1));
-  const int last = d.end - d.base > 0 ? d.end - d.base - 1 : 0;
-#pragma unroll
-  for (int j = 0; j < WITER; ++j) {
-    const int k = lane + 64 * j;
-    const int kk = k < last ? k : last;         // tail lanes re-read the last entry (one cache line)
-    q.tv[j] = stream_load<NT>(val + d.base + kk);
-    q.tc[j] = stream_load<NT>(col + d.base + kk);
-  }
-}
-
-template <int MODE, bool NT, bool PIPE>
-__global__ __launch_bounds__(BLOCK) void k_spmv_c(i64 n, i64 nchunks, const int* __restrict__ chunk_desc,
-                                                  const int* __restrict__ rowptr, const int* __restrict__ col,
-                                                  const double* __restrict__ val, const double* __restrict__ x,
-                                                  double* __restrict__ y, const double* __restrict__ aux,
-                                                  double* __restrict__ partials, const double* __restrict__ sc) {
-  __shared__ double s_val[BLOCK / 64][64 * WITER];
-  __shared__ int s_col[BLOCK / 64][64 * WITER];
-  __shared__ double s_red[BLOCK / 64];
-  if (sc && sc[S_DONE] != 0.0) return;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  double* __restrict__ sv = s_val[wave];
-  int* __restrict__ scl = s_col[wave];
-  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
-  const i64 first = (i64)blockIdx.x * (BLOCK / 64) + wave, wstride = (i64)gridDim.x * (BLOCK / 64);
-  const i64 lastc = nchunks - 1;
-  Stream q;
-  Desc dcur, dnext;
-  if (first < nchunks) {
-    dcur = load_desc(chunk_desc, first);
-    dnext = load_desc(chunk_desc, first + wstride < nchunks ? first + wstride : lastc);
-    if (PIPE) stream_issue<NT>(q, dcur, rowptr, col, val, lane);
-  }
-  for (i64 chunk = first; chunk < nchunks; chunk += wstride) {
-    if (!PIPE) stream_issue<NT>(q, dcur, rowptr, col, val, lane);
-    const int r = dcur.r0 + lane;
-    const bool live = r < dcur.r1;
-    const int a = q.ra - dcur.base, b = q.rb - dcur.base;
-#if PG_SPMV_ABLATE == 3
-    // ablation: stream only -- no LDS, no gathers: consume the registers directly
-    double sum3 = 0.0;
-#pragma unroll
-    for (int j = 0; j < WITER; ++j) sum3 += q.tv[j] * (double)q.tc[j];
-    const i64 c23 = chunk + 2 * wstride;
-    const Desc dn23 = load_desc(chunk_desc, c23 < nchunks ? c23 : lastc);
-    if (PIPE) stream_issue<NT>(q, dnext, rowptr, col, val, lane);
-    if (live) y[r] = sum3 + a + b;
-    dcur = dnext;
-    dnext = dn23;
-    continue;
-#endif
-    // stream -> LDS slice (fixed 2*WITER stores; slots past the chunk hold copies of its last entry)
-#pragma unroll
-    for (int j = 0; j < WITER; ++j) {
-      sv[lane + 64 * j] = q.tv[j];
-      scl[lane + 64 * j] = q.tc[j];
-    }
-    __builtin_amdgcn_wave_barrier();
-    double xv[WUNR], vv[WUNR];
-#pragma unroll
-    for (int j = 0; j < WUNR; ++j) {
-      const int p = a + j < b ? a + j : 0;      // slot 0 always holds a valid column
-#if PG_SPMV_ABLATE == 1
-      xv[j] = 1.0 + p;                          // ablation: no gathers
-#elif PG_SPMV_ABLATE == 2
-      xv[j] = x[scl[p] & 1023];                 // ablation: gathers always hit L1/L2
-#else
-      xv[j] = x[scl[p]];
-#endif
-      vv[j] = a + j < b ? sv[p] : 0.0;
-    }
-    // stage 1 of the NEXT iteration and stage 0 of the one after: both behind this chunk's gathers
-    const i64 c2 = chunk + 2 * wstride;
-    const Desc dnext2 = load_desc(chunk_desc, c2 < nchunks ? c2 : lastc);
-    if (PIPE) stream_issue<NT>(q, dnext, rowptr, col, val, lane);   // counted vmcnt keeps these in flight
-    double sum = 0.0;
-#pragma unroll
-    for (int j = 0; j < WUNR; ++j) sum += vv[j] * xv[j];
-    if (__builtin_expect(b - a > WUNR, 0))
-      for (int k = a + WUNR; k < b; ++k) sum += sv[k] * x[scl[k]];   // cut-cell rows (> 8 entries)
-    __builtin_amdgcn_wave_barrier();
-    if (live) {
-#if PG_SPMV_ABLATE == 4
-      if (sum == 1.2345e-300) y[r] = sum;   // ablation: no y store
-#elif PG_SPMV_ABLATE == 5
-      __builtin_nontemporal_store(sum, &y[r]);
-#else
-      y[r] = sum;
-#endif
-      if (MODE == 1) acc0 += aux[r] * sum;
-      if (MODE >= 2) {
-        acc0 += sum * x[r];
-        acc1 += sum * sum;
-      }
-      if (MODE == 3) acc2 += aux[r] * sum;
-    }
-    dcur = dnext;
-    dnext = dnext2;
-  }
-  if (MODE >= 1) {
-    const double t0 = block_sum(acc0, s_red);
-    if (threadIdx.x == 0) partials[blockIdx.x] = t0;
-  }
-  if (MODE >= 2) {
-    const double t1 = block_sum(acc1, s_red);
-    if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = t1;
-  }
-  if (MODE == 3) {
-    const double t2 = block_sum(acc2, s_red);
-    if (threadIdx.x == 0) partials[4 * (size_t)gridDim.x + blockIdx.x] = t2;
-  }
-}
-
-// ---- same kernel with 16-byte stream loads (bit 32) ------------------------------------------------------------
+// ---- chunked CSR kernel, 16-byte stream loads ---------------------------------------------------------------------
 // values are read as aligned pairs of doubles starting at base & ~1, columns as aligned quads of ints starting at
 // base & ~3 (1 KiB per wave instruction, the widest coalesced access; 6 instead of 16 stream instructions per
 // chunk); the LDS image keeps the same shift.  Chunks hold <= 508 entries so the shifted image fits 512 slots;
@@ -295,7 +151,7 @@ __device__ inline void stream_issue_w(StreamW& q, const Desc& d, const int* __re
   }
 }
 
-template <int MODE, bool NT, bool PIPE>
+template <int MODE, bool NT>
 __global__ __launch_bounds__(BLOCK) void k_spmv_cw(i64 n, i64 nchunks, const int* __restrict__ chunk_desc,
                                                    const int* __restrict__ rowptr, const int* __restrict__ col,
                                                    const double* __restrict__ val, const double* __restrict__ x,
@@ -319,10 +175,9 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_cw(i64 n, i64 nchunks, const int
   if (first < nchunks) {
     dcur = load_desc(chunk_desc, first);
     dnext = load_desc(chunk_desc, first + wstride < nchunks ? first + wstride : lastc);
-    if (PIPE) stream_issue_w<NT>(q, dcur, rowptr, col, val, lane);
   }
   for (i64 chunk = first; chunk < nchunks; chunk += wstride) {
-    if (!PIPE) stream_issue_w<NT>(q, dcur, rowptr, col, val, lane);
+    stream_issue_w<NT>(q, dcur, rowptr, col, val, lane);
     const int r = dcur.r0 + lane;
     const bool live = r < dcur.r1;
     const int basev = dcur.base & ~1, basec = dcur.base & ~3;
@@ -342,7 +197,6 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_cw(i64 n, i64 nchunks, const int
     }
     const i64 c2 = chunk + 2 * wstride;
     const Desc dnext2 = load_desc(chunk_desc, c2 < nchunks ? c2 : lastc);
-    if (PIPE) stream_issue_w<NT>(q, dnext, rowptr, col, val, lane);
     double sum = 0.0;
 #pragma unroll
     for (int j = 0; j < WUNR; ++j) sum += vv[j] * xv[j];
@@ -705,8 +559,7 @@ __global__ void k_fill_records(i64 nslices, int* __restrict__ srec, const int* _
 }
 
 int variant() {
-  // default 70 = stencil slices + non-temporal streams.  38 = chunked CSR + non-temporal + 16-byte stream loads (the
-  // best plain-CSR kernel; pipelining measured neutral: profiles/r01_spmv_sweeps.txt)
+  // default 70 = stencil slices + non-temporal streams; 38 = the chunked CSR kernel + non-temporal streams; 1 = first kernel
   static const int v = getenv("PG_SPMV_VARIANT") ? atoi(getenv("PG_SPMV_VARIANT")) : 70;
   return v;
 }
@@ -744,18 +597,9 @@ bool launch_mode(int v, const CsrMatrix& A, const double* x, double* y, const do
                        aux, partials, sc);
     return false;
   }
-  const bool nt = (v & 4) != 0, pipe = (v & 16) != 0;
-  if (v & 32) {
-    if (nt && pipe) PG_LAUNCH_C((k_spmv_cw<MODE, true, true>));
-    else if (nt) PG_LAUNCH_C((k_spmv_cw<MODE, true, false>));
-    else if (pipe) PG_LAUNCH_C((k_spmv_cw<MODE, false, true>));
-    else PG_LAUNCH_C((k_spmv_cw<MODE, false, false>));
-    return false;
-  }
-  if (nt && pipe) PG_LAUNCH_C((k_spmv_c<MODE, true, true>));
-  else if (nt) PG_LAUNCH_C((k_spmv_c<MODE, true, false>));
-  else if (pipe) PG_LAUNCH_C((k_spmv_c<MODE, false, true>));
-  else PG_LAUNCH_C((k_spmv_c<MODE, false, false>));
+  // every other variant: the chunked CSR kernel (bit 2), with (bit 4) or without the non-temporal stream hint
+  if (v & 4) PG_LAUNCH_C((k_spmv_cw<MODE, true>));
+  else PG_LAUNCH_C((k_spmv_cw<MODE, false>));
   return false;
 }
 
