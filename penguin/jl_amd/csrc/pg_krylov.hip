@@ -51,6 +51,9 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_init(i64 n, i64 nvec, const doub
 
 // s = r - αv written over r (r is not needed again: r_new = s - ωt); partials slots 2, 3 = (r̂,s), (s,s): they are
 // summed together with the dots of the SpMV that follows (one scalar kernel instead of two)
+// NTV: stream hints on the vectors that are dead after this kernel (v here; x, t, v in k_bicg_xrp), so that they do not
+// push the SpMV's matrix data (records, packed irregular rows: ~90 MB) out of the 256 MB Infinity Cache between launches
+template <bool NTV>
 __global__ __launch_bounds__(BLOCK) void k_bicg_s(i64 n, const double* __restrict__ sc, const double* __restrict__ v,
                                                   const double* __restrict__ rhat, double* __restrict__ r,
                                                   double* __restrict__ partials) {
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_s(i64 n, const double* __restric
   const double alpha = sc[S_ALPHA];
   double a0 = 0.0, a1 = 0.0;
   for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) {
-    const double si = r[i] - alpha * v[i];
+    const double si = r[i] - alpha * (NTV ? __builtin_nontemporal_load(v + i) : v[i]);
     r[i] = si;
     a0 += rhat[i] * si;
     a1 += si * si;
@@ -73,6 +76,7 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_s(i64 n, const double* __restric
 // x += αp + ωs;  r = s - ωt;  p = r + β(p - ωv)  (restart: p = r̂ = r);  partial slot 1 = (r,r).
 // β is known before r exists because ρ_new = (r̂,r) = (r̂,s) - ω(r̂,t) comes out of the dots of k_bicg_s and of the
 // second SpMV: the classical p-update kernel (4 vector passes) and one scalar kernel per iteration disappear.
+template <bool NTV>
 __global__ __launch_bounds__(BLOCK) void k_bicg_xrp(i64 n, double* sc, const double* __restrict__ t,
                                                     const double* __restrict__ v, double* __restrict__ x,
                                                     double* __restrict__ r, double* __restrict__ p,
@@ -84,14 +88,15 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_xrp(i64 n, double* sc, const dou
   double a0 = 0.0;
   for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) {
     const double si = r[i], pi = p[i];
-    x[i] = x[i] + alpha * pi + omega * si;
-    const double ri = si - omega * t[i];
+    const double xi = (NTV ? __builtin_nontemporal_load(x + i) : x[i]) + alpha * pi + omega * si;
+    if (NTV) __builtin_nontemporal_store(xi, x + i); else x[i] = xi;
+    const double ri = si - omega * (NTV ? __builtin_nontemporal_load(t + i) : t[i]);
     r[i] = ri;
     if (restart) {
       p[i] = ri;
       rhat[i] = ri;
     } else {
-      p[i] = ri + beta * (pi - omega * v[i]);
+      p[i] = ri + beta * (pi - omega * (NTV ? __builtin_nontemporal_load(v + i) : v[i]));
     }
     a0 += ri * ri;
   }
@@ -274,6 +279,7 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
   SpmvTimer timer(cx.profiling);
 
   const bool cg = opts.method == PG_METHOD_CG;
+  static const bool ntv = getenv("PG_KRYLOV_NT") ? atoi(getenv("PG_KRYLOV_NT")) != 0 : true;
   PG_REQUIRE(!preinit || !cg, "preinit is a BiCGStab path");
   if (!cg) {
     if (!preinit)
@@ -308,15 +314,16 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
         timer.end(st);
         // previous iteration's (r,r): convergence / restart; then α
         if (folded1) finalize_folded(PH_BICG_1, 2, w, st); else finalize(PH_BICG_1, 2, w, st, true);
-        hipLaunchKernelGGL(k_bicg_s, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p);
+        if (ntv) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_s<true>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_s<false>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p);
         if (A.halo_needed) halo_exchange(nb, slab, w.r.p, st);                                          // r now holds s
         timer.begin(st, launched + it);
         const FinArgs f2{w.ticket.p, w.sc.p, PH_BICG_2, 5, derive_here};
         const bool folded2 = launch_spmv(3, A, w.r.p, w.t.p, w.rhat.p, w.partials.p, w.sc.p, G, st, &f2);   // t = Â s, (t,s), (t,t), (r̂,t)
         timer.end(st);
         if (folded2) finalize_folded(PH_BICG_2, 5, w, st); else finalize(PH_BICG_2, 5, w, st, true);   // ω, ρ, β / restart
-        hipLaunchKernelGGL(k_bicg_xrp, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.t.p, w.v.p, x, w.r.p, w.p.p, w.rhat.p,
-                           w.partials.p);
+        if (ntv) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_xrp<true>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.t.p, w.v.p, x, w.r.p, w.p.p, w.rhat.p, w.partials.p);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_xrp<false>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.t.p, w.v.p, x, w.r.p, w.p.p, w.rhat.p, w.partials.p);
       } else {
         if (A.halo_needed) halo_exchange(nb, slab, w.p.p, st);
         timer.begin(st, launched + it);

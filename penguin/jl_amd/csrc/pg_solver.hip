@@ -983,17 +983,24 @@ int32_t pg_solver_time_spmv(pg_solver* s, int32_t which, int32_t reps, double* a
   PG_API_BEGIN
   require_init();
   PG_REQUIRE(s && avg_ms && reps > 0, "pg_solver_time_spmv: bad arguments");
-  if (which == 1) PG_REQUIRE(s->have_run, "run matrix not assembled yet");
-  const CsrMatrix& A = which == 0 ? s->A_ctor : run_matrix(s);
+  const int sel = which & 1, mode = (which >> 4) & 3;   // bits 4-5: fused-dot mode of the launch (0 plain, 1, 2, 3)
+  if (sel == 1) PG_REQUIRE(s->have_run, "run matrix not assembled yet");
+  const CsrMatrix& A = sel == 0 ? s->A_ctor : run_matrix(s);
   hipStream_t st = ctx().stream;
   hipEvent_t e0, e1;
   PG_HIP(hipEventCreate(&e0));
   PG_HIP(hipEventCreate(&e1));
-  for (int i = 0; i < 3; ++i) spmv(A, s->z.p, s->y.p, st);
+  KrylovWork& w = s->work;
+  auto one = [&]() {
+    if (mode == 0) spmv(A, s->z.p, s->y.p, st);
+    else launch_spmv(mode, A, s->z.p, s->y.p, w.rhat.p, w.partials.p, nullptr, w.grid, st);
+  };
+  for (int i = 0; i < 3; ++i) one();
   PG_HIP(hipEventRecord(e0, st));
-  for (int i = 0; i < reps; ++i) spmv(A, s->z.p, s->y.p, st);
+  for (int i = 0; i < reps; ++i) one();
   PG_HIP(hipEventRecord(e1, st));
   PG_HIP(hipEventSynchronize(e1));
+  PG_HIP(hipGetLastError());
   float ms = 0.f;
   PG_HIP(hipEventElapsedTime(&ms, e0, e1));
   (void)hipEventDestroy(e0);

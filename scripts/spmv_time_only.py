@@ -13,6 +13,8 @@ s = pj.DiffusionUnsteadyMono(ph, bcb, pj.Dirichlet(1.0), 0.75 * (4.0 / n) ** 2, 
 info = s.system_info(0)
 b = 12 * info.nnz + 20 * info.n_own
 ms = C.c_double()
-for rep in range(3):
-    L.check(L.lib().pg_solver_time_spmv(s._h, 0, 50, C.byref(ms)))
-    print(f"spmv {ms.value:.4f} ms = {b/ms.value/1e6:.0f} GB/s ({b/ms.value/1e6/80:.1f}% of 8 TB/s)", flush=True)
+import os
+for mode in [int(m) for m in os.environ.get("PG_TIME_MODES", "0").split(",")]:
+    for rep in range(2):
+        L.check(L.lib().pg_solver_time_spmv(s._h, 0 | (mode << 4), 50, C.byref(ms)))
+        print(f"spmv mode {mode} {ms.value:.4f} ms = {b/ms.value/1e6:.0f} GB/s ({b/ms.value/1e6/80:.1f}% of 8 TB/s)", flush=True)
