@@ -218,17 +218,21 @@ __global__ __launch_bounds__(BLOCK) void k_rhs_init(i64 n, i64 nvec, int scheme,
   double acc = 0.0, accb = 0.0;
   for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < nvec; i += (i64)gridDim.x * BLOCK) {
     if (i < n) {
+      // (stream hints: the per-row data is read once per step and b̂ is only kept for inspection -- neither should
+      //  displace the SpMV's matrix data from the Infinity Cache)
       double bi;
+      const double yh = __builtin_nontemporal_load(yhat + i);
       if (isblk[i]) {
         bi = b[i];
       } else {
-        const double d = ds[i];
-        if (fixed[i]) bi = d * bconst[i];
-        else if (scheme == PG_SCHEME_CN) bi = d * (2.0 * (mass[i] * (d * z[i])) + bconst[i]) - yhat[i];
-        else bi = d * (mass[i] * (d * z[i]) + bconst[i]);
-        b[i] = bi;
+        const double d = __builtin_nontemporal_load(ds + i), bc = __builtin_nontemporal_load(bconst + i);
+        const double ms = __builtin_nontemporal_load(mass + i);
+        if (fixed[i]) bi = d * bc;
+        else if (scheme == PG_SCHEME_CN) bi = d * (2.0 * (ms * (d * z[i])) + bc) - yh;
+        else bi = d * (ms * (d * z[i]) + bc);
+        __builtin_nontemporal_store(bi, b + i);
       }
-      const double ri = bi - yhat[i];
+      const double ri = bi - yh;
       r[i] = ri; rhat[i] = ri; p[i] = ri;
       acc += ri * ri;
       accb += bi * bi;
