@@ -1,18 +1,18 @@
 // pg_krylov.hip -- K11 of SURVEY.md section 2.3: the Krylov inner loop of solve_system! (src/solver.jl:158-188)
 //
 //   reference (IterativeSolvers 0.9.4, single thread)          here
-//   CSC mul!                                                   k_spmv: CSR row blocks staged through LDS
-//   dot / axpy! / norm (OpenBLAS BLAS-1)                       fused update+dot kernels, wave64 reductions
-//   method(A_reduced, b_reduced; kwargs...)                    device-resident BiCGStab / CG: all scalars stay
-//                                                              on the GPU, the host polls a done flag every
-//                                                              `check_every` iterations (no per-iteration sync)
+//   CSC mul!                                                   pg_spmv.hip (stencil slices; dots fused into the launch)
+//   dot / axpy! / norm (OpenBLAS BLAS-1)                       two fused vector kernels per BiCGStab iteration
+//   method(A_reduced, b_reduced; kwargs...)                    device-resident BiCGStab / CG: all scalars stay on the
+//                                                              GPU; the host polls a done flag between batches of
+//                                                              queued iterations (no per-iteration sync)
 //
-// SpMV design (CDNA4): a 256-thread block owns 256 consecutive rows.  Their val/col entries are one
-// contiguous range of the CSR arrays, streamed into LDS with fully coalesced loads (the matrix is read
-// exactly once: 12 B/nnz); then thread t walks row t out of LDS and gathers x[col].  Because rows are in
-// box order, for a fixed stencil slot consecutive threads read consecutive x entries, so the gathers
-// coalesce and hit L2 / Infinity Cache (x = 8 B x n fits the 256 MB MALL at 512^3).  The dots that follow
-// an SpMV in BiCGStab / CG are fused into its epilogue.
+// One BiCGStab iteration = 4 launches on one rank:
+//   SpMV (v = Â p, (r̂,v); its last block evaluates: previous iteration's (r,r) -> convergence / restart, then α)
+//   k_bicg_s   (s = r - αv over r; (r̂,s), (s,s))
+//   SpMV (t = Â s, (t,s), (t,t), (r̂,t); last block: ω, ρ' = (r̂,s) - ω(r̂,t), β / restart decision)
+//   k_bicg_xrp (x += αp + ωs; r = s - ωt; p = r + β(p - ωv); (r,r))
+// With several ranks the SpMV's last block leaves the local sums, an RCCL all-reduce and k_derive follow.
 #include "pg_krylov.h"
 #include "pg_spmv.h"
 
