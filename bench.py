@@ -59,22 +59,32 @@ def main() -> None:
     import torch.distributed as dist
 
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-
     import penguin.jl_amd as pj
     from penguin.jl_amd import _lib as L
 
-    if world > 1:
-        box = [pj.get_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        pj.init_distributed(local_rank, rank, world, box[0])
-    elif os.environ.get("PG_TEST_RCCL"):
-        # 1-rank RCCL communicator: exercises ncclCommInitRank / ncclAllReduce on a 1-GPU box
-        pj.init_distributed(local_rank, 0, 1, pj.get_unique_id())
-    else:
-        pj.init(local_rank)
+    # RCCL prints a version banner on STDOUT the first time a communicator is created on a box; stdout is reserved for
+    # the one JSON line, so fd 1 points at stderr while the communicators come up
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            box = [pj.get_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            pj.init_distributed(local_rank, rank, world, box[0])
+            dist.barrier()
+        elif os.environ.get("PG_TEST_RCCL"):
+            # 1-rank RCCL communicator: exercises ncclCommInitRank / ncclAllReduce on a 1-GPU box
+            pj.init_distributed(local_rank, 0, 1, pj.get_unique_id())
+        else:
+            pj.init(local_rank)
+        torch.cuda.synchronize()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
     lib = L.lib()
 
     # ---------------------------------------------------------------- workload (synthetic, deterministic)
