@@ -50,7 +50,8 @@ enum { PG_KEY_LEFT = 0 /* dim2 = 1 */, PG_KEY_RIGHT = 1 /* dim2 = n2 */, PG_KEY_
        PG_KEY_TOP = 3 /* dim1 = n1 */, PG_KEY_BACKWARD = 4 /* dim3 = 1 */, PG_KEY_FORWARD = 5 /* dim3 = n3 */ };
 enum { PG_SCHEME_BE = 0, PG_SCHEME_CN = 1,                   /* "BE" / "CN" strings of the reference */
        PG_SCHEME_STEADY = 2 };                                /* internal: the steady constructors */
-enum { PG_METHOD_BICGSTAB = 0, PG_METHOD_CG = 1 };           /* IterativeSolvers methods kept     */
+enum { PG_METHOD_BICGSTAB = 0, PG_METHOD_CG = 1, PG_METHOD_GMRES = 2 };   /* IterativeSolvers methods kept:
+   bicgstab (also serves `\` and bicgstabl), cg, gmres (solve_system!'s default, src/solver.jl:158) */
 
 /* ---- plain structs ------------------------------------------------------------------- */
 typedef struct {
@@ -82,6 +83,7 @@ typedef struct {
   int32_t check_every; /* host convergence poll period in iterations (<=0: default 4) */
   int32_t warm_start;  /* != 0: pg_solver_step starts BiCGStab from the previous time level instead of zero
                           (IterativeSolvers starts from zero; same solution to reltol, fewer iterations) */
+  int32_t restart;     /* GMRES only: Krylov vectors per restart cycle (<= 0: 20, IterativeSolvers' default) */
 } pg_krylov_opts;
 
 typedef struct {
@@ -242,12 +244,15 @@ int32_t pg_debug_spmv_compare(pg_solver* s, int32_t which, int32_t variant_a, in
 int32_t pg_debug_read_probe(int64_t bytes, int32_t elem_bytes, int32_t nt, int32_t blocks, int32_t reps, double* gbs);
 /* run the slab-decomposed monophasic path with `nranks` VIRTUAL ranks (host threads sharing this GPU, in-process
    halo exchange / all-reduce standing in for RCCL): Dirichlet(interface_value) on the body, Dirichlet(border_value)
-   on `keys`, T0 = 0, initial solve with scheme_ctor then `steps` steps with scheme_run.  x_out: 2M. */
+   on `keys`, T0 = 0, initial solve with scheme_ctor then `steps` steps with scheme_run.  x_out: 2M, or NULL (full-size
+   rehearsals: sizes and iteration counts only). */
 int32_t pg_debug_run_virtual_ranks(int32_t nranks, int32_t N, const int64_t* n, const double* L, int32_t body_kind,
                                    const double* params, int32_t nparams, double interface_value, double border_value,
                                    int32_t nkeys, const int32_t* keys, double dt, int32_t scheme_ctor, int32_t scheme_run,
                                    int64_t steps, double* x_out, int64_t* n_own_out, int64_t* nnz_out,
                                    int64_t* n_ghost_out, int64_t* iters_out);
+/* Krylov method (PG_METHOD_*) and GMRES restart length of the virtual-rank runs that follow (default BiCGStab) */
+int32_t pg_debug_set_virtual_rank_method(int32_t method, int32_t restart);
 
 #ifdef __cplusplus
 }

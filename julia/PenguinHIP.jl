@@ -184,7 +184,13 @@ end
 # ---------------------------------------------------------------------------------- Solver (src/solver.jl:33-42)
 struct pg_bc_desc; kind::Int32; alpha::Float64; beta::Float64; value::Float64; value_array::Ptr{Float64}; end
 struct pg_border_desc; key::Int32; kind::Int32; value::Float64; end
-struct pg_krylov_opts; method::Int32; reltol::Float64; abstol::Float64; maxiter::Int32; check_every::Int32; warm_start::Int32; end
+struct pg_krylov_opts; method::Int32; reltol::Float64; abstol::Float64; maxiter::Int32; check_every::Int32; warm_start::Int32; restart::Int32; end
+# method kwarg -> PG_METHOD_*: :cg / IterativeSolvers.cg -> 1, :gmres / IterativeSolvers.gmres -> 2 (restarted GMRES on the device),
+# everything else (`\`, bicgstabl, nothing) -> 0 = BiCGStab run to reltol
+function _method_id(m)
+    n = m isa Symbol ? String(m) : (m isa Function ? String(nameof(m)) : "")
+    n == "cg" ? Int32(1) : (n == "gmres" ? Int32(2) : Int32(0))
+end
 mutable struct pg_step_info; iters::Int32; converged::Int32; resnorm::Float64; bnorm::Float64; extremum::Float64; time::Float64
     pg_step_info() = new(0, 0, 0.0, 0.0, 0.0, 0.0); end
 const KEYS = Dict(:left => 0, :right => 1, :bottom => 2, :top => 3, :backward => 4, :forward => 5)
@@ -233,7 +239,7 @@ function solve_DiffusionUnsteadyMono!(s::Solver, phase::Phase, Î”t::Float64, Tâ‚
                                       method=nothing, algorithm=nothing, kwargs...)
     s.handle == C_NULL && error("Solver is not initialized. Call a solver constructor first.")
     kw = (; kwargs...)
-    opts = Ref(pg_krylov_opts(method === :cg ? 1 : 0, get(kw, :reltol, 1e-12), get(kw, :abstol, 0.0), get(kw, :maxiter, 0), 4, get(kw, :warm_start, true) ? 1 : 0))
+    opts = Ref(pg_krylov_opts(_method_id(method), get(kw, :reltol, 1e-12), get(kw, :abstol, 0.0), get(kw, :maxiter, 0), 4, get(kw, :warm_start, true) ? 1 : 0, get(kw, :restart, 0)))
     info = pg_step_info()
     t = 0.0
     check(ccall((:pg_solver_initial_solve, libpg), Int32, (Ptr{Cvoid}, Ptr{pg_krylov_opts}, Ref{pg_step_info}), s.handle, opts, info))
@@ -284,7 +290,7 @@ function solve_DiffusionSteadyMono!(s::Solver; method=nothing, algorithm=nothing
     s.handle == C_NULL && error("Solver is not initialized. Call a solver constructor first.")
     println("Solving the system:"); println("- Monophasic problem"); println("- Steady problem"); println("- Diffusion problem")
     kw = (; kwargs...)
-    opts = Ref(pg_krylov_opts(method === :cg ? 1 : 0, get(kw, :reltol, 1e-12), get(kw, :abstol, 0.0), get(kw, :maxiter, 0), 4, 0))
+    opts = Ref(pg_krylov_opts(_method_id(method), get(kw, :reltol, 1e-12), get(kw, :abstol, 0.0), get(kw, :maxiter, 0), 4, 0, get(kw, :restart, 0)))
     info = pg_step_info()
     check(ccall((:pg_solver_initial_solve, libpg), Int32, (Ptr{Cvoid}, Ptr{pg_krylov_opts}, Ref{pg_step_info}), s.handle, opts, info))
     s.x = _state(s)

@@ -492,9 +492,69 @@ def cg_ref(A: sp.csr_matrix, b: np.ndarray, reltol: float = 1e-12, abstol: float
     return x, it, math.sqrt(rr)
 
 
+def gmres_ref(A: sp.csr_matrix, b: np.ndarray, reltol: float = 1e-12, abstol: float = 0.0, restart: int = 20,
+              maxiter: int = 10000):
+    """Restarted GMRES as IterativeSolvers 0.9.4 `gmres` runs it (the default `method` of solve_system!,
+    src/solver.jl:158): zero initial guess, Arnoldi with modified Gram-Schmidt, Givens rotations, convergence on the
+    rotated residual estimate |g_{j+1}| <= max(reltol*||r0||, abstol), true residual recomputed at every restart.
+    IterativeSolvers is not vendored: this follows the published algorithm (Saad & Schultz 1986); the solution is
+    checked against scipy's gmres and the direct solve in tests/test_oracle_pins.py.  pg_gmres.hip orthogonalises with
+    classical Gram-Schmidt applied twice instead (one fused multi-dot per pass); counts agree to +-1."""
+    n = A.shape[0]
+    m = max(1, min(restart, n))
+    x = np.zeros(n)
+    r = b.copy()
+    beta = np.linalg.norm(r)
+    tol = max(reltol * beta, abstol)
+    it = 0
+    res = beta
+    while it < maxiter:
+        if res <= tol or beta == 0.0:
+            break
+        V = np.zeros((m + 1, n))
+        H = np.zeros((m + 1, m))
+        cs, sn, g = np.zeros(m), np.zeros(m), np.zeros(m + 1)
+        V[0] = r / beta
+        g[0] = beta
+        J = 0
+        for j in range(m):
+            if it >= maxiter:
+                break
+            w = A @ V[j]
+            for i in range(j + 1):
+                H[i, j] = V[i] @ w
+                w = w - H[i, j] * V[i]
+            hn = np.linalg.norm(w)
+            H[j + 1, j] = hn
+            for i in range(j):
+                a, c = H[i, j], H[i + 1, j]
+                H[i, j], H[i + 1, j] = cs[i] * a + sn[i] * c, -sn[i] * a + cs[i] * c
+            d = math.hypot(H[j, j], hn)
+            it += 1
+            if d == 0.0:
+                break
+            cs[j], sn[j] = H[j, j] / d, hn / d
+            H[j, j], H[j + 1, j] = d, 0.0
+            g[j + 1] = -sn[j] * g[j]
+            g[j] = cs[j] * g[j]
+            J = j + 1
+            res = abs(g[j + 1])
+            if res <= tol or hn == 0.0:
+                break
+            V[j + 1] = w / hn
+        if J > 0:
+            y = np.linalg.solve(np.triu(H[:J, :J]), g[:J])
+            x = x + V[:J].T @ y
+        if res <= tol or J == 0:
+            break
+        r = b - A @ x
+        beta = res = np.linalg.norm(r)
+    return x, it, res
+
+
 def solve_system(s: Solver, method: str = "\\", **kwargs):
     """src/solver.jl:158-188.  method "\\" = direct LU (UMFPACK in the reference, SuperLU
-    here), "bicgstab" / "cg" = the Krylov restatements above."""
+    here), "bicgstab" / "cg" / "gmres" = the Krylov restatements above."""
     n = s.A.shape[0]
     Ar, br, idx = remove_zero_rows_cols(s.A, s.b)  # :163
     if method == "\\":
@@ -504,6 +564,8 @@ def solve_system(s: Solver, method: str = "\\", **kwargs):
         xr, its, _ = bicgstab_ref(Ar, br, **kwargs)
     elif method == "cg":
         xr, its, _ = cg_ref(Ar, br, **kwargs)
+    elif method == "gmres":
+        xr, its, _ = gmres_ref(Ar, br, **kwargs)
     else:
         raise ValueError(f"unknown method {method}")
     s.x = np.zeros(n)  # :186

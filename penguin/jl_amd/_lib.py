@@ -30,7 +30,7 @@ PG_OP_C0, PG_OP_K0 = 3, 6            # ConvectionOps: C_d = PG_OP_C0 + d, K_d = 
 PG_BC_NONE, PG_BC_DIRICHLET, PG_BC_NEUMANN, PG_BC_ROBIN, PG_BC_PERIODIC = 0, 1, 2, 3, 4
 PG_KEY = {"left": 0, "right": 1, "bottom": 2, "top": 3, "backward": 4, "forward": 5}
 PG_SCHEME = {"BE": 0, "CN": 1, "STEADY": 2}
-PG_METHOD = {"bicgstab": 0, "cg": 1}
+PG_METHOD = {"bicgstab": 0, "cg": 1, "gmres": 2}
 
 c_double_p = C.POINTER(C.c_double)
 c_i64_p = C.POINTER(C.c_int64)
@@ -53,7 +53,7 @@ class pg_jump_desc(C.Structure):
 
 class pg_krylov_opts(C.Structure):
     _fields_ = [("method", C.c_int32), ("reltol", C.c_double), ("abstol", C.c_double), ("maxiter", C.c_int32),
-                ("check_every", C.c_int32), ("warm_start", C.c_int32)]
+                ("check_every", C.c_int32), ("warm_start", C.c_int32), ("restart", C.c_int32)]
 
 
 class pg_step_info(C.Structure):

@@ -616,15 +616,15 @@ def _border_values(bc_b: BorderConditions, mesh: Mesh, t: Optional[float]) -> np
 
 
 def _krylov_opts(method, kwargs) -> L.pg_krylov_opts:
-    """method may be "bicgstab" / "cg" or a callable named like IterativeSolvers' (bicgstabl, cg, gmres...).
-    The reference's default (gmres) and `\\` are served by BiCGStab run to reltol (default 1e-12: the parity
-    target is the direct-solve path)."""
+    """method may be "bicgstab" / "cg" / "gmres" or a callable named like IterativeSolvers' (bicgstabl, cg, gmres...).
+    gmres -> restarted GMRES on the device (restart kwarg, default 20); cg -> CG; `\\`, bicgstabl and anything else ->
+    BiCGStab.  reltol defaults to 1e-12: the parity target is the direct-solve path."""
     name = method if isinstance(method, str) else getattr(method, "__name__", "bicgstab")
     name = name.lower()
-    m = L.PG_METHOD["cg"] if name == "cg" else L.PG_METHOD["bicgstab"]
+    m = L.PG_METHOD.get(name, L.PG_METHOD["bicgstab"])
     return L.pg_krylov_opts(m, float(kwargs.get("reltol", 1e-12)), float(kwargs.get("abstol", 0.0)),
                             int(kwargs.get("maxiter", 0)), int(kwargs.get("check_every", 4)),
-                            int(bool(kwargs.get("warm_start", True))))
+                            int(bool(kwargs.get("warm_start", True))), int(kwargs.get("restart", 0)))
 
 
 def DiffusionUnsteadyMono(phase: Phase, bc_b: BorderConditions, bc_i, Δt: float, Tᵢ: np.ndarray, scheme: str,

@@ -38,6 +38,9 @@ struct VArgs {
   int64_t* iters_out;
 };
 
+// Krylov method of the virtual-rank runs (pg_debug_set_virtual_rank_method): BiCGStab unless a test asks otherwise
+int g_method = PG_METHOD_BICGSTAB, g_restart = 0;
+
 void check(int32_t st, const char* what) {
   if (st != 0) {
     char buf[1024];
@@ -77,7 +80,7 @@ void rank_main(const VArgs& a, int rank, LocalComm* lc, int device, std::string*
     std::vector<double> T0(a.x_out ? 2 * M : 0, 0.0);
     check(pg_solver_create_unsteady_mono(cap, ops, &bc, borders.data(), a.nkeys, nullptr, nullptr, a.dt,
                                          a.x_out ? T0.data() : nullptr, a.scheme_ctor, &sol), "solver");
-    pg_krylov_opts o{PG_METHOD_BICGSTAB, 1e-13, 0.0, 0, 4};
+    pg_krylov_opts o{g_method, 1e-13, 0.0, 0, 4, g_method == PG_METHOD_BICGSTAB ? 1 : 0, g_restart};
     pg_run_info info{};
     check(pg_solver_run(sol, 1e300, a.scheme_run, &o, 1, a.steps, 0, &info), "run");
     pg_system_info si{};
@@ -104,6 +107,14 @@ void rank_main(const VArgs& a, int rank, LocalComm* lc, int device, std::string*
 }
 
 }  // namespace
+
+extern "C" int32_t pg_debug_set_virtual_rank_method(int32_t method, int32_t restart) {
+  PG_API_BEGIN
+  PG_REQUIRE(method == PG_METHOD_BICGSTAB || method == PG_METHOD_CG || method == PG_METHOD_GMRES, "unknown Krylov method");
+  g_method = method;
+  g_restart = restart;
+  PG_API_END
+}
 
 extern "C" int32_t pg_debug_run_virtual_ranks(int32_t nranks, int32_t N, const int64_t* n, const double* L, int32_t body_kind,
                                               const double* params, int32_t nparams, double interface_value,

@@ -1,0 +1,299 @@
+// pg_gmres.hip -- restarted GMRES(m) on the device: `method = IterativeSolvers.gmres`, the DEFAULT of the reference's
+// solve_system! (src/solver.jl:158-188; 18 call sites in its examples / tests use it, e.g. test/solver_test.jl:71).
+//
+//   reference (IterativeSolvers 0.9.4 gmres!, one thread)            here
+//   Arnoldi with modified Gram-Schmidt: j dot/axpy pairs per step     classical Gram-Schmidt applied twice (CGS2): the j
+//                                                                     dots of a pass are ONE kernel per group of 8 basis
+//                                                                     vectors (2 reductions per step instead of j; with
+//                                                                     several ranks 3 all-reduces per step instead of j+1)
+//   Givens rotations / least squares on the host                      one-thread kernels on device scalars: H, cs, sn, g
+//                                                                     never leave the GPU; the host polls the done flag
+//                                                                     once per restart cycle
+//   restart = 20, zero initial guess, ||r|| <= max(reltol ||r0||, abstol) on the Givens residual estimate    same
+//
+// It iterates on the same preconditioned system  Â = B⁻¹SAS  as BiCGStab / CG (pg_precond.hip), so the residual it
+// minimises is the preconditioned one.  Not on the benchmark path (BiCGStab needs 18 vector passes per two SpMVs, GMRES
+// ~4j + 6 per SpMV); it is here so that `method = gmres` means GMRES.
+#include "pg_krylov.h"
+#include "pg_spmv.h"
+
+using namespace pg;
+
+namespace {
+
+constexpr int GRP = 8;   // basis vectors handled per launch of the dot / update kernels
+
+// device scalar block of GMRES (KrylovWork::gm), after the H / cs / sn / g / y / h arrays
+struct GmLayout {
+  int m;
+  __host__ __device__ int H(int i, int j) const { return (m + 1) * j + i; }        // (m+1) x m, column major
+  __host__ __device__ int cs(int i) const { return (m + 1) * m + i; }
+  __host__ __device__ int sn(int i) const { return (m + 1) * m + m + i; }
+  __host__ __device__ int g(int i) const { return (m + 1) * m + 2 * m + i; }       // m + 1
+  __host__ __device__ int y(int i) const { return (m + 1) * m + 3 * m + 1 + i; }   // m
+  __host__ __device__ int h1(int i) const { return (m + 1) * m + 4 * m + 1 + i; }  // m + 2: first-pass coefficients
+  __host__ __device__ int h2(int i) const { return (m + 1) * m + 5 * m + 3 + i; }  // m + 2: second pass, then ||w||^2
+  __host__ __device__ int J() const { return (m + 1) * m + 6 * m + 5; }            // columns of the current cycle
+  __host__ __device__ int invn() const { return J() + 1; }                          // 1 / norm of the vector to scale
+  __host__ __device__ int size() const { return J() + 2; }
+};
+
+// v = b - Ax (Ax == nullptr: v = b), ghosts zeroed; partial slot 0 = (v,v)
+__global__ __launch_bounds__(BLOCK) void k_gm_resid(i64 n, i64 nvec, const double* __restrict__ b, const double* __restrict__ Ax,
+                                                    double* __restrict__ v, double* __restrict__ x_zero,
+                                                    double* __restrict__ partials) {
+  __shared__ double s_red[BLOCK / 64];
+  double acc = 0.0;
+  for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < nvec; i += (i64)gridDim.x * BLOCK) {
+    double vi = 0.0;
+    if (i < n) vi = Ax ? b[i] - Ax[i] : b[i];
+    v[i] = vi;
+    if (x_zero) x_zero[i] = 0.0;
+    acc += vi * vi;
+  }
+  const double t = block_sum(acc, s_red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// sums of `nslots` partial slots (fixed order: deterministic) into out[0..nslots)
+__global__ __launch_bounds__(BLOCK) void k_gm_reduce(int nslots, int grid, const double* __restrict__ partials,
+                                                     double* __restrict__ out, const double* __restrict__ sc, int check_done) {
+  __shared__ double s_red[BLOCK / 64];
+  if (check_done && sc[S_DONE] != 0.0) return;
+  for (int s = 0; s < nslots; ++s) {
+    double a = 0.0;
+    for (int i = threadIdx.x; i < grid; i += BLOCK) a += partials[(size_t)s * grid + i];
+    const double t = block_sum(a, s_red);
+    if (threadIdx.x == 0) out[s] = t;
+  }
+}
+
+// start of a restart cycle: beta = ||r||; tolerance from the FIRST residual (zero initial guess: ||r0|| = ||b||)
+__global__ void k_gm_begin(GmLayout L, double* __restrict__ gm, double* __restrict__ sc, int first) {
+  const double rr = gm[L.h2(0)];
+  if (first) {
+    sc[S_BB] = rr;
+    sc[S_ITERS] = 0.0;
+    const double t2 = sc[S_RELTOL2] * rr;
+    sc[S_TOL2] = t2 > sc[S_ABSTOL2] ? t2 : sc[S_ABSTOL2];
+  }
+  sc[S_RR] = rr;
+  const double beta = sqrt(rr > 0.0 ? rr : 0.0);
+  for (int i = 0; i <= L.m; ++i) gm[L.g(i)] = 0.0;
+  gm[L.g(0)] = beta;
+  gm[L.J()] = 0.0;
+  gm[L.invn()] = beta > 0.0 ? 1.0 / beta : 0.0;
+  sc[S_DONE] = (rr <= sc[S_TOL2] || beta == 0.0) ? 1.0 : 0.0;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_gm_scale(i64 n, const double* __restrict__ sc, const double* __restrict__ gm,
+                                                    int invn_at, double* __restrict__ v) {
+  if (sc[S_DONE] != 0.0) return;
+  const double f = gm[invn_at];
+  for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) v[i] *= f;
+}
+
+// partial slots [k0, k0+cnt) = (V_i, w), i = k0 .. k0+cnt-1   (cnt <= GRP)
+__global__ __launch_bounds__(BLOCK) void k_gm_dots(i64 n, i64 stride, int k0, int cnt, const double* __restrict__ V,
+                                                   const double* __restrict__ w, const double* __restrict__ sc,
+                                                   double* __restrict__ partials) {
+  __shared__ double s_red[BLOCK / 64];
+  if (sc[S_DONE] != 0.0) return;
+  double acc[GRP];
+#pragma unroll
+  for (int q = 0; q < GRP; ++q) acc[q] = 0.0;
+  const double* __restrict__ V0 = V + (size_t)k0 * stride;
+  for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) {
+    const double wi = w[i];
+#pragma unroll
+    for (int q = 0; q < GRP; ++q)
+      if (q < cnt) acc[q] += V0[(size_t)q * stride + i] * wi;
+  }
+#pragma unroll
+  for (int q = 0; q < GRP; ++q) {
+    if (q < cnt) {   // block-uniform
+      const double t = block_sum(acc[q], s_red);
+      if (threadIdx.x == 0) partials[(size_t)(k0 + q) * gridDim.x + blockIdx.x] = t;
+    }
+  }
+}
+
+// w -= sum_{i in [k0,k0+cnt)} h_i V_i ;  norm_slot >= 0: partial slot norm_slot = (w,w) after the update
+__global__ __launch_bounds__(BLOCK) void k_gm_update(i64 n, i64 stride, int k0, int cnt, const double* __restrict__ V,
+                                                     double* __restrict__ w, const double* __restrict__ h,
+                                                     const double* __restrict__ sc, int norm_slot,
+                                                     double* __restrict__ partials) {
+  __shared__ double s_red[BLOCK / 64];
+  if (sc[S_DONE] != 0.0) return;
+  double hc[GRP];
+#pragma unroll
+  for (int q = 0; q < GRP; ++q) hc[q] = q < cnt ? h[k0 + q] : 0.0;
+  const double* __restrict__ V0 = V + (size_t)k0 * stride;
+  double acc = 0.0;
+  for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) {
+    double wi = w[i];
+#pragma unroll
+    for (int q = 0; q < GRP; ++q)
+      if (q < cnt) wi -= hc[q] * V0[(size_t)q * stride + i];
+    w[i] = wi;
+    acc += wi * wi;
+  }
+  if (norm_slot >= 0) {
+    const double t = block_sum(acc, s_red);
+    if (threadIdx.x == 0) partials[(size_t)norm_slot * gridDim.x + blockIdx.x] = t;
+  }
+}
+
+// column j of the Hessenberg matrix: h = h1 + h2 (CGS2), previous rotations, new rotation, residual estimate
+__global__ void k_gm_hess(GmLayout L, int j, double* __restrict__ gm, double* __restrict__ sc) {
+  if (sc[S_DONE] != 0.0) return;
+  for (int i = 0; i <= j; ++i) gm[L.H(i, j)] = gm[L.h1(i)] + gm[L.h2(i)];
+  const double nn = gm[L.h2(j + 1)];
+  const double hn = sqrt(nn > 0.0 ? nn : 0.0);
+  gm[L.H(j + 1, j)] = hn;
+  for (int i = 0; i < j; ++i) {
+    const double c = gm[L.cs(i)], s = gm[L.sn(i)];
+    const double a = gm[L.H(i, j)], b = gm[L.H(i + 1, j)];
+    gm[L.H(i, j)] = c * a + s * b;
+    gm[L.H(i + 1, j)] = -s * a + c * b;
+  }
+  const double a = gm[L.H(j, j)];
+  const double d = hypot(a, hn);
+  sc[S_ITERS] += 1.0;
+  gm[L.J()] = (double)(j + 1);
+  if (d == 0.0) {   // A v_j = 0: singular system; keep the previous columns only
+    gm[L.J()] = (double)j;
+    sc[S_DONE] = 2.0;
+    return;
+  }
+  const double c = a / d, s = hn / d;
+  gm[L.cs(j)] = c;
+  gm[L.sn(j)] = s;
+  gm[L.H(j, j)] = d;
+  gm[L.H(j + 1, j)] = 0.0;
+  const double gj = gm[L.g(j)];
+  gm[L.g(j)] = c * gj;
+  gm[L.g(j + 1)] = -s * gj;
+  const double rr = gm[L.g(j + 1)] * gm[L.g(j + 1)];
+  sc[S_RR] = rr;
+  gm[L.invn()] = hn > 0.0 ? 1.0 / hn : 0.0;
+  if (rr <= sc[S_TOL2] || hn == 0.0) sc[S_DONE] = 1.0;   // hn == 0: the Krylov space is exhausted (exact solution)
+}
+
+// y = H(0:J,0:J)^-1 g(0:J)   (back substitution on the rotated, upper-triangular H)
+__global__ void k_gm_solve_y(GmLayout L, double* __restrict__ gm) {
+  const int J = (int)gm[L.J()];
+  for (int i = J - 1; i >= 0; --i) {
+    double s = gm[L.g(i)];
+    for (int k = i + 1; k < J; ++k) s -= gm[L.H(i, k)] * gm[L.y(k)];
+    gm[L.y(i)] = s / gm[L.H(i, i)];
+  }
+}
+
+// x += sum_{i<J} y_i V_i
+__global__ __launch_bounds__(BLOCK) void k_gm_xupdate(i64 n, i64 stride, GmLayout L, const double* __restrict__ gm,
+                                                      const double* __restrict__ V, double* __restrict__ x) {
+  const int J = (int)gm[L.J()];
+  if (J <= 0) return;
+  for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) {
+    double xi = x[i];
+    for (int k = 0; k < J; ++k) xi += gm[L.y(k)] * V[(size_t)k * stride + i];
+    x[i] = xi;
+  }
+}
+
+}  // namespace
+
+namespace pg {
+
+void gmres_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, const double* b, double* x, KrylovWork& w,
+                 const pg_krylov_opts& opts, SolveStats& stats) {
+  Context& cx = ctx();
+  hipStream_t st = cx.stream;
+  const i64 n = A.n, nvec = nb.n_vec();
+  PG_REQUIRE(w.n == n && w.nvec == nvec, "krylov workspace size mismatch");
+  const int G = w.grid;
+  int m = opts.restart > 0 ? opts.restart : 20;                 // IterativeSolvers: restart = min(20, size(A, 2))
+  m = std::min(m, 200);
+  const bool multi = cx.nranks > 1 || cx.comm;
+  if (!multi && n > 0) m = (int)std::min<i64>(m, n);
+  const int maxiter = opts.maxiter > 0 ? opts.maxiter : 100000;
+  const GmLayout L{m};
+  const i64 stride = nvec > 0 ? nvec : 1;
+  if (w.gm_m != m) {
+    w.gm_basis.alloc((i64)(m + 1) * stride);
+    w.gm_basis.zero();                                          // ghost segments of every basis vector start defined
+    w.gm.alloc(L.size());
+    w.gm_partials.alloc((i64)(m + 2) * G);
+    w.gm_m = m;
+  }
+  w.gm.zero();
+  double* V = w.gm_basis.p;
+  double* gm = w.gm.p;
+  double* part = w.gm_partials.p;
+
+  double hs[S_COUNT];
+  std::memset(hs, 0, sizeof(hs));
+  hs[S_RELTOL2] = opts.reltol * opts.reltol;
+  hs[S_ABSTOL2] = opts.abstol * opts.abstol;
+  PG_HIP(hipMemcpyAsync(w.sc.p, hs, sizeof(hs), hipMemcpyHostToDevice, st));
+
+  auto reduce = [&](int nslots, double* out, bool check_done) {
+    hipLaunchKernelGGL(k_gm_reduce, dim3(1), dim3(BLOCK), 0, st, nslots, G, part, out, w.sc.p, check_done ? 1 : 0);
+    if (multi) comm_allreduce_sum_f64(out, nslots, st);   // identical sums, hence identical control flow, on every rank
+  };
+
+  int launched = 0;
+  bool first = true, done = false;
+  while (!done) {
+    // r = b - Â x  ->  v_0 = r / ||r||
+    if (first) {
+      hipLaunchKernelGGL(k_gm_resid, dim3(G), dim3(BLOCK), 0, st, n, nvec, b, (const double*)nullptr, V, x, part);
+    } else {
+      if (A.halo_needed) halo_exchange(nb, slab, x, st);
+      spmv(A, x, w.t.p, st);
+      hipLaunchKernelGGL(k_gm_resid, dim3(G), dim3(BLOCK), 0, st, n, nvec, b, (const double*)w.t.p, V, (double*)nullptr, part);
+    }
+    reduce(1, gm + L.h2(0), false);
+    hipLaunchKernelGGL(k_gm_begin, dim3(1), dim3(1), 0, st, L, gm, w.sc.p, first ? 1 : 0);
+    hipLaunchKernelGGL(k_gm_scale, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, gm, L.invn(), V);
+    first = false;
+    const int steps = std::max(0, std::min(m, maxiter - launched));
+    for (int j = 0; j < steps; ++j) {
+      double* vj = V + (size_t)j * stride;
+      double* wv = V + (size_t)(j + 1) * stride;
+      if (A.halo_needed) halo_exchange(nb, slab, vj, st);
+      launch_spmv(0, A, vj, wv, nullptr, nullptr, w.sc.p, spmv_default_grid(n), st);
+      const int k = j + 1;
+      for (int pass = 0; pass < 2; ++pass) {
+        double* h = gm + (pass == 0 ? L.h1(0) : L.h2(0));
+        for (int k0 = 0; k0 < k; k0 += GRP)
+          hipLaunchKernelGGL(k_gm_dots, dim3(G), dim3(BLOCK), 0, st, n, stride, k0, std::min(GRP, k - k0), (const double*)V,
+                             (const double*)wv, (const double*)w.sc.p, part);
+        reduce(k, h, true);
+        for (int k0 = 0; k0 < k; k0 += GRP) {
+          const bool last = pass == 1 && k0 + GRP >= k;
+          hipLaunchKernelGGL(k_gm_update, dim3(G), dim3(BLOCK), 0, st, n, stride, k0, std::min(GRP, k - k0), (const double*)V, wv,
+                             (const double*)h, (const double*)w.sc.p, last ? 0 : -1, part);
+        }
+      }
+      reduce(1, gm + L.h2(k), true);   // ||w||^2 after both passes
+      hipLaunchKernelGGL(k_gm_hess, dim3(1), dim3(1), 0, st, L, j, gm, w.sc.p);
+      hipLaunchKernelGGL(k_gm_scale, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, gm, L.invn(), wv);
+    }
+    launched += steps;
+    // end of the cycle (or convergence inside it): x += V y
+    hipLaunchKernelGGL(k_gm_solve_y, dim3(1), dim3(1), 0, st, L, gm);
+    hipLaunchKernelGGL(k_gm_xupdate, dim3(G), dim3(BLOCK), 0, st, n, stride, L, (const double*)gm, (const double*)V, x);
+    PG_HIP(hipGetLastError());
+    PG_HIP(hipMemcpyAsync(w.h_sc, w.sc.p, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, st));
+    PG_HIP(hipStreamSynchronize(st));
+    if (w.h_sc[S_DONE] != 0.0 || launched >= maxiter || steps == 0) done = true;
+  }
+  stats.iters = (int)w.h_sc[S_ITERS];
+  stats.converged = w.h_sc[S_DONE] == 1.0 ? 1 : 0;
+  stats.resnorm = std::sqrt(w.h_sc[S_RR]);
+  stats.bnorm = std::sqrt(w.h_sc[S_BB]);
+}
+
+}  // namespace pg

@@ -1,4 +1,4 @@
-// pg_krylov.h -- K11: Krylov solve of the reduced system on one slab (BiCGStab / CG).
+// pg_krylov.h -- K11: Krylov solve of the reduced system on one slab (BiCGStab / CG / GMRES).
 #pragma once
 #include "pg_system.h"
 
@@ -13,6 +13,9 @@ struct KrylovWork {
   int grid = 1;
   DevBuf<unsigned> ticket;              // arrival counter of the in-launch scalar phases (pg_spmv.h)
   int last_iters = 0;                   // iterations of the previous solve (sizes the first launch batch)
+  // GMRES(m) only, allocated on first use (pg_gmres.hip): m+1 basis vectors, H / rotations / g, per-block partial sums
+  DevBuf<double> gm_basis, gm, gm_partials;
+  int gm_m = -1;
   void init(i64 n_own, i64 n_vec);
   ~KrylovWork();
 };
@@ -36,5 +39,9 @@ void spmv(const CsrMatrix& A, const double* x, double* y, hipStream_t st);
 void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, const double* b, double* x,
                   KrylovWork& w, const pg_krylov_opts& opts, SolveStats& stats, const double* x0 = nullptr,
                   const double* Ax0 = nullptr, bool preinit = false);
+
+// restarted GMRES (pg_gmres.hip): zero initial guess, x (n_vec, overwritten) = A^{-1} b
+void gmres_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, const double* b, double* x, KrylovWork& w,
+                 const pg_krylov_opts& opts, SolveStats& stats);
 
 }  // namespace pg

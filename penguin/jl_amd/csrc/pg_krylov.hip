@@ -270,6 +270,13 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
   hipStream_t st = cx.stream;
   const i64 n = A.n, nvec = nb.n_vec();
   PG_REQUIRE(w.n == n && w.nvec == nvec, "krylov workspace size mismatch");
+  PG_REQUIRE(opts.method == PG_METHOD_BICGSTAB || opts.method == PG_METHOD_CG || opts.method == PG_METHOD_GMRES,
+             "unknown Krylov method");
+  if (opts.method == PG_METHOD_GMRES) {
+    PG_REQUIRE(!preinit && !x0, "GMRES starts from zero (IterativeSolvers' default)");
+    gmres_solve(A, nb, slab, b, x, w, opts, stats);
+    return;
+  }
   const int G = w.grid;
   const int check_every = opts.check_every > 0 ? opts.check_every : 4;
   int maxiter = opts.maxiter;

@@ -543,6 +543,7 @@ pg_krylov_opts default_opts() {
   o.maxiter = 0;
   o.check_every = 4;
   o.warm_start = 1;
+  o.restart = 0;
   return o;
 }
 

@@ -45,4 +45,13 @@ for case, (n, zf, centers) in {"sphere": (24, 1, [(2.01, 2.01, 2.01)]),
         err = float(np.linalg.norm(x - ref) / np.linalg.norm(ref))
         out[f"{case}_{nr}"] = {"rel_l2": err, "n_own": n_own.tolist(), "n_total_1": int(n1[0]), "nnz": nnz.tolist(),
                                "nnz_total_1": int(nnz1[0]), "n_ghost": ngh.tolist(), "iters": its.tolist(), "iters_1": int(it1[0])}
+# GMRES(m): the same slab code with the multi-dot all-reduces of pg_gmres.hip
+L.check(lib.pg_debug_set_virtual_rank_method(L.PG_METHOD["gmres"], 6))
+ref, n1, nnz1, _, it1 = run(1, 24, 1, [(2.01, 2.01, 2.01)], 2, 1)
+for nr in (2, 3):
+    x, n_own, nnz, ngh, its = run(nr, 24, 1, [(2.01, 2.01, 2.01)], 2, 1)
+    out[f"gmres_sphere_{nr}"] = {"rel_l2": float(np.linalg.norm(x - ref) / np.linalg.norm(ref)), "n_own": n_own.tolist(),
+                                 "n_total_1": int(n1[0]), "nnz": nnz.tolist(), "nnz_total_1": int(nnz1[0]),
+                                 "n_ghost": ngh.tolist(), "iters": its.tolist(), "iters_1": int(it1[0])}
+L.check(lib.pg_debug_set_virtual_rank_method(L.PG_METHOD["bicgstab"], 0))
 print(json.dumps(out))

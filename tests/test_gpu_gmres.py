@@ -1,0 +1,87 @@
+"""`method = IterativeSolvers.gmres` (the default of solve_system!, src/solver.jl:158) on the device: restarted GMRES of
+pg_gmres.hip against the oracle's direct solve (<= 1e-10 rel-L2, the north star's bar) and against the oracle's own
+GMRES restatement on the SAME preconditioned system (iteration counts)."""
+import numpy as np
+import pytest
+
+from oracle import penguin_oracle as po
+from tests.common import rel_l2
+from tests.test_gpu_parity import HEAT_BORDERS, TOL_T, _mono_pair
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("scheme0,scheme,restart", [("BE", "BE", 0), ("BE", "CN", 0), ("CN", "CN", 4)])
+def test_gmres_heat_monophasic(pj, scheme0, scheme, restart):
+    """test/solver/diffusion_test.jl:57-80 shape with method=gmres; restart=4 forces several restart cycles."""
+    n = 24
+    M = (n + 1) ** 2
+    u0 = np.concatenate([np.zeros(M), np.ones(M)])
+    dt = 0.25 * (4.0 / n) ** 2
+    (s, ph, bcb, bci), (so, oph, obcb, obci) = _mono_pair(
+        pj, 2, n, 4.0, (2.01, 2.01), 1.0, pj.Dirichlet(1.0), po.Dirichlet(1.0),
+        {k: pj.Dirichlet(0.0) for k in HEAT_BORDERS}, {k: po.Dirichlet(0.0) for k in HEAT_BORDERS}, dt, u0, scheme0)
+    # the constructor's preconditioned system, before any solve: what the first GMRES solve iterates on
+    Ah, bh, _ = s.system(2)
+    Ah = Ah[:, : Ah.shape[0]].tocsr()
+    kw = {"restart": restart} if restart else {}
+    pj.solve_DiffusionUnsteadyMono_b(s, ph, dt, 5 * dt, bcb, bci, scheme, method="gmres", reltol=1e-13, log=True, **kw)
+    po.solve_DiffusionUnsteadyMono(so, oph, dt, 5 * dt, obcb, obci, scheme, method="\\")
+    assert len(s.states) == len(so.states)
+    for a, b in zip(s.states, so.states):
+        assert rel_l2(a, b) <= TOL_T
+    assert all(c["isconverged"] for c in s.ch)
+    # same iteration as the oracle's GMRES (modified Gram-Schmidt there, CGS2 here) on the same system
+    _, it_ref, _ = po.gmres_ref(Ah, bh, reltol=1e-13, restart=restart or 20)
+    assert abs(s.ch[0]["iters"] - it_ref) <= 2, (s.ch[0]["iters"], it_ref)
+
+
+def test_gmres_robin_3d(pj):
+    """Robin interface in 3-D (non-trivial cell blocks, non-symmetric system)."""
+    n = 12
+    M = (n + 1) ** 3
+    rng = np.random.default_rng(11)
+    u0 = np.concatenate([rng.uniform(0.0, 1.0, M), rng.uniform(0.0, 1.0, M)])
+    dt = 0.5 * (4.0 / n) ** 2
+    keys = ("left", "right", "top", "bottom", "forward", "backward")
+    (s, ph, bcb, bci), (so, oph, obcb, obci) = _mono_pair(
+        pj, 3, n, 4.0, (2.03, 1.98, 2.01), 1.1, pj.Robin(1.0, 0.5, 0.3), po.Robin(1.0, 0.5, 0.3),
+        {k: pj.Dirichlet(0.2) for k in keys}, {k: po.Dirichlet(0.2) for k in keys}, dt, u0, "BE")
+    pj.solve_DiffusionUnsteadyMono_b(s, ph, dt, 3 * dt, bcb, bci, "CN", method="gmres", reltol=1e-13, restart=30)
+    po.solve_DiffusionUnsteadyMono(so, oph, dt, 3 * dt, obcb, obci, "CN", method="\\")
+    assert rel_l2(s.x, so.x) <= TOL_T
+
+
+def test_gmres_callable_named_like_iterativesolvers(pj):
+    """A callable whose name is `gmres` (the way the reference passes IterativeSolvers.gmres) selects GMRES; maxiter caps
+    the total number of inner iterations (IterativeSolvers' meaning) and an unconverged solve is reported as such."""
+    def gmres():   # stands in for IterativeSolvers.gmres
+        raise AssertionError("never called: only its name crosses the boundary")
+
+    n = 16
+    M = (n + 1) ** 2
+    u0 = np.concatenate([np.zeros(M), np.ones(M)])
+    dt = 0.25 * (4.0 / n) ** 2
+    (s, ph, bcb, bci), _ = _mono_pair(
+        pj, 2, n, 4.0, (2.01, 2.01), 1.0, pj.Dirichlet(1.0), po.Dirichlet(1.0),
+        {k: pj.Dirichlet(0.0) for k in HEAT_BORDERS}, {k: po.Dirichlet(0.0) for k in HEAT_BORDERS}, dt, u0, "BE")
+    pj.solve_DiffusionUnsteadyMono_b(s, ph, dt, dt, bcb, bci, "BE", method=gmres, reltol=1e-14, maxiter=3, log=True)
+    assert s.ch[0]["iters"] == 3 and not s.ch[0]["isconverged"]
+
+
+def test_gmres_steady_poisson(pj):
+    """Steady diffusion with gmres: no mass term, so the restart length matters (test/convergence_test.jl:30-70 shape)."""
+    n = 24
+    mesh, omesh = pj.Mesh((n, n), (4.0, 4.0), (0.0, 0.0)), po.Mesh((n, n), (4.0, 4.0), (0.0, 0.0))
+    from tests.common import oracle_capacity_from_product
+    cap = pj.Capacity(pj.Sphere((2.0, 2.0), 1.0), mesh)
+    ocap = oracle_capacity_from_product(cap, omesh)
+    op, oop = pj.DiffusionOps(cap), po.make_diffusion_ops(ocap)
+    f = lambda x, y, z, t=0.0: 4.0
+    D = lambda x, y, z: 1.0
+    ph, oph = pj.Phase(cap, op, f, D), po.Phase(ocap, oop, f, D)
+    s = pj.DiffusionSteadyMono(ph, pj.BorderConditions({}), pj.Dirichlet(0.0))
+    so = po.DiffusionSteadyMono(oph, po.BorderConditions({}), po.Dirichlet(0.0))
+    pj.solve_DiffusionSteadyMono_b(s, method="gmres", reltol=1e-13, restart=60)
+    po.solve_DiffusionSteadyMono(so, method="\\")
+    assert rel_l2(s.x, so.x) <= TOL_T

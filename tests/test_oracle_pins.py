@@ -279,3 +279,37 @@ def test_advection_diffusion_1d_exponential_profile():
     xc = np.array(mesh.centers[0])
     exact = (np.exp(Pe * (xc - xc[0])) - 1.0) / (np.exp(Pe * (xc[-1] - xc[0])) - 1.0)
     assert np.abs(s.x[:n] - exact).max() < 5e-4
+
+
+def test_gmres_restatement_against_direct_solve_and_scipy():
+    """gmres_ref (IterativeSolvers.gmres semantics; the package is not vendored) on a cut-cell heat system: same
+    solution as the direct solve and as scipy's GMRES, for the default restart and a short one; the reference's own
+    pin for this path is test/solver_test.jl:71-72 (bicgstabl vs gmres solutions agree to 1e-2)."""
+    import scipy.sparse.linalg as spla
+
+    n = 16
+    mesh = po.Mesh((n, n), (4.0, 4.0), (0.0, 0.0))
+    cap = po.make_capacity(Ball((2.01, 2.01), 1.0), mesh)
+    op = po.make_diffusion_ops(cap)
+    M = (n + 1) ** 2
+    ph = po.Phase(cap, op, lambda x, y, z, t: 0.0, lambda x, y, z: 1.0)
+    bcb = po.BorderConditions({k: po.Dirichlet(0.0) for k in ("left", "right", "top", "bottom")})
+    s = po.DiffusionUnsteadyMono(ph, bcb, po.Dirichlet(1.0), 0.25 * (4.0 / n) ** 2, np.concatenate([np.zeros(M), np.ones(M)]), "BE")
+    A, b, _ = po.remove_zero_rows_cols(s.A, s.b)
+    x_direct = spla.spsolve(A.tocsc(), b)
+    for restart in (20, 5):
+        x, it, res = po.gmres_ref(A, b, reltol=1e-13, restart=restart)
+        assert res <= 1e-13 * np.linalg.norm(b)
+        assert np.linalg.norm(x - x_direct) <= 1e-10 * np.linalg.norm(x_direct)
+        xs, info = spla.gmres(A, b, rtol=1e-13, atol=0.0, restart=restart, maxiter=1000)
+        assert info == 0 and np.linalg.norm(x - xs) <= 1e-9 * np.linalg.norm(xs)
+    _, it20, _ = po.gmres_ref(A, b, reltol=1e-13, restart=20)
+    _, it5, _ = po.gmres_ref(A, b, reltol=1e-13, restart=5)
+    assert it5 >= it20                       # restarting can only slow GMRES down
+    x3, it3, res3 = po.gmres_ref(A, b, reltol=1e-13, maxiter=3)
+    assert it3 == 3 and res3 > 1e-13 * np.linalg.norm(b)
+    # through solve_system (method="gmres"), the way the reference's default reaches it (src/solver.jl:158)
+    po.solve_system(s, method="gmres", reltol=1e-13)
+    xg = s.x.copy()
+    po.solve_system(s, method="\\")
+    assert np.linalg.norm(xg - s.x) <= 1e-10 * np.linalg.norm(s.x)
