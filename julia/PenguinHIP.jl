@@ -310,7 +310,8 @@ function ConvectionOps(capacity::Capacity{N}, uₒ::NTuple{N,Vector{Float64}}, u
     end
     op
 end
-# AdvectionDiffusionSteadyMono / SteadyDiph / UnsteadyMono and their solve_...! functions are the diffusion constructors
-# and loops above called with such an operator (DarcyFlow / DarcyFlowUnsteady likewise alias the diffusion drivers).
+# AdvectionDiffusionSteadyMono / SteadyDiph / UnsteadyMono / UnsteadyDiph ("BE" only: the reference's "CN" right-hand
+# side for the diphasic driver omits the diffusion term, advectiondiffusion.jl:375-377) and their solve_...! functions are
+# the diffusion constructors and loops above called with such an operator (DarcyFlow / DarcyFlowUnsteady likewise alias the diffusion drivers).
 
 end # module

@@ -1049,6 +1049,92 @@ def solve_AdvectionDiffusionUnsteadyMono(s: Solver, phase: Phase, dt, Tend, bc_b
     return s
 
 
+# ---- advection-diffusion, unsteady diphasic (src/solver/advectiondiffusion.jl:299-418) ----------------
+
+
+def A_diph_unstead_advdiff(op1: ConvectionOps, op2: ConvectionOps, cap1, cap2, D1, D2, ic, dt: float, scheme: str):
+    """src/solver/advectiondiffusion.jl:313-354."""
+    if scheme not in ("BE", "CN"):
+        raise ValueError("Unknown scheme.")                                   # :343-345
+    n = int(np.prod(op1.size))
+    jump, flux = ic.scalar, ic.flux
+    I_n = sp.identity(n, format="csr")
+    Id1 = sp.diags(build_I_D(op1, D1, cap1))
+    Id2 = sp.diags(build_I_D(op2, D2, cap2))
+    L1, M1, P1, Q1 = _blocks(op1)
+    L2, M2, P2, Q2 = _blocks(op2)
+    cb1, ci1, _ = _conv(op1)
+    cb2, ci2, _ = _conv(op2)
+    th = dt / 2 if scheme == "CN" else dt
+    return sp.bmat(
+        [[op1.V + th * (cb1 + ci1) + th * (Id1 @ L1), th * ci1 + th * (Id1 @ M1), None, None],
+         [None, jump.alpha1 * I_n, None, -jump.alpha2 * I_n],
+         [None, None, op2.V + th * (cb2 + ci2) + th * (Id2 @ L2), th * ci2 + th * (Id2 @ M2)],
+         [flux.beta1 * P1, flux.beta1 * Q1, flux.beta2 * P2, flux.beta2 * Q2]], format="csr")
+
+
+def b_diph_unstead_advdiff(op1: ConvectionOps, op2: ConvectionOps, f1, f2, cap1, cap2, D1, D2, ic, Ti, dt, t, scheme):
+    """src/solver/advectiondiffusion.jl:356-387.  Restated as written: the CN right-hand side carries the convection
+    terms only -- the diffusion part of the explicit half step is absent (:375-377) -- unlike the monophasic one."""
+    N = int(np.prod(op1.size))
+    jump, flux = ic.scalar, ic.flux
+    gg = build_g_g(op1, jump, cap1)
+    hh = build_g_g(op2, flux, cap2)
+    f1n, f2n = build_source(op1, f1, t, cap1), build_source(op2, f2, t, cap2)
+    f1p, f2p = build_source(op1, f1, t + dt, cap1), build_source(op2, f2, t + dt, cap2)
+    Tw1, Tg1, Tw2, Tg2 = Ti[:N], Ti[N:2 * N], Ti[2 * N:3 * N], Ti[3 * N:]
+    if scheme == "CN":
+        cb1, ci1, _ = _conv(op1)
+        cb2, ci2, _ = _conv(op2)
+        b1 = cap1.V * Tw1 - dt / 2 * ((cb1 + ci1) @ Tw1) - dt / 2 * (ci1 @ Tg1) + dt / 2 * cap1.V * (f1n + f1p)
+        b3 = cap2.V * Tw2 - dt / 2 * ((cb2 + ci2) @ Tw2) - dt / 2 * (ci2 @ Tg2) + dt / 2 * cap2.V * (f2n + f2p)
+    elif scheme == "BE":
+        b1 = cap1.V * Tw1 + dt * cap1.V * f1p
+        b3 = cap2.V * Tw2 + dt * cap2.V * f2p
+    else:
+        raise ValueError("Unknown scheme.")
+    return np.concatenate([b1, gg, b3, cap2.G * hh])
+
+
+def AdvectionDiffusionUnsteadyDiph(phase1: Phase, phase2: Phase, bc_b, ic, dt, Ti, scheme, ctor_borders: bool = False) -> Solver:
+    """src/solver/advectiondiffusion.jl:299-311.  The reference's constructor does not apply the border rows (its loop
+    does, :404); ctor_borders=True applies them as DiffusionUnsteadyDiph does -- the form the HIP path implements."""
+    s = Solver("Unsteady", "Diphasic", "DiffusionAdvection")
+    s.A = A_diph_unstead_advdiff(phase1.operator, phase2.operator, phase1.capacity, phase2.capacity,
+                                 phase1.Diffusion_coeff, phase2.Diffusion_coeff, ic, dt, scheme)
+    s.b = b_diph_unstead_advdiff(phase1.operator, phase2.operator, phase1.source, phase2.source, phase1.capacity,
+                                 phase2.capacity, phase1.Diffusion_coeff, phase2.Diffusion_coeff, ic, Ti, dt, 0.0, scheme)
+    if ctor_borders:
+        s.A, s.b = BC_border_diph(s.A, s.b, bc_b, phase1.capacity, phase2.capacity)
+    return s
+
+
+def solve_AdvectionDiffusionUnsteadyDiph(s, phase1, phase2, dt, Tend, bc_b, ic, scheme, method="\\",
+                                         max_steps: Optional[int] = None, **kwargs):
+    """src/solver/advectiondiffusion.jl:389-418."""
+    if s.A is None:
+        raise RuntimeError("Solver is not initialized. Call a solver constructor first.")
+    t = 0.0
+    solve_system(s, method=method, **kwargs)
+    s.states.append(s.x)
+    Ti = s.x
+    steps = 0
+    while t < Tend:
+        if max_steps is not None and steps >= max_steps:
+            break
+        t += dt
+        s.A = A_diph_unstead_advdiff(phase1.operator, phase2.operator, phase1.capacity, phase2.capacity,
+                                     phase1.Diffusion_coeff, phase2.Diffusion_coeff, ic, dt, scheme)
+        s.b = b_diph_unstead_advdiff(phase1.operator, phase2.operator, phase1.source, phase2.source, phase1.capacity,
+                                     phase2.capacity, phase1.Diffusion_coeff, phase2.Diffusion_coeff, ic, Ti, dt, t, scheme)
+        s.A, s.b = BC_border_diph(s.A, s.b, bc_b, phase1.capacity, phase2.capacity)
+        solve_system(s, method=method, **kwargs)
+        s.states.append(s.x)
+        Ti = s.x
+        steps += 1
+    return s
+
+
 # ---- Darcy: aliases of the diffusion drivers (src/solver/darcy.jl) --------------------
 
 

@@ -7,7 +7,8 @@ call without the shared library or a HIP device raises PenguinHipError.
 """
 from ._lib import PenguinHipError, device_name, finalize, get_unique_id, init, init_distributed, lib  # noqa: F401
 from .api import (  # noqa: F401
-    AdvectionDiffusionSteadyDiph, AdvectionDiffusionSteadyMono, AdvectionDiffusionUnsteadyMono, ConvectionOps,
+    AdvectionDiffusionSteadyDiph, AdvectionDiffusionSteadyMono, AdvectionDiffusionUnsteadyDiph,
+    AdvectionDiffusionUnsteadyMono, ConvectionOps, solve_AdvectionDiffusionUnsteadyDiph_b,
     solve_AdvectionDiffusionSteadyDiph_b, solve_AdvectionDiffusionSteadyMono_b, solve_AdvectionDiffusionUnsteadyMono_b,
     BorderConditions, Capacity, Circle, DarcyFlow, DarcyFlowUnsteady, DiffusionOps, DiffusionSteadyDiph, DiffusionSteadyMono, DiffusionUnsteadyDiph,
     DiffusionUnsteadyMono, Dirichlet,

@@ -792,8 +792,10 @@ def solve_DiffusionUnsteadyMono_b(s: Solver, phase: Phase, Δt: float, Tₑ: flo
 
 
 def DiffusionUnsteadyDiph(phase1: Phase, phase2: Phase, bc_b: BorderConditions, ic: InterfaceConditions, Δt: float,
-                          Tᵢ: np.ndarray, scheme: str, verbose: bool = False) -> Solver:
+                          Tᵢ: np.ndarray, scheme: str, verbose: bool = False, _ops_kind=None) -> Solver:
     """DiffusionUnsteadyDiph(phase1, phase2, bc_b, ic, Δt, Tᵢ, scheme) -- src/solver/diffusion.jl:319-332."""
+    _require_ops(phase1, _ops_kind or DiffusionOps)
+    _require_ops(phase2, _ops_kind or DiffusionOps)
     if verbose:
         print("Solver creation:\n- Diphasic problem\n- Unsteady problem\n- Diffusion problem")
     s = Solver("Unsteady", "Diphasic", "Diffusion")
@@ -1059,6 +1061,36 @@ def solve_AdvectionDiffusionUnsteadyMono_b(s: Solver, phase: Phase, Δt: float, 
                                            scheme: str, method="bicgstab", algorithm=None, **kwargs):
     """solve_AdvectionDiffusionUnsteadyMono!(...) -- src/solver/advectiondiffusion.jl:256-282 (intended loop)."""
     return solve_DiffusionUnsteadyMono_b(s, phase, Δt, Tₑ, bc_b, bc, scheme, method=method, algorithm=algorithm, **kwargs)
+
+
+def AdvectionDiffusionUnsteadyDiph(phase1: Phase, phase2: Phase, bc_b: BorderConditions, ic: InterfaceConditions, Δt: float,
+                                   Tᵢ: np.ndarray, scheme: str, verbose: bool = False) -> Solver:
+    """AdvectionDiffusionUnsteadyDiph(phase1, phase2, bc_b, ic, Δt, Tᵢ, scheme) -- src/solver/advectiondiffusion.jl:299-311.
+
+    Backward Euler only.  The reference's Crank-Nicolson right-hand side for this driver carries the convection terms
+    but not the diffusion part of the explicit half step (:375-377), so it is neither Crank-Nicolson nor what the
+    device loop computes (b from Â xⁿ with the one run matrix); rather than return a different answer silently, "CN"
+    is refused.  As with the monophasic driver the border rows are applied from the constructor on (the reference's
+    constructor leaves them out and its loop adds them, :404)."""
+    _require_ops(phase1, ConvectionOps)
+    _require_ops(phase2, ConvectionOps)
+    if scheme not in ("BE", "CN"):
+        raise ValueError("Unknown scheme.")                       # :343-345
+    if scheme == "CN":
+        raise PenguinHipError('AdvectionDiffusionUnsteadyDiph: scheme "CN" is not available on the HIP path (the reference\'s '
+                              "right-hand side for it omits the diffusion term, advectiondiffusion.jl:375-377); use \"BE\"")
+    s = DiffusionUnsteadyDiph(phase1, phase2, bc_b, ic, Δt, Tᵢ, "BE", verbose=verbose, _ops_kind=ConvectionOps)
+    s.equation_type = "DiffusionAdvection"
+    return s
+
+
+def solve_AdvectionDiffusionUnsteadyDiph_b(s: Solver, phase1: Phase, phase2: Phase, Δt: float, Tₑ: float,
+                                           bc_b: BorderConditions, ic: InterfaceConditions, scheme: str,
+                                           method="bicgstab", algorithm=None, **kwargs):
+    """solve_AdvectionDiffusionUnsteadyDiph!(...) -- src/solver/advectiondiffusion.jl:389-418 (BE, see the constructor)."""
+    if scheme != "BE":
+        raise PenguinHipError('solve_AdvectionDiffusionUnsteadyDiph!: only scheme "BE" is available on the HIP path')
+    return solve_DiffusionUnsteadyDiph_b(s, phase1, phase2, Δt, Tₑ, bc_b, ic, "BE", method=method, algorithm=algorithm, **kwargs)
 
 
 # =============================================================================== Darcy (src/solver/darcy.jl: aliases)

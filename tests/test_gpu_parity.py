@@ -869,3 +869,41 @@ def test_advection_diffusion_diphasic_steady_matches_oracle(pj):
     pj.solve_AdvectionDiffusionSteadyDiph_b(s, reltol=1e-13)
     po.solve_system(so, method="\\")
     assert s.ch[-1]["converged"] and rel_l2(s.x, so.x) <= 1e-9
+
+
+def test_advection_diffusion_diphasic_unsteady_matches_oracle(pj):
+    """AdvectionDiffusionUnsteadyDiph (src/solver/advectiondiffusion.jl:299-418), backward Euler: constructor system and
+    every state against the oracle, without borders (where the reference's constructor and loop agree on the rows) and
+    with borders applied from the constructor on; "CN" is refused, not approximated."""
+    n = 24
+    mesh, omesh = pj.Mesh((n, n), (4.0, 4.0)), po.Mesh((n, n), (4.0, 4.0), (0.0, 0.0))
+    c1, c2 = pj.Capacity(pj.Sphere((2.0, 2.0), 1.0), mesh), pj.Capacity(pj.Sphere((2.0, 2.0), 1.0, complement=True), mesh)
+    oc1, oc2 = oracle_capacity_from_product(c1, omesh), oracle_capacity_from_product(c2, omesh)
+    M = (n + 1) ** 2
+    u1, ug1 = _velocity_fields(c1, 2, M)
+    u2, ug2 = _velocity_fields(c2, 2, M)
+    f1, f2 = (lambda x, y, z, t: 1.0 + 0.1 * x), (lambda x, y, z, t: 0.5)
+    D1, D2 = (lambda x, y, z=0.0: 1.0), (lambda x, y, z=0.0: 0.7 + 0.05 * y)
+    p1, p2 = pj.Phase(c1, pj.ConvectionOps(c1, u1, ug1), f1, D1), pj.Phase(c2, pj.ConvectionOps(c2, u2, ug2), f2, D2)
+    q1 = po.Phase(oc1, po.make_convection_ops(oc1, u1, ug1), f1, D1)
+    q2 = po.Phase(oc2, po.make_convection_ops(oc2, u2, ug2), f2, D2)
+    ic = pj.InterfaceConditions(pj.ScalarJump(1.0, 0.8, 0.1), pj.FluxJump(1.0, 2.0, 0.0))
+    oic = po.InterfaceConditions(po.ScalarJump(1.0, 0.8, 0.1), po.FluxJump(1.0, 2.0, 0.0))
+    dt = 0.25 * (4.0 / n) ** 2
+    u0 = np.concatenate([np.ones(M), np.ones(M), np.zeros(M), np.zeros(M)])
+    for borders in ({}, {k: 0.3 for k in HEAT_BORDERS}):
+        bcb = pj.BorderConditions({k: pj.Dirichlet(v) for k, v in borders.items()})
+        obcb = po.BorderConditions({k: po.Dirichlet(v) for k, v in borders.items()})
+        s = pj.AdvectionDiffusionUnsteadyDiph(p1, p2, bcb, ic, dt, u0, "BE")
+        so = po.AdvectionDiffusionUnsteadyDiph(q1, q2, obcb, oic, dt, u0, "BE", ctor_borders=True)
+        assert s.equation_type == "DiffusionAdvection"
+        _check_system(s, so)
+        pj.solve_AdvectionDiffusionUnsteadyDiph_b(s, p1, p2, dt, 4 * dt, bcb, ic, "BE", reltol=1e-13)
+        po.solve_AdvectionDiffusionUnsteadyDiph(so, q1, q2, dt, 4 * dt, obcb, oic, "BE", method="\\")
+        assert len(s.states) == len(so.states) == 5
+        for a, b in zip(s.states, so.states):
+            assert rel_l2(a, b) <= 1e-9
+    with pytest.raises(pj.PenguinHipError):
+        pj.AdvectionDiffusionUnsteadyDiph(p1, p2, bcb, ic, dt, u0, "CN")
+    with pytest.raises(ValueError):
+        pj.AdvectionDiffusionUnsteadyDiph(p1, p2, bcb, ic, dt, u0, "RK4")

@@ -313,3 +313,36 @@ def test_gmres_restatement_against_direct_solve_and_scipy():
     xg = s.x.copy()
     po.solve_system(s, method="\\")
     assert np.linalg.norm(xg - s.x) <= 1e-10 * np.linalg.norm(s.x)
+
+
+def test_unsteady_diphasic_advection_diffusion_reduces_to_diffusion_at_zero_velocity():
+    """The reference ships no test for AdvectionDiffusionUnsteadyDiph (src/solver/advectiondiffusion.jl:299-418); the
+    restatement is tied to the pinned diffusion restatement instead: with u = 0 its matrix equals
+    A_diph_unstead_diff for both schemes and its BE right-hand side equals b_diph_unstead_diff; its CN right-hand
+    side differs from the diffusion one by exactly the diffusion term the reference leaves out (:375-377)."""
+    n = 12
+    mesh = po.Mesh((n, n), (4.0, 4.0), (0.0, 0.0))
+    c1 = po.make_capacity(Ball((2.0, 2.0), 1.0), mesh)
+    c2 = po.make_capacity(Ball((2.0, 2.0), 1.0, complement=True), mesh)
+    M = (n + 1) ** 2
+    zero = [np.zeros(M), np.zeros(M)]
+    f = lambda x, y, z, t: 1.0 + 0.1 * x
+    D = lambda x, y, z: 0.7
+    q = [po.Phase(c, po.make_convection_ops(c, zero, np.zeros(2 * M)), f, D) for c in (c1, c2)]
+    d = [po.Phase(c, po.make_diffusion_ops(c), f, D) for c in (c1, c2)]
+    ic = po.InterfaceConditions(po.ScalarJump(1.0, 0.8, 0.1), po.FluxJump(1.0, 2.0, 0.0))
+    dt = 0.01
+    rng = np.random.default_rng(3)
+    Ti = rng.uniform(0.0, 1.0, 4 * M)
+    for sch in ("BE", "CN"):
+        Aa = po.A_diph_unstead_advdiff(q[0].operator, q[1].operator, c1, c2, D, D, ic, dt, sch)
+        Ad = po.A_diph_unstead_diff(d[0].operator, d[1].operator, c1, c2, D, D, ic, dt, sch)
+        assert abs(Aa - Ad).max() <= 1e-15 * abs(Ad).max()
+    args = lambda ph: (ph[0].operator, ph[1].operator, f, f, c1, c2, D, D, ic, Ti, dt, 0.3)
+    assert np.allclose(po.b_diph_unstead_advdiff(*args(q), "BE"), po.b_diph_unstead_diff(*args(d), "BE"), rtol=0, atol=1e-15)
+    ba, bd = po.b_diph_unstead_advdiff(*args(q), "CN"), po.b_diph_unstead_diff(*args(d), "CN")
+    L1, M1, _, _ = po._blocks(d[0].operator)
+    missing = -dt / 2 * 0.7 * (L1 @ Ti[:M] + M1 @ Ti[M:2 * M])
+    assert np.allclose(bd[:M] - ba[:M], missing, rtol=0, atol=1e-13)
+    with pytest.raises(ValueError):
+        po.A_diph_unstead_advdiff(q[0].operator, q[1].operator, c1, c2, D, D, ic, dt, "RK4")
