@@ -169,7 +169,9 @@ def main() -> None:
     out = {
         "metric": "time-steps/sec + SpMV GB/s (% HBM roofline), 3D mono diffusion 512^3",
         "value": g * args.steps / elapsed,
-        "unit": "time-steps/s" if g == 1 else f"{n}^3-subdomain time-steps/s (aggregate over {world} slabs)",
+        # weak scaling: every rank advances its own n^3 slab each step, so the whole-job rate is N x the global step rate
+        # (n^3-subdomain time-steps per second summed over the slabs); at N = 1 and with --strong it is the plain step rate
+        "unit": "time-steps/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
@@ -188,7 +190,12 @@ def main() -> None:
             "krylov_iters_per_step": iters,
             "spmv_per_step": run.spmv_launches / max(run.steps, 1),
             "parallelism": f"slab-z x{world}, RCCL halo + dot all-reduce",
+            "value_is": "global time-steps/s" if g == 1 else f"{n}^3-slab time-steps/s summed over the {world} slabs "
+                        f"(= {world} x {args.steps / elapsed:.1f} global steps/s)",
             "setup_s": setup_s, "capacity_kernels_ms": cap_ms,
+            # set-up kernels reported separately, over the (3 + 5N) * 8 * M bytes of capacity fields they produce
+            "capacity_cells_per_s": M / (cap_ms * 1e-3) / max(world, 1) if cap_ms > 0 else None,
+            "capacity_GBs": (3 + 5 * 3) * 8 * M / max(world, 1) / (cap_ms * 1e-3) / 1e9 if cap_ms > 0 else None,
             "device": pj.device_name(),
         },
         "roofline": {

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <array>
+#include <memory>
 #include <set>
 
 namespace pg {
@@ -129,7 +130,9 @@ int32_t pg_mesh_create(int32_t N, const int64_t* n, const double* L, const doubl
   PG_API_BEGIN
   PG_REQUIRE(N >= 1 && N <= 3, "pg_mesh_create: N must be 1, 2 or 3");
   PG_REQUIRE(out != nullptr, "pg_mesh_create: out is NULL");
-  auto* m = new pg_mesh();
+  PG_REQUIRE(n != nullptr && L != nullptr, "pg_mesh_create: n / L is NULL");
+  std::unique_ptr<pg_mesh> guard(new pg_mesh());   // released on success; an argument error below frees it
+  pg_mesh* m = guard.get();
   m->N = N;
   for (int d = 0; d < N; ++d) {
     PG_REQUIRE(n[d] >= 1, "pg_mesh_create: n_d must be >= 1");
@@ -148,7 +151,7 @@ int32_t pg_mesh_create(int32_t N, const int64_t* n, const double* L, const doubl
       m->d_nodes[d].upload(m->nodes[d].data(), n[d] + 1);
     }
   }
-  *out = m;
+  *out = guard.release();
   PG_API_END
 }
 
