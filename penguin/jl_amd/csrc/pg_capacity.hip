@@ -171,10 +171,12 @@ __global__ void k_sections(GeoView g, BallSet bs, i64 Mloc, const double* ct, co
         double t = (double)PG_CUT;
         if (real) t = ct[lc];
         else if (idx[d] >= g.n[d] && lc - g.stride[d] >= 0) t = ct[lc - g.stride[d]];
-        if (t == (double)PG_FULL) {
+        // the faces / sections of a full (empty) cell are full (empty) -- except in 1-D, where a face is a POINT and a
+        // point exactly on the interface counts as fluid (f <= 0) whichever cell owns it: always evaluated there
+        if (g.N > 1 && t == (double)PG_FULL) {
           a = full_measure(g, d);
           b = real ? a : 0.0;
-        } else if (t == (double)PG_EMPTY) {
+        } else if (g.N > 1 && t == (double)PG_EMPTY) {
           a = 0.0;
           b = 0.0;
         } else {

@@ -100,8 +100,10 @@ PG_HD Sec2 disc_rect_all(double rho, double a, double b, double t0, double t1, b
   bp[nb++] = ua;
   double e[2];
   int ne = 0;
-  if (fabs(t1) < rho) e[ne++] = sqrt(rho2 - t1 * t1);
-  if (fabs(t0) < rho) e[ne++] = sqrt(rho2 - t0 * t0);
+  // <=: a side that touches the circle (|t| == rho) has its double root u = 0 as a kink -- the chord limit switches
+  // between the side and the arc there, and the midpoint test below would otherwise sit exactly on the tangent point
+  if (fabs(t1) <= rho) e[ne++] = sroot(rho, t1);
+  if (fabs(t0) <= rho) e[ne++] = sroot(rho, t0);
   double cand[4];
   int nc = 0;
   for (int k = 0; k < ne; ++k) {

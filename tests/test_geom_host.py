@@ -111,3 +111,33 @@ def test_multiball_picks_the_right_ball(lib):
         o = cbox(lib, 3, centers, 1.0, lo, hi)
         assert int(o[0]) == m.type
         assert abs(o[1] - m.vol) <= 1e-14
+
+
+@pytest.mark.parametrize("N", [2, 3])
+def test_boxes_tangent_to_the_ball_at_an_interior_point_of_a_face(lib, N):
+    """A box face that touches the ball exactly (|t| == rho: a double root of the chord function, met by every mesh whose
+    nodes are round numbers -- centre on a node, r a multiple of h) must not flip the closed-form integration to the full
+    rectangle: found by tests/test_gpu_degenerate.py (W_d of the two cells around the south pole came out as the full
+    staggered box)."""
+    c, r = np.array([2.125, 2.125, 2.125])[:N], 1.0
+    # staggered box around the south pole of the ball: symmetric in x, bottom face tangent at its midpoint
+    for half in (0.12225, 0.125, 0.03):
+        for (t0, t1) in ((1.125, 1.375), (0.875, 1.125), (3.125, 3.375), (2.875, 3.125)):      # tangent from inside / outside, south / north
+            lo = [2.125 - half, t0] + ([2.125 - 0.1] if N == 3 else [])
+            hi = [2.125 + half, t1] + ([2.125 + 0.15] if N == 3 else [])
+            for comp in (0, 1):
+                m = Ball(c, r, complement=bool(comp)).box(lo, hi)
+                o = cbox(lib, N, c, r, np.array(lo), np.array(hi), comp)
+                assert int(o[0]) == m.type
+                full = float(np.prod(np.array(hi) - np.array(lo)))
+                assert abs(o[1] - m.vol) <= 2e-11 * full, (half, t0, comp, o[1], m.vol)
+                if m.type == -1:
+                    assert abs(o[5] - m.gamma) <= 2e-10 * max(full ** ((N - 1) / N), 1e-300)
+    # sections through the tangent plane (A_d / B_d of such cells)
+    for d in range(N):
+        lo = list(c - 0.2)
+        hi = list(c + 0.3)
+        for s in (c[d] - r, c[d] + r):
+            for comp in (0, 1):
+                ref = Ball(c, r, complement=bool(comp)).section(d, s, lo, hi)
+                assert abs(csec(lib, N, c, r, d, s, np.array(lo), np.array(hi), comp) - ref) <= 1e-12
