@@ -17,12 +17,18 @@ def test_virtual_ranks_reproduce_single_rank():
                        text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
-    assert set(out) >= {"sphere_2", "sphere_3", "sphere_4", "two_spheres_2", "two_spheres_4"}
+    assert set(out) >= {"sphere_2", "sphere_3", "sphere_4", "two_spheres_2", "two_spheres_4", "gmres_sphere_2"}
+    assert sum(1 for k in out if k.startswith("random")) == 8
     for case, v in out.items():
         assert v["rel_l2"] <= 1e-12, (case, v)                       # same solution as one rank
         assert sum(v["n_own"]) == v["n_total_1"], (case, v)          # every active unknown owned exactly once
         assert sum(v["nnz"]) == v["nnz_total_1"], (case, v)          # every matrix entry assembled exactly once
-        assert len(set(v["iters"])) == 1 and v["iters"][0] == v["iters_1"], (case, v)   # identical Krylov history
+        assert len(set(v["iters"])) == 1, (case, v)                  # every rank sees the same scalars
+        if v.get("random"):
+            # the all-reduced dots are summed in another order than on one rank: the history may shift by an iteration
+            assert abs(v["iters"][0] - v["iters_1"]) <= 2, (case, v)
+            continue
+        assert v["iters"][0] == v["iters_1"], (case, v)              # identical Krylov history
         assert all(g > 0 for g in v["n_ghost"]), (case, v)           # every rank exchanges a halo
     # one sphere per slab (the weak-scaling body): the partition by active rows is balanced
     v = out["two_spheres_2"]
