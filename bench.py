@@ -47,7 +47,8 @@ def main() -> None:
                     help="strong scaling (SURVEY 8d, config 4): the SAME n^3 problem slab-decomposed over the ranks "
                          "(default: weak scaling, one n^3 sphere problem per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=1)
+    ap.add_argument("--cpu-steps", type=int, default=6,
+                    help="time-steps the CPU baseline times per thread count (6 single-thread steps ~ 10 s, + 6 on all cores)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
