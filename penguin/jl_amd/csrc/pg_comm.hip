@@ -72,6 +72,8 @@ void comm_allreduce_sum_u64(unsigned long long* dev, i64 count, hipStream_t st) 
   else PG_NCCL(ncclAllReduce(dev, dev, count, ncclUint64, ncclSum, cx.comm, st));
 }
 
+static void rccl_halo(const Numbering& nb, const Slab& slab, double* vec, hipStream_t st);
+
 // C1: ghost segments of `vec` <- boundary chunks of the neighbours' owned parts.  The chunks are contiguous
 // (Numbering), so there is nothing to pack: one send and one recv per unknown kind and neighbour, grouped.
 void halo_exchange(const Numbering& nb, const Slab& slab, double* vec, hipStream_t st) {
@@ -103,6 +105,30 @@ void halo_exchange(const Numbering& nb, const Slab& slab, double* vec, hipStream
     lc->barrier();                      // nobody overwrites a source before it has been copied
     return;
   }
+  rccl_halo(nb, slab, vec, st);
+}
+
+void halo_begin(const Numbering& nb, const Slab& slab, double* vec, hipStream_t st) {
+  Context& cx = ctx();
+  if (cx.nranks == 1) return;
+  if (cx.local) { halo_exchange(nb, slab, vec, st); return; }
+  if (!cx.ev_fork) PG_HIP(hipEventCreateWithFlags(&cx.ev_fork, hipEventDisableTiming));
+  if (!cx.ev_join) PG_HIP(hipEventCreateWithFlags(&cx.ev_join, hipEventDisableTiming));
+  PG_HIP(hipEventRecord(cx.ev_fork, st));                      // the producer of vec's owned part has run
+  PG_HIP(hipStreamWaitEvent(cx.comm_stream, cx.ev_fork, 0));
+  rccl_halo(nb, slab, vec, cx.comm_stream);
+  PG_HIP(hipEventRecord(cx.ev_join, cx.comm_stream));
+}
+
+void halo_end(hipStream_t st) {
+  Context& cx = ctx();
+  if (cx.nranks == 1 || cx.local) return;
+  PG_HIP(hipStreamWaitEvent(st, cx.ev_join, 0));
+}
+
+static void rccl_halo(const Numbering& nb, const Slab& slab, double* vec, hipStream_t st) {
+  Context& cx = ctx();
+  const bool has_lo = slab.p0 > 0, has_hi = slab.p1 < slab.nplanes;
   // ranks own increasing plane ranges: the lower neighbour is rank-1, the upper one rank+1
   PG_NCCL(ncclGroupStart());
   for (int k = 0; k < nb.K; ++k) {

@@ -67,6 +67,7 @@ struct Context {
   int device = 0;
   hipStream_t stream = nullptr;      // compute stream: every kernel of the path runs here
   hipStream_t comm_stream = nullptr; // halo exchange stream (overlaps interior SpMV rows)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // compute stream -> comm stream -> compute stream (halo_begin / halo_end)
   int rank = 0, nranks = 1;
   ncclComm_t comm = nullptr;
   bool profiling = false;

@@ -95,6 +95,8 @@ int32_t pg_finalize(void) {
     if (c.comm) { (void)ncclCommDestroy(c.comm); c.comm = nullptr; }
     if (c.stream) { (void)hipStreamDestroy(c.stream); c.stream = nullptr; }
     if (c.comm_stream) { (void)hipStreamDestroy(c.comm_stream); c.comm_stream = nullptr; }
+    if (c.ev_fork) { (void)hipEventDestroy(c.ev_fork); c.ev_fork = nullptr; }
+    if (c.ev_join) { (void)hipEventDestroy(c.ev_join); c.ev_join = nullptr; }
     c.inited = false;
   }
   PG_API_END

@@ -250,8 +250,7 @@ void gmres_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, cons
     if (first) {
       hipLaunchKernelGGL(k_gm_resid, dim3(G), dim3(BLOCK), 0, st, n, nvec, b, (const double*)nullptr, V, x, part);
     } else {
-      if (A.halo_needed) halo_exchange(nb, slab, x, st);
-      spmv(A, x, w.t.p, st);
+      spmv_halo(A, nb, slab, x, w.t.p, st);
       hipLaunchKernelGGL(k_gm_resid, dim3(G), dim3(BLOCK), 0, st, n, nvec, b, (const double*)w.t.p, V, (double*)nullptr, part);
     }
     reduce(1, gm + L.h2(0), false);
@@ -262,8 +261,7 @@ void gmres_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, cons
     for (int j = 0; j < steps; ++j) {
       double* vj = V + (size_t)j * stride;
       double* wv = V + (size_t)(j + 1) * stride;
-      if (A.halo_needed) halo_exchange(nb, slab, vj, st);
-      launch_spmv(0, A, vj, wv, nullptr, nullptr, w.sc.p, spmv_default_grid(n), st);
+      spmv_with_halo(0, A, nb, slab, vj, wv, nullptr, nullptr, w.sc.p, spmv_default_grid(n), st);
       const int k = j + 1;
       for (int pass = 0; pass < 2; ++pass) {
         double* h = gm + (pass == 0 ? L.h1(0) : L.h2(0));

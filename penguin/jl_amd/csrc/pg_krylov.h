@@ -30,8 +30,15 @@ struct SolveStats {
 
 // halo exchange of the ghost segments of `vec` (no-op on one rank)
 void halo_exchange(const Numbering& nb, const Slab& slab, double* vec, hipStream_t st);
+// the same exchange, split: halo_begin forks it off `st` onto the communication stream (everything enqueued on `st` so
+// far is waited for there), halo_end makes `st` wait for its completion; work enqueued on `st` in between overlaps it.
+// (Virtual ranks exchange synchronously inside halo_begin.)
+void halo_begin(const Numbering& nb, const Slab& slab, double* vec, hipStream_t st);
+void halo_end(hipStream_t st);
 // y[0..n) = A * x   (x must hold valid ghosts)
 void spmv(const CsrMatrix& A, const double* x, double* y, hipStream_t st);
+// halo exchange of x (when the matrix needs one) overlapped with y[0..n) = A * x
+void spmv_halo(const CsrMatrix& A, const Numbering& nb, const Slab& slab, double* x, double* y, hipStream_t st);
 // x (n_vec, overwritten) = A^{-1} b.  x0 == nullptr: zero initial guess; else start from x0 with Ax0 = A*x0 given
 // (BiCGStab only).  x must not alias x0.
 // preinit (BiCGStab only): the caller has already written x, w.r = w.rhat = w.p = r0 and the partial sums of (r0,r0)

@@ -258,6 +258,11 @@ KrylovWork::~KrylovWork() {
   if (h_sc) (void)hipHostFree(h_sc);
 }
 
+void spmv_halo(const CsrMatrix& A, const Numbering& nb, const Slab& slab, double* x, double* y, hipStream_t st) {
+  spmv_with_halo(0, A, nb, slab, x, y, nullptr, nullptr, nullptr, spmv_default_grid(A.n), st);
+  PG_HIP(hipGetLastError());
+}
+
 void spmv(const CsrMatrix& A, const double* x, double* y, hipStream_t st) {
   if (A.n == 0) return;
   launch_spmv(0, A, x, y, nullptr, nullptr, nullptr, spmv_default_grid(A.n), st);
@@ -319,29 +324,27 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
     ++polls;
     for (int it = 0; it < batch; ++it) {
       if (!cg) {
-        if (A.halo_needed) halo_exchange(nb, slab, w.p.p, st);
         timer.begin(st, launched + it);
-        // the scalar phase that follows an SpMV is evaluated by the last block of that launch (stencil-slice kernel)
+        // the scalar phase that follows an SpMV is evaluated by the last block of that launch (stencil-slice kernel);
+        // with several ranks the halo exchange of p overlaps the rows that need no ghost value (spmv_with_halo)
         const int derive_here = (cx.nranks == 1 && !cx.comm) ? 1 : 0;
         const FinArgs f1{w.ticket.p, w.sc.p, PH_BICG_1, 2, derive_here};
-        const bool folded1 = launch_spmv(1, A, w.p.p, w.v.p, w.rhat.p, w.partials.p, w.sc.p, G, st, &f1);   // v = Â p, (r̂,v)
+        const bool folded1 = spmv_with_halo(1, A, nb, slab, w.p.p, w.v.p, w.rhat.p, w.partials.p, w.sc.p, G, st, &f1);   // v = Â p, (r̂,v)
         timer.end(st);
         // previous iteration's (r,r): convergence / restart; then α
         if (folded1) finalize_folded(PH_BICG_1, 2, w, st); else finalize(PH_BICG_1, 2, w, st, true);
         if (ntv) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_s<true>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_s<false>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p);
-        if (A.halo_needed) halo_exchange(nb, slab, w.r.p, st);                                          // r now holds s
         timer.begin(st, launched + it);
         const FinArgs f2{w.ticket.p, w.sc.p, PH_BICG_2, 5, derive_here};
-        const bool folded2 = launch_spmv(3, A, w.r.p, w.t.p, w.rhat.p, w.partials.p, w.sc.p, G, st, &f2);   // t = Â s, (t,s), (t,t), (r̂,t)
+        const bool folded2 = spmv_with_halo(3, A, nb, slab, w.r.p, w.t.p, w.rhat.p, w.partials.p, w.sc.p, G, st, &f2);   // r holds s: t = Â s, (t,s), (t,t), (r̂,t)
         timer.end(st);
         if (folded2) finalize_folded(PH_BICG_2, 5, w, st); else finalize(PH_BICG_2, 5, w, st, true);   // ω, ρ, β / restart
         if (ntv) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_xrp<true>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.t.p, w.v.p, x, w.r.p, w.p.p, w.rhat.p, w.partials.p);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_xrp<false>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.t.p, w.v.p, x, w.r.p, w.p.p, w.rhat.p, w.partials.p);
       } else {
-        if (A.halo_needed) halo_exchange(nb, slab, w.p.p, st);
         timer.begin(st, launched + it);
-        launch_spmv(2, A, w.p.p, w.v.p, nullptr, w.partials.p, w.sc.p, G, st);   // v = A p ; (v.p), (v.v)
+        spmv_with_halo(2, A, nb, slab, w.p.p, w.v.p, nullptr, w.partials.p, w.sc.p, G, st);   // v = A p ; (v.p), (v.v)
         timer.end(st);
         finalize(PH_CG_1, 1, w, st, true);
         hipLaunchKernelGGL(k_cg_xr, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.p.p, w.v.p, x, w.r.p, w.partials.p);

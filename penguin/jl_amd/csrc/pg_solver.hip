@@ -574,8 +574,7 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
       hipLaunchKernelGGL(k_rescale_state, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, stream, n, s->z_matrix->ds.p, A.ds.p, s->z.p);
       s->z_matrix = &A;
     }
-    if (A.halo_needed) halo_exchange(s->nb, s->slab, s->z.p, stream);
-    spmv(A, s->z.p, s->y.p, stream);   // ŷ = Â z = B⁻¹S A x: CN right-hand side and warm-start residual
+    spmv_halo(A, s->nb, s->slab, s->z.p, s->y.p, stream);   // ŷ = Â z = B⁻¹S A x: CN right-hand side and warm-start residual
     if (A.n_blk > 0)
       hipLaunchKernelGGL(k_rhs_block, dim3(grid_for(A.n_blk, BLOCK)), dim3(BLOCK), 0, stream, A.n_blk, scheme, A.blk_rows.p,
                          A.blk_idx.p, A.blk_coef.p, A.blk_cn.p, s->z.p, A.ds.p, s->y.p, s->mass.p, s->bconst.p, s->fixed.p,
@@ -593,8 +592,7 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
     if (n > 0) {
       if (scheme == PG_SCHEME_CN) {
         hipLaunchKernelGGL(k_scale_state, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, stream, n, A.ds.p, s->x.p, s->z.p, 1);
-        if (A.halo_needed) halo_exchange(s->nb, s->slab, s->z.p, stream);
-        spmv(A, s->z.p, s->y.p, stream);
+        spmv_halo(A, s->nb, s->slab, s->z.p, s->y.p, stream);
       }
       hipLaunchKernelGGL(k_rhs, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, stream, n, scheme, s->x.p, s->y.p, A.ds.p, s->mass.p,
                          s->bconst.p, s->fixed.p, s->b.p);

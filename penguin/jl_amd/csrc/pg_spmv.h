@@ -125,6 +125,9 @@ __device__ inline double load_partial(const double* p) {
                                                             __HIP_MEMORY_SCOPE_AGENT));
 }
 
+// store (accum == 0) or add to (accum != 0) one partial sum
+__device__ inline void put_partial(double* p, double v, int accum) { store_partial(p, accum ? v + load_partial(p) : v); }
+
 __device__ inline bool last_block_arrives(unsigned* ticket, unsigned nblocks, double* sh /* >= 1 double of LDS */) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -149,13 +152,14 @@ struct FinArgs {
   int do_derive;      // 0: sums only (several ranks: an all-reduce follows)
 };
 
-// executed by every block at the end of a producing launch (after its partials are stored)
-__device__ inline void fold_scalar_phase(const FinArgs& fin, const double* __restrict__ partials, double* s_red) {
+// executed by every block at the end of a producing launch (after its partials are stored); nparts = partial sums per
+// slot (the slot stride; == gridDim.x unless the launch completes an earlier, larger one)
+__device__ inline void fold_scalar_phase(const FinArgs& fin, const double* __restrict__ partials, double* s_red, int nparts) {
   if (!fin.ticket) return;
   if (!last_block_arrives(fin.ticket, gridDim.x, s_red)) return;
   for (int sl = 0; sl < fin.nslots; ++sl) {
     double a = 0.0;
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += BLOCK) a += load_partial(partials + (size_t)sl * gridDim.x + i);
+    for (int i = threadIdx.x; i < nparts; i += BLOCK) a += load_partial(partials + (size_t)sl * nparts + i);
     const double t = block_sum(a, s_red);
     if (threadIdx.x == 0) fin.sc[S_RED0 + sl] = t;
   }
@@ -169,6 +173,13 @@ __device__ inline void fold_scalar_phase(const FinArgs& fin, const double* __res
 // does that (the stencil-slice kernel), false when the caller still has to launch the scalar kernel itself.
 bool launch_spmv(int mode, const CsrMatrix& A, const double* x, double* y, const double* aux, double* partials,
                  const double* sc, int grid, hipStream_t st, const FinArgs* fin = nullptr);
+// y = A x on a slab whose x needs a halo exchange first (C1 of SURVEY.md 2.3): the exchange of x's ghost segments runs on
+// the communication stream while the slices that reference no ghost column are multiplied; the slices that do (rows of
+// the first / last owned plane) follow in a second, small launch once the halo has landed, adding their partial sums
+// to the first launch's.  Falls back to exchange-then-multiply for the CSR kernels or when nothing can be split off.
+// Same arguments and return value as launch_spmv; x is non-const because its ghost segments are received into.
+bool spmv_with_halo(int mode, const CsrMatrix& A, const Numbering& nb, const Slab& slab, double* x, double* y, const double* aux,
+                    double* partials, const double* sc, int grid, hipStream_t st, const FinArgs* fin = nullptr);
 // plain y = A x with an explicit kernel variant (PG_SPMV_VARIANT numbering): kernel-vs-kernel parity checks
 void launch_spmv_variant(int variant, const CsrMatrix& A, const double* x, double* y, hipStream_t st);
 int spmv_default_grid(i64 n);

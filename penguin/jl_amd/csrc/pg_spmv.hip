@@ -25,6 +25,7 @@
 #include <thread>
 #include <vector>
 
+#include "pg_krylov.h"
 #include "pg_spmv.h"
 
 namespace pg {
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_s(i64 nslices, const int* __rest
                                                   const double* __restrict__ g_val, const double* __restrict__ x,
                                                   double* __restrict__ y, const double* __restrict__ aux,
                                                   double* __restrict__ partials, const double* __restrict__ sc, int xcd,
-                                                  FinArgs fin) {
+                                                  FinArgs fin, int pstride, int accum) {
   __shared__ __attribute__((aligned(16))) double s_val[BLOCK / 64][512];
   __shared__ __attribute__((aligned(16))) int s_col[BLOCK / 64][512];
   __shared__ double s_red[BLOCK / 64];
@@ -479,26 +480,32 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_s(i64 nslices, const int* __rest
     rec = rec_n;
   }
   // (write-through stores: the last block of this launch may read them, see fold_scalar_phase)
+  // pstride = blocks per partial slot (the grid the Krylov workspace was sized for; >= gridDim.x).  accum: this launch
+  // covers the rows left out by an earlier launch of the same product (spmv_with_halo: the rows that had to wait for
+  // the halo) and adds its sums to that launch's -- which has completed: same stream.
   if (MODE >= 1) {
     const double t0 = block_sum(acc0, s_red);
-    if (threadIdx.x == 0) store_partial(partials + blockIdx.x, t0);
+    if (threadIdx.x == 0) put_partial(partials + blockIdx.x, t0, accum);
   }
   if (MODE >= 2) {
     const double t1 = block_sum(acc1, s_red);
-    if (threadIdx.x == 0) store_partial(partials + gridDim.x + blockIdx.x, t1);
+    if (threadIdx.x == 0) put_partial(partials + pstride + blockIdx.x, t1, accum);
   }
   if (MODE == 3) {
     const double t2 = block_sum(acc2, s_red);
-    if (threadIdx.x == 0) store_partial(partials + 4 * (size_t)gridDim.x + blockIdx.x, t2);
+    if (threadIdx.x == 0) put_partial(partials + 4 * (size_t)pstride + blockIdx.x, t2, accum);
   }
-  if (MODE >= 1) fold_scalar_phase(fin, partials, s_red);
+  if (MODE >= 1) fold_scalar_phase(fin, partials, s_red, pstride);
 }
 
-// flags[r]: bit 0 = row r has the count and (col - row) offsets of row r-1, bit 1 = and bitwise the same values
+// flags[r]: bit 0 = row r has the count and (col - row) offsets of row r-1, bit 1 = and bitwise the same values,
+// bit 2 = row r references a ghost column (col >= n: its product needs the halo exchange of x to have landed)
 __global__ void k_row_same(i64 n, const int* __restrict__ rowptr, const int* __restrict__ col,
                            const double* __restrict__ val, unsigned char* __restrict__ flags) {
   for (i64 r = blockIdx.x * (i64)blockDim.x + threadIdx.x; r < n; r += (i64)gridDim.x * blockDim.x) {
     unsigned char f = 0;
+    bool ghost = false;
+    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) ghost = ghost || col[k] >= n;
     if (r > 0) {
       const int a = rowptr[r], b = rowptr[r + 1], pa = rowptr[r - 1];
       if (b - a == a - pa) {
@@ -510,7 +517,7 @@ __global__ void k_row_same(i64 n, const int* __restrict__ rowptr, const int* __r
         f = same ? (vsame ? 3 : 1) : 0;
       }
     }
-    flags[r] = f;
+    flags[r] = f | (ghost ? 4 : 0);
   }
 }
 
@@ -577,20 +584,26 @@ namespace {
   hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL), dim3(grid), dim3(BLOCK), 0, st, A.n, A.nchunks, A.chunk_desc.p, \
                      A.rowptr.p, A.col.p, A.val.p, x, y, aux, partials, sc)
 
+// slices [s0, s0 + ns) of the slice image (the whole image: 0, A.nslices); `grid` blocks, partial slots `pstride` apart
+template <int MODE>
+bool launch_slices(int v, const CsrMatrix& A, i64 s0, i64 ns, const double* x, double* y, const double* aux, double* partials,
+                   const double* sc, int grid, int pstride, int accum, hipStream_t st, const FinArgs* fin) {
+  FinArgs fa{nullptr, nullptr, PH_NONE, 0, 0};
+  if (fin && MODE >= 1) fa = *fin;
+  const int* rec = A.srec.p + SL_REC * s0;
+  if (v & 4)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_s<MODE, true>), dim3(grid), dim3(BLOCK), 0, st, ns, rec, A.pval.p,
+                       A.g_rowid.p, A.g_rowptr.p, A.g_col.p, A.g_val.p, x, y, aux, partials, sc, xcd_map(), fa, pstride, accum);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_s<MODE, false>), dim3(grid), dim3(BLOCK), 0, st, ns, rec, A.pval.p,
+                       A.g_rowid.p, A.g_rowptr.p, A.g_col.p, A.g_val.p, x, y, aux, partials, sc, xcd_map(), fa, pstride, accum);
+  return fa.ticket != nullptr;
+}
+
 template <int MODE>
 bool launch_mode(int v, const CsrMatrix& A, const double* x, double* y, const double* aux, double* partials,
                  const double* sc, int grid, hipStream_t st, const FinArgs* fin) {
-  if (v & 64) {
-    FinArgs fa{nullptr, nullptr, PH_NONE, 0, 0};
-    if (fin && MODE >= 1) fa = *fin;
-    if (v & 4)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_s<MODE, true>), dim3(grid), dim3(BLOCK), 0, st, A.nslices, A.srec.p, A.pval.p,
-                         A.g_rowid.p, A.g_rowptr.p, A.g_col.p, A.g_val.p, x, y, aux, partials, sc, xcd_map(), fa);
-    else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_s<MODE, false>), dim3(grid), dim3(BLOCK), 0, st, A.nslices, A.srec.p, A.pval.p,
-                         A.g_rowid.p, A.g_rowptr.p, A.g_col.p, A.g_val.p, x, y, aux, partials, sc, xcd_map(), fa);
-    return fa.ticket != nullptr;
-  }
+  if (v & 64) return launch_slices<MODE>(v, A, 0, A.nslices, x, y, aux, partials, sc, grid, grid, 0, st, fin);
   if (v != 1) ensure_csr_chunks(A);
   if (v == 1) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv<MODE>), dim3(grid), dim3(BLOCK), 0, st, A.n, A.rowptr.p, A.col.p, A.val.p, x, y,
@@ -611,6 +624,7 @@ namespace {
 struct Slice {
   int r0, meta, base, aux;
   int key;   // first matrix row (sort key)
+  int bnd;   // 1: some row references a ghost column (the slice waits for the halo exchange)
 };
 
 // stencil-slice image of A (see "stencil slices" above); rp = host copy of A.rowptr
@@ -638,7 +652,9 @@ void build_slices(CsrMatrix& A, const int* rp) {
       const i64 maxrows = type == SL_U ? SL_MAXROWS_U : SL_MAXROWS_P;
       for (i64 r = a; r < b; r += maxrows) {
         const int rows = (int)std::min<i64>(maxrows, b - r);
-        out.up.push_back(Slice{(int)r, rows | (type << 8) | (cnt << 16), 0, 0, (int)r});
+        int bnd = 0;
+        for (i64 q = r; q < r + rows; ++q) bnd |= (fl[q] >> 2) & 1;
+        out.up.push_back(Slice{(int)r, rows | (type << 8) | (cnt << 16), 0, 0, (int)r, bnd});
       }
       (type == SL_U ? out.rows_u : out.rows_p) += b - a;
       if (type == SL_P) out.nnz_p += (b - a) * cnt;
@@ -717,8 +733,12 @@ void build_slices(CsrMatrix& A, const int* rp) {
     }
   }
   A.pval.alloc(A.nnz_p + 8);
-  // packed CSR of the irregular rows + its chunks
+  // packed CSR of the irregular rows + its chunks: the rows that reference a ghost column go last, so that no chunk
+  // mixes rows that can be multiplied before the halo has landed with rows that cannot
+  std::stable_partition(grows.begin(), grows.end(), [&](int r) { return (fl[r] & 4) == 0; });
   const i64 ng = (i64)grows.size();
+  i64 ng_int = 0;
+  while (ng_int < ng && (fl[grows[ng_int]] & 4) == 0) ++ng_int;
   A.rows_g = ng;
   std::vector<int> grp(ng + 1, 0);
   for (i64 q = 0; q < ng; ++q) grp[q + 1] = grp[q] + (rp[grows[q] + 1] - rp[grows[q]]);
@@ -740,13 +760,17 @@ void build_slices(CsrMatrix& A, const int* rp) {
     while (q < ng) {
       i64 e = q + 1;
       PG_REQUIRE(grp[e] - grp[q] <= SPMV_CHUNK_ENTRIES, "CSR row longer than an SpMV chunk");
-      while (e < ng && e - q < 64 && grp[e + 1] - grp[q] <= SPMV_CHUNK_ENTRIES) ++e;
-      all.push_back(Slice{(int)q, (int)(e - q) | (SL_G << 8), grp[q], grp[e], grows[q]});
+      const i64 stop = q < ng_int ? ng_int : ng;   // chunks end at the interior / boundary seam
+      while (e < stop && e - q < 64 && grp[e + 1] - grp[q] <= SPMV_CHUNK_ENTRIES) ++e;
+      all.push_back(Slice{(int)q, (int)(e - q) | (SL_G << 8), grp[q], grp[e], grows[q], q >= ng_int ? 1 : 0});
       q = e;
     }
   }
-  std::stable_sort(all.begin(), all.end(), [](const Slice& a, const Slice& b) { return a.key < b.key; });
+  // by first row within each group; the slices that wait for the halo form the tail [nslices_int, nslices)
+  std::stable_sort(all.begin(), all.end(), [](const Slice& a, const Slice& b) { return a.bnd != b.bnd ? a.bnd < b.bnd : a.key < b.key; });
   A.nslices = (i64)all.size();
+  A.nslices_int = 0;
+  while (A.nslices_int < A.nslices && !all[A.nslices_int].bnd) ++A.nslices_int;
   std::vector<int> sd(SL_REC * (A.nslices + 1), 0);
   for (i64 q = 0; q < A.nslices; ++q) {
     int* rec = sd.data() + SL_REC * q;
@@ -768,8 +792,8 @@ void build_slices(CsrMatrix& A, const int* rp) {
   laps.lap("    slices: packing + records");
   A.spmv_bytes = 4 * SL_REC * A.nslices + 8 * A.nnz_p + 12 * A.nnz_g + 8 * ng + 16 * n;
   if (getenv("PG_DEBUG"))
-    fprintf(stderr, "[pg_spmv] slices %lld: rows U %lld P %lld G %lld of %lld; nnz P %lld G %lld of %lld; bytes/launch %lld (CSR %lld)\n",
-            (long long)A.nslices, (long long)A.rows_u, (long long)A.rows_p, (long long)A.rows_g,
+    fprintf(stderr, "[pg_spmv] slices %lld (%lld wait for the halo): rows U %lld P %lld G %lld of %lld; nnz P %lld G %lld of %lld; bytes/launch %lld (CSR %lld)\n",
+            (long long)A.nslices, (long long)(A.nslices - A.nslices_int), (long long)A.rows_u, (long long)A.rows_p, (long long)A.rows_g,
             (long long)n, (long long)A.nnz_p, (long long)A.nnz_g, (long long)A.nnz, (long long)A.spmv_bytes,
             (long long)(12 * A.nnz + 20 * n));
 }
@@ -854,6 +878,7 @@ bool build_slices_like(const CsrMatrix& T, CsrMatrix& A) {
   A.chunk_desc.release();
   A.nchunks = 0;
   A.nslices = T.nslices;
+  A.nslices_int = T.nslices_int;
   A.rows_u = T.rows_u; A.rows_p = T.rows_p; A.rows_g = T.rows_g; A.nnz_p = T.nnz_p; A.nnz_g = T.nnz_g;
   A.spmv_bytes = T.spmv_bytes;
   clone_buf(A.srec, T.srec, st);
@@ -898,6 +923,36 @@ bool launch_spmv(int mode, const CsrMatrix& A, const double* x, double* y, const
   if (mode == 1) return launch_mode<1>(v, A, x, y, aux, partials, sc, grid, st, fin);
   if (mode == 2) return launch_mode<2>(v, A, x, y, aux, partials, sc, grid, st, fin);
   return launch_mode<3>(v, A, x, y, aux, partials, sc, grid, st, fin);
+}
+
+bool spmv_with_halo(int mode, const CsrMatrix& A, const Numbering& nb, const Slab& slab, double* x, double* y, const double* aux,
+                    double* partials, const double* sc, int grid, hipStream_t st, const FinArgs* fin) {
+  if (A.n == 0 || !A.halo_needed) {
+    // (a rank without rows still takes part in the exchange: its neighbours receive from it)
+    if (A.halo_needed) halo_exchange(nb, slab, x, st);
+    return launch_spmv(mode, A, x, y, aux, partials, sc, grid, st, fin);
+  }
+  const int v = variant();
+  static const bool overlap = getenv("PG_HALO_OVERLAP") ? atoi(getenv("PG_HALO_OVERLAP")) != 0 : true;
+  const i64 ni = A.nslices_int, nbnd = A.nslices - A.nslices_int;
+  if (!(v & 64) || !overlap || ni == 0 || nbnd == 0) {
+    halo_exchange(nb, slab, x, st);
+    return launch_spmv(mode, A, x, y, aux, partials, sc, grid, st, fin);
+  }
+  // blocks of the second launch: one wave per slice, never more blocks than partial-sum entries per slot
+  const int grid2 = (int)std::max<i64>(1, std::min<i64>(grid, (nbnd + BLOCK / 64 - 1) / (BLOCK / 64)));
+  halo_begin(nb, slab, x, st);                      // x's owned part is final on `st`; ghosts arrive on the comm stream
+  bool folded;
+#define PG_SPLIT(MODE_)                                                                                              \
+  launch_slices<MODE_>(v, A, 0, ni, x, y, aux, partials, sc, grid, grid, 0, st, nullptr);                           \
+  halo_end(st);                                                                                                      \
+  folded = launch_slices<MODE_>(v, A, ni, nbnd, x, y, aux, partials, sc, grid2, grid, 1, st, fin)
+  if (mode == 0) { PG_SPLIT(0); }
+  else if (mode == 1) { PG_SPLIT(1); }
+  else if (mode == 2) { PG_SPLIT(2); }
+  else { PG_SPLIT(3); }
+#undef PG_SPLIT
+  return folded;
 }
 
 void launch_spmv_variant(int v, const CsrMatrix& A, const double* x, double* y, hipStream_t st) {

@@ -59,6 +59,7 @@ struct CsrMatrix {
   DevBuf<int> g_rowid, g_rowptr, g_col;
   DevBuf<double> g_val;
   i64 nslices = 0;
+  i64 nslices_int = 0;   // slices [0, nslices_int) reference no ghost column (computable before the halo of x has landed)
   DevBuf<unsigned char> rowflags;   // k_row_same flags the slices were cut from (structure reuse, assemble_csr_like)
   i64 rows_u = 0, rows_p = 0, rows_g = 0, nnz_p = 0, nnz_g = 0;
   i64 spmv_bytes = 0;        // bytes one launch has to move with this format: records + P/G streams + 16 n (x, y)

@@ -2,7 +2,7 @@
 run the (n, n, n*nranks) grid with one sphere per slab -- the problem `bench.py --gpus nranks` gives to real ranks.
 Catches what small grids cannot: 2M > 2^31 padded unknowns at 8 x 512^3, per-rank sizes, partition balance.
 
-    python scripts/virtual_ranks_fullsize.py [nranks=8] [n=512] [steps=3]
+    python scripts/virtual_ranks_fullsize.py [nranks=8] [n=512] [steps=3] [strong]
 """
 import ctypes as C
 import json
@@ -40,8 +40,14 @@ def run(nr, zf):
     return dict(n_own=n_own.tolist(), nnz=nnz.tolist(), n_ghost=ngh.tolist(), iters=its.tolist(), wall_s=time.time() - t0)
 
 
+strong = len(sys.argv) > 4 and sys.argv[4] == "strong"   # the SAME n^3 sphere problem cut into slabs: every rank exchanges halos
 one = run(1, 1)
-many = run(nranks, nranks)
+many = run(nranks, 1 if strong else nranks)
+if strong:
+    ok = (sum(many["n_own"]) == one["n_own"][0] and sum(many["nnz"]) == one["nnz"][0] and len(set(many["iters"])) == 1
+          and abs(many["iters"][0] - one["iters"][0]) <= 2 and all(g > 0 for g in many["n_ghost"]))
+    print(json.dumps({"nranks": nranks, "n": n, "strong": True, "one_rank": one, "virtual": many, "slabs_sum_to_one_rank": ok}))
+    sys.exit(0 if ok else 1)
 # the spheres sit at 2.01 + 4s: the last bits of (z - c) differ from slab to slab, so a handful of cut cells may differ
 close = lambda a, b: abs(a - b) <= 1e-3 * b
 ok = (all(close(v, one["n_own"][0]) for v in many["n_own"]) and all(close(v, one["nnz"][0]) for v in many["nnz"])
