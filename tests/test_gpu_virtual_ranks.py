@@ -33,3 +33,18 @@ def test_virtual_ranks_reproduce_single_rank():
     # one sphere per slab (the weak-scaling body): the partition by active rows is balanced
     v = out["two_spheres_2"]
     assert max(v["n_own"]) <= 1.15 * min(v["n_own"])
+
+
+def test_strong_scaling_shape_splits_the_spmv_around_the_halo():
+    """One 96^3 sphere problem cut into 3 slabs (every rank exchanges halos): the slices that wait for the halo run in a
+    second launch that accumulates into the first one's partial sums (spmv_with_halo); sizes add up to the 1-rank system
+    and the Krylov history matches it, with the overlap split and without."""
+    import os
+    for overlap in ("1", "0"):
+        r = subprocess.run([sys.executable, str(ROOT / "scripts" / "virtual_ranks_fullsize.py"), "3", "96", "2", "strong"], cwd=ROOT,
+                           capture_output=True, text=True, timeout=300, env={**os.environ, "PG_HALO_OVERLAP": overlap, "PG_DEBUG": "1"})
+        assert r.returncode == 0, (overlap, r.stdout[-500:], r.stderr[-1500:])
+        out = json.loads(r.stdout.strip().splitlines()[-1])
+        assert out["slabs_sum_to_one_rank"], out
+        waits = [int(l.split("(")[1].split()[0]) for l in r.stderr.splitlines() if l.startswith("[pg_spmv] slices")]
+        assert any(w > 0 for w in waits), r.stderr[-1500:]          # some slices do wait for the halo
