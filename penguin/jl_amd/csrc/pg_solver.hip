@@ -294,7 +294,7 @@ __global__ void k_maxabs(i64 n, const double* x, const double* ds /*NULL: x is u
   sh[threadIdx.x] = m;
   __syncthreads();
   for (int s = BLOCK / 2; s > 0; s >>= 1) {
-    if (threadIdx.x < s) sh[threadIdx.x] = sh[threadIdx.x] > sh[threadIdx.x + s] ? sh[threadIdx.x] : sh[threadIdx.x + s];
+    if ((int)threadIdx.x < s) sh[threadIdx.x] = sh[threadIdx.x] > sh[threadIdx.x + s] ? sh[threadIdx.x] : sh[threadIdx.x + s];
     __syncthreads();
   }
   if (threadIdx.x == 0) partials[blockIdx.x] = sh[0];
