@@ -95,6 +95,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv(i64 n, const int* __restrict__ r
 
 // ---- chunked wave kernel ---------------------------------------------------------------------------------------
 constexpr int WUNR = 8;                          // gathers issued together per row (bulk rows: 2N+1 <= 7)
+constexpr int GUNR = 4;                          // slice kernel, irregular rows: LDS (value, x) pairs read per round
 
 template <bool NT, class T>
 __device__ inline T stream_load(const T* p) {
@@ -385,15 +386,15 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_s(i64 nslices, const int* __rest
                                                   double* __restrict__ partials, const double* __restrict__ sc, int xcd,
                                                   FinArgs fin, int pstride, int accum) {
   __shared__ __attribute__((aligned(16))) double s_val[BLOCK / 64][512];
-  __shared__ __attribute__((aligned(16))) int s_col[BLOCK / 64][512];
+  __shared__ __attribute__((aligned(16))) double s_x[BLOCK / 64][512];   // G chunks: x[col] of every entry of the chunk
   __shared__ double s_red[BLOCK / 64];
   if (sc && sc[S_DONE] != 0.0) return;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   double* __restrict__ sv = s_val[wave];
-  int* __restrict__ scl = s_col[wave];
+  double* __restrict__ sx = s_x[wave];
   d2_t* sv2 = reinterpret_cast<d2_t*>(sv);
-  i4_t* sc4 = reinterpret_cast<i4_t*>(scl);
+  d2_t* sx2 = reinterpret_cast<d2_t*>(sx);
   double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
   // diagnostics (PG_SPMV_XCD bits 8..; results are wrong with any of them): 1 skip G chunks, 2 skip U/P slices,
   // 4 every x load hits one line, 8 no y stores in U/P slices
@@ -441,13 +442,27 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_s(i64 nslices, const int* __rest
       const int av = q.ra - basev, ac = q.ra - basec, len = q.rb - q.ra;
 #pragma unroll
       for (int j = 0; j < XV_IT; ++j) sv2[lane + 64 * j] = q.v[j];
+      // the dot operands of the row ride with the gathers (issued before the LDS phase, not after it)
+      const double auxr = (MODE == 1 || MODE == 3) ? aux[rid] : 0.0;
+      const double xr = MODE >= 2 ? x[rid] : 0.0;
+      // ENTRY-parallel x gathers: lane l holds the columns of entries 4l..4l+3 (and 256 + 4l..), so neighbouring lanes
+      // gather for the same or the next row and one gather instruction touches ~20 cache lines -- a row per lane (the CSR
+      // kernel's way) touches 64, and the vector-memory unit serves a line per cycle.  The x values go to LDS next to the
+      // matrix values; the row sums then read LDS only, in CSR entry order (bitwise the CSR kernels' result).
+      double xg[XC_IT][4];
 #pragma unroll
-      for (int j = 0; j < XC_IT; ++j) sc4[lane + 64 * j] = q.c[j];
+      for (int j = 0; j < XC_IT; ++j) {
+        xg[j][0] = x[q.c[j].x]; xg[j][1] = x[q.c[j].y]; xg[j][2] = x[q.c[j].z]; xg[j][3] = x[q.c[j].w];
+      }
+#pragma unroll
+      for (int j = 0; j < XC_IT; ++j) {
+        d2_t lo2, hi2;
+        lo2.x = xg[j][0]; lo2.y = xg[j][1]; hi2.x = xg[j][2]; hi2.y = xg[j][3];
+        sx2[2 * (lane + 64 * j)] = lo2;
+        sx2[2 * (lane + 64 * j) + 1] = hi2;
+      }
       __builtin_amdgcn_wave_barrier();
-      const int c0 = dd.base - basec;
       double sum = 0.0;
-      // rounds of 8 gathers issued together (irregular rows often hold 9..14 entries: a per-entry tail loop would
-      // expose one full memory latency per entry)
       int maxlen = len;
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) {
@@ -455,26 +470,27 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_s(i64 nslices, const int* __rest
         maxlen = other > maxlen ? other : maxlen;
       }
       maxlen = __builtin_amdgcn_readfirstlane(maxlen);
-      for (int j0 = 0; j0 < maxlen; j0 += WUNR) {
-        double xv[WUNR], vv[WUNR];
+      for (int j0 = 0; j0 < maxlen; j0 += GUNR) {   // LDS reads of a round issued together
+        double vv[GUNR], xv[GUNR];
 #pragma unroll
-        for (int j = 0; j < WUNR; ++j) {
-          const bool ok = j0 + j < len;
-          xv[j] = x[scl[ok ? ac + j0 + j : c0]];
-          vv[j] = ok ? sv[av + j0 + j] : 0.0;
+        for (int j = 0; j < GUNR; ++j) {
+          const int k = j0 + j < len ? j0 + j : 0;
+          vv[j] = sv[av + k];
+          xv[j] = sx[ac + k];
         }
 #pragma unroll
-        for (int j = 0; j < WUNR; ++j) sum += vv[j] * xv[j];
+        for (int j = 0; j < GUNR; ++j)
+          if (j0 + j < len) sum += vv[j] * xv[j];
       }
       __builtin_amdgcn_wave_barrier();
       if (live) {
         y[rid] = sum;
-        if (MODE == 1) acc0 += aux[rid] * sum;
+        if (MODE == 1) acc0 += auxr * sum;
         if (MODE >= 2) {
-          acc0 += sum * x[rid];
+          acc0 += sum * xr;
           acc1 += sum * sum;
         }
-        if (MODE == 3) acc2 += aux[rid] * sum;
+        if (MODE == 3) acc2 += auxr * sum;
       }
     }
     rec = rec_n;
