@@ -16,4 +16,9 @@ from .api import (  # noqa: F401
     check_convergence, div, grad, lp_norm, nC, solve_DarcyFlow_b, solve_DarcyFlowUnsteady_b, solve_darcy_velocity, solve_DiffusionSteadyDiph_b, solve_DiffusionSteadyMono_b,
     solve_DiffusionUnsteadyDiph_b, solve_DiffusionUnsteadyMono_b,
 )
+from .utils import (  # noqa: F401,E402
+    cfl_restriction, initialize_poiseuille_velocity_field, initialize_radial_velocity_field,
+    initialize_rotating_velocity_field, initialize_temperature_circle_b, initialize_temperature_function_b,
+    initialize_temperature_square_b, initialize_temperature_uniform_b,
+)
 from .vtk import write_vtk  # noqa: F401,E402
