@@ -290,6 +290,14 @@ __global__ void k_plane_weights(GeoView g, BallSet bs, i64 plane_lo, i64 plane_h
     pick_ball(bs, lo, hi, type);
     if (type != PG_CUT && bs.complement) type = 1 - type;
     if (type != PG_EMPTY) atomicAdd(&weight[p], type == PG_CUT ? 2ull : 1ull);
+    else {
+      // an empty cell on a lateral face of the box still becomes a row when a border condition is set there (identity
+      // row of BC_border_mono!): 1.05 M of the 10.3 M rows of the 512^3 benchmark problem, spread over ALL planes --
+      // left out, the slabs outside the body end up 20 % larger than the others when one body is cut into 8 slabs
+      bool lateral = false;
+      for (int d = 0; d < g.N - 1; ++d) lateral = lateral || idx[d] == 0 || idx[d] == g.n[d] - 1;
+      if (lateral) atomicAdd(&weight[p], 1ull);
+    }
   }
 }
 
