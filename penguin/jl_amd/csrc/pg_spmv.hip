@@ -415,12 +415,13 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_s(i64 nslices, const int* __rest
   }
   const i64 lastc = hi - 1;
   const int l31 = lane & 31;
-  // the record of a slice is fetched with ONE vector load one slice ahead (lane l reads dword l & 31) and its
+  // the record of a slice is fetched with ONE vector load TWO slices ahead (lane l reads dword l & 31) and its
   // wave-uniform fields are broadcast with v_readlane
   int rec = first < hi ? srec[SL_REC * first + l31] : 0;
+  int rec_n = srec[SL_REC * (first + wstride < hi ? first + wstride : (first < hi ? lastc : 0)) + l31];
   for (i64 chunk = first; chunk < hi; chunk += wstride) {
-    const i64 cn = chunk + wstride;
-    const int rec_n = srec[SL_REC * (cn < hi ? cn : lastc) + l31];
+    const i64 cnn = chunk + 2 * wstride;
+    const int rec_nn = srec[SL_REC * (cnn < hi ? cnn : lastc) + l31];
     SDesc d;
     d.r0 = rlane(rec, 0); d.meta = rlane(rec, 1); d.base = rlane(rec, 2); d.aux = rlane(rec, 3);
     const int nrows = d.meta & 255, type = (d.meta >> 8) & 3, cnt = d.meta >> 16;
@@ -494,6 +495,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_s(i64 nslices, const int* __rest
       }
     }
     rec = rec_n;
+    rec_n = rec_nn;
   }
   // (write-through stores: the last block of this launch may read them, see fold_scalar_phase)
   // pstride = blocks per partial slot (the grid the Krylov workspace was sized for; >= gridDim.x).  accum: this launch
