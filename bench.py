@@ -14,8 +14,9 @@ N > 1 is weak scaling: grid (n, n, n*N), domain (4, 4, 4
 slab-decomposed along z with RCCL halo exchange + dot all-reduce inside libpenguin_hip.so; `value` is the
 aggregate n^3-subdomain time-steps per second (N x global steps/s).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = CSR
-SpMV, HIP-event timed on the library stream inside the timed region) and `cpu_baseline` (the oracle's C
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = the
+SpMV, HIP-event timed on the library stream inside the timed region), `step_roofline` (the whole time step's
+algorithmic bytes over its wall time) and `cpu_baseline` (the oracle's C
 restatement of the same Krylov loop on the same matrix, on the host cores of this box; rank 0, N=1 only).
 """
 from __future__ import annotations
@@ -215,6 +216,24 @@ def main() -> None:
             "avg_launch_ms": spmv_ms,
             "launches_timed": int(run.spmv_launches),
         },
+    }
+
+    # The whole SpMV-bound time step against the same roofline (north star: ">= 60 % of the HBM roofline on the SpMV-bound
+    # time-step"): algorithmic bytes of one CN step of THIS loop on this rank -- every kernel's operand vectors once, the
+    # matrix in the format that is streamed --
+    #   per BiCGStab iteration: 2 SpMV (format bytes, x and y included) + r-hat in both (2 x 8n) + k_bicg_s (r, v, r-hat -> s:
+    #   4 x 8n) + k_bicg_xrp (x, p, s, t, v -> x, r, p: 8 x 8n)  = 2 spmv_bytes + 112 n
+    #   per step: + the right-hand side's SpMV (spmv_bytes) + k_rhs_init (74 n)
+    # divided by the measured wall time of the step (launch gaps, host polls and the per-step kernels included).
+    b_fmt = int(sysinfo.spmv_bytes)
+    step_bytes = (2.0 * iters + 1.0) * b_fmt + iters * 112.0 * n_rows + 74.0 * n_rows
+    step_gbs = step_bytes / (elapsed / args.steps) / 1e9
+    out["step_roofline"] = {
+        "what": "one CN time step of the loop on rank 0: (2 iters + 1) SpMV format bytes + iters x 112 n (BiCGStab vector "
+                "kernels and the r-hat dot operands) + 74 n (right-hand side), over the wall time per step",
+        "bound": "hbm", "bytes_per_step": step_bytes, "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": step_gbs / HBM_PEAK_GBS,
+        "survey_8d_bytes_per_step": iters * (2.0 * b_csr + 168.0 * n_rows) + 48.0 * n_rows + 16.0 * n_rows,
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
