@@ -226,11 +226,20 @@ def main() -> None:
     #   per step: + the right-hand side's SpMV (spmv_bytes) + k_rhs_init (74 n)
     # divided by the measured wall time of the step (launch gaps, host polls and the per-step kernels included).
     b_fmt = int(sysinfo.spmv_bytes)
-    step_bytes = (2.0 * iters + 1.0) * b_fmt + iters * 112.0 * n_rows + 74.0 * n_rows
+    neumann = bool(sysinfo.neumann_ok) and os.environ.get("PG_POLY", "1") != "0"
+    if neumann:
+        # right-preconditioned iteration (M^-1 = 2I - A): 4 SpMVs (two of them with the 2x - Ax epilogue, no r-hat), the
+        # separate (t, s) operand, k_bicg_s (4 vectors) and k_bicg_xrp with u and u_s (10 vectors):
+        # 4 spmv_bytes + (2 + 1 + 4 + 10) x 8 n = 4 spmv_bytes + 136 n
+        step_bytes = (4.0 * iters + 1.0) * b_fmt + iters * 136.0 * n_rows + 74.0 * n_rows
+    else:
+        step_bytes = (2.0 * iters + 1.0) * b_fmt + iters * 112.0 * n_rows + 74.0 * n_rows
     step_gbs = step_bytes / (elapsed / args.steps) / 1e9
     out["step_roofline"] = {
-        "what": "one CN time step of the loop on rank 0: (2 iters + 1) SpMV format bytes + iters x 112 n (BiCGStab vector "
-                "kernels and the r-hat dot operands) + 74 n (right-hand side), over the wall time per step",
+        "what": ("one CN time step of the loop on rank 0: (4 iters + 1) SpMV format bytes + iters x 136 n" if neumann else
+                 "one CN time step of the loop on rank 0: (2 iters + 1) SpMV format bytes + iters x 112 n") +
+                " (BiCGStab vector kernels and the dot operands) + 74 n (right-hand side), over the wall time per step",
+        "neumann_preconditioner": neumann, "gershgorin_radius": float(sysinfo.gershgorin),
         "bound": "hbm", "bytes_per_step": step_bytes, "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": step_gbs / HBM_PEAK_GBS,
         "survey_8d_bytes_per_step": iters * (2.0 * b_csr + 168.0 * n_rows) + 48.0 * n_rows + 16.0 * n_rows,

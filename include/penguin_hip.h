@@ -119,6 +119,9 @@ typedef struct {
   int64_t rows_uniform;   /* rows in U slices (shared offsets and values, nothing streamed)      */
   int64_t rows_pattern;   /* rows in P slices (shared offsets, 8 B/entry value stream)           */
   int64_t rows_irregular; /* rows in G chunks (packed CSR, 12 B/entry)                           */
+  int64_t neumann_ok;     /* 1: the spectrum of the preconditioned matrix is provably inside |z - 1| < 0.95, BiCGStab
+                             runs right-preconditioned with M^-1 = 2I - A (half the iterations, same SpMV count) */
+  double gershgorin;      /* the largest Gershgorin radius that decision rests on (all ranks)     */
 } pg_system_info;
 
 /* ---- library / device -------------------------------------------------------------------- */

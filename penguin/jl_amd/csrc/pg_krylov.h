@@ -13,6 +13,7 @@ struct KrylovWork {
   int grid = 1;
   DevBuf<unsigned> ticket;              // arrival counter of the in-launch scalar phases (pg_spmv.h)
   int last_iters = 0;                   // iterations of the previous solve (sizes the first launch batch)
+  DevBuf<double> u, us;                 // M⁻¹p and M⁻¹s of the Neumann-preconditioned BiCGStab (n_vec each; on first use)
   // GMRES(m) only, allocated on first use (pg_gmres.hip): m+1 basis vectors, H / rotations / g, per-block partial sums
   DevBuf<double> gm_basis, gm, gm_partials;
   int gm_m = -1;

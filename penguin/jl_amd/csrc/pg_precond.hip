@@ -230,6 +230,38 @@ __global__ void k_count_ghost_refs(i64 nnz, i64 n_own, const int* __restrict__ c
   if (c) atomicAdd(out, c);
 }
 
+// largest Gershgorin radius |1 - â_ii| + Σ_{j != i} |â_ij| ds_i / ds_j over the rows with more than one entry, the
+// columns j that are identity rows (one entry, their own) left out; ghost columns count (their rows are not here)
+__global__ void k_gershgorin(i64 n, const int* __restrict__ rowptr, const int* __restrict__ col,
+                             const double* __restrict__ val, const double* __restrict__ ds, double* __restrict__ out) {
+  double worst = 0.0;
+  for (i64 r = blockIdx.x * (i64)blockDim.x + threadIdx.x; r < n; r += (i64)gridDim.x * blockDim.x) {
+    const int a = rowptr[r], b = rowptr[r + 1];
+    if (b - a <= 1) {
+      // identity-like row: eigenvalue = its diagonal (1 after equilibration)
+      const double d = b > a && col[a] == r ? fabs(1.0 - val[a]) : 1.0;
+      worst = d > worst ? d : worst;
+      continue;
+    }
+    double diag = 0.0, off = 0.0;
+    for (int k = a; k < b; ++k) {
+      const int c = col[k];
+      if (c == r) { diag = val[k]; continue; }
+      if (c < n && rowptr[c + 1] - rowptr[c] == 1 && col[rowptr[c]] == c) continue;   // column of an identity row
+      off += fabs(val[k]) * (ds[r] / ds[c]);
+    }
+    const double rad = fabs(1.0 - diag) + off;
+    worst = rad > worst ? rad : worst;
+  }
+  // max over the grid: values are >= 0, so the bit pattern orders like the number
+  for (int o = 32; o > 0; o >>= 1) {
+    const double other = __shfl_down(worst, o, 64);
+    worst = other > worst ? other : worst;
+  }
+  if ((threadIdx.x & 63) == 0)
+    atomicMax(reinterpret_cast<unsigned long long*>(out), (unsigned long long)__double_as_longlong(worst));
+}
+
 __global__ void k_pl_simple(i64 n, const double* __restrict__ ds, const double* __restrict__ in, double* __restrict__ out) {
   for (i64 r = blockIdx.x * (i64)blockDim.x + threadIdx.x; r < n; r += (i64)gridDim.x * blockDim.x) out[r] = ds[r] * in[r];
 }
@@ -296,6 +328,7 @@ void assemble_csr_preconditioned(const SysParams& P, const Slab& s, const Number
       nref.download(&h, 1);
       A.halo_needed = h != 0;
     }
+    decide_poly(A);
     return;
   }
   hipLaunchKernelGGL(k_point_scale, dim3(grid_for((i64)nb.K * nb.Mloc, 256, 256 * 16)), dim3(256), 0, st, P, nb.K, nb.Mloc,
@@ -359,6 +392,7 @@ void assemble_csr_preconditioned(const SysParams& P, const Slab& s, const Number
   laps.lap("  asm: count/fill/table kernels");
   build_spmv_chunks(A);
   laps.lap("  asm: SpMV chunks + slices");
+  decide_poly(A);
 }
 
 __global__ void k_structure_differs(i64 n, const int* __restrict__ cnt, const int* __restrict__ rowptr,
@@ -433,6 +467,26 @@ void assemble_csr_like(const SysParams& P, const Slab& s, const Numbering& nb, c
   laps.lap("  asm-like: values on the ctor matrix' pattern");
   if (!build_slices_like(T, A)) build_spmv_chunks(A);
   laps.lap("  asm-like: slices");
+  decide_poly(A);
+}
+
+void decide_poly(CsrMatrix& A) {
+  hipStream_t st = ctx().stream;
+  DevBuf<double> worst(1);
+  worst.zero();
+  if (A.n > 0) {
+    hipLaunchKernelGGL(k_gershgorin, dim3(grid_for(A.n, 256, 4096)), dim3(256), 0, st, A.n, A.rowptr.p, A.col.p, A.val.p, A.ds.p,
+                       worst.p);
+    PG_HIP(hipGetLastError());
+  }
+  comm_allreduce_max_f64(worst.p, 1, st);
+  double h = 0.0;
+  worst.download(&h, 1);
+  A.gersh = h;
+  A.poly_ok = h < 0.95;
+  if (getenv("PG_DEBUG"))
+    fprintf(stderr, "[pg_precond] rank %d: largest Gershgorin radius %.4f => Neumann preconditioner %s\n", ctx().rank, h,
+            A.poly_ok ? "admissible" : "not used");
 }
 
 // out = B⁻¹ S in   (in and out must not alias)

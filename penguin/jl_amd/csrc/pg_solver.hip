@@ -882,6 +882,8 @@ int32_t pg_solver_system_info(const pg_solver* s, int32_t which, pg_system_info*
   out->rows_uniform = A.rows_u;
   out->rows_pattern = A.rows_p;
   out->rows_irregular = A.rows_g;
+  out->neumann_ok = A.poly_ok ? 1 : 0;
+  out->gershgorin = A.gersh;
   PG_API_END
 }
 

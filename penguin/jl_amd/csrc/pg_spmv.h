@@ -150,6 +150,7 @@ struct FinArgs {
   int phase;          // PH_*
   int nslots;         // partial slots [0, nslots) to sum into S_RED0..
   int do_derive;      // 0: sums only (several ranks: an all-reduce follows)
+  const double* dotx; // operand of the (y, .) dot of modes 2 / 3; nullptr: the input vector x itself
 };
 
 // executed by every block at the end of a producing launch (after its partials are stored); nparts = partial sums per
@@ -166,6 +167,7 @@ __device__ inline void fold_scalar_phase(const FinArgs& fin, const double* __res
   if (threadIdx.x == 0 && fin.do_derive) derive(fin.phase, fin.sc);
 }
 
+// mode 4: y = 2x - A x (u = M⁻¹x for the Neumann preconditioner M⁻¹ = 2I - Â of the BiCGStab driver), no dots, slice kernel only.
 // y = A x on rows [0, A.n).  mode 0: plain; 1: partials[0..grid) = aux . y; 2: partials[0..grid) = y . x and
 // partials[grid..2grid) = y . y; 3: mode 2 plus partials[4grid..5grid) = aux . y.  `sc` (may be NULL): kernels return immediately when sc[S_DONE] != 0.
 // `grid` must be the value used to size `partials` (KrylovWork::grid) for modes 1/2.
@@ -183,5 +185,6 @@ bool spmv_with_halo(int mode, const CsrMatrix& A, const Numbering& nb, const Sla
 // plain y = A x with an explicit kernel variant (PG_SPMV_VARIANT numbering): kernel-vs-kernel parity checks
 void launch_spmv_variant(int variant, const CsrMatrix& A, const double* x, double* y, hipStream_t st);
 int spmv_default_grid(i64 n);
+bool spmv_supports_preconditioner_product();   // mode 4 and FinArgs::dotx exist in the slice kernel only (PG_SPMV_VARIANT)
 
 }  // namespace pg

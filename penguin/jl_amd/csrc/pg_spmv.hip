@@ -279,7 +279,8 @@ __device__ inline d2_t load_pair(const double* p) {
 template <int CNT, int NB, bool PSL, int MODE, bool NT>
 __device__ inline void slice_rows(const SDesc& d, int nrows, int rec, const double* __restrict__ pval,
                                   const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ aux,
-                                  int lane, double& acc0, double& acc1, double& acc2, int dbg) {
+                                  const double* __restrict__ dx, int lane, double& acc0, double& acc1, double& acc2, int dbg) {
+  constexpr bool DOTS = MODE >= 1 && MODE <= 3;   // MODE 4: y = 2x - Ax (the Neumann preconditioner), no dots
   int o[CNT];
 #pragma unroll
   for (int j = 0; j < CNT; ++j) o[j] = (dbg & 4) ? 0 : rlane(rec, 4 + j);
@@ -326,13 +327,15 @@ __device__ inline void slice_rows(const SDesc& d, int nrows, int rec, const doub
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     if (MODE == 1) ax[b] = load_pair<false>(aux + d.r0 + l0[b]);
-    else if (MODE >= 2) ax[b] = load_pair<false>(x + d.r0 + l0[b]);
+    else if (MODE == 2 || MODE == 3) ax[b] = load_pair<false>(dx + d.r0 + l0[b]);
+    else if (MODE == 4) ax[b] = load_pair<false>(x + d.r0 + l0[b]);      // the row's own x: y = 2x - Ax
     else { ax[b].x = 0.0; ax[b].y = 0.0; }
     if (MODE == 3) ax2[b] = load_pair<false>(aux + d.r0 + l0[b]);
     else { ax2[b].x = 0.0; ax2[b].y = 0.0; }
   }
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
+    if (MODE == 4) { sum[b].x = 2.0 * ax[b].x - sum[b].x; sum[b].y = 2.0 * ax[b].y - sum[b].y; }
     const bool st = !(dbg & 8) || sum[b].x == 1.2345e-300;
     double* yp = y + d.r0 + l0[b];
     if (live1[b]) {
@@ -341,13 +344,13 @@ __device__ inline void slice_rows(const SDesc& d, int nrows, int rec, const doub
         out.x = sum[b].x; out.y = sum[b].y;
         *reinterpret_cast<d2u_t*>(yp) = out;
       }
-      if (MODE >= 1) acc0 += ax[b].x * sum[b].x + ax[b].y * sum[b].y;
-      if (MODE >= 2) acc1 += sum[b].x * sum[b].x + sum[b].y * sum[b].y;
+      if (DOTS) acc0 += ax[b].x * sum[b].x + ax[b].y * sum[b].y;
+      if (DOTS && MODE >= 2) acc1 += sum[b].x * sum[b].x + sum[b].y * sum[b].y;
       if (MODE == 3) acc2 += ax2[b].x * sum[b].x + ax2[b].y * sum[b].y;
     } else if (live0[b]) {
       if (st) *yp = sum[b].x;
-      if (MODE >= 1) acc0 += ax[b].x * sum[b].x;
-      if (MODE >= 2) acc1 += sum[b].x * sum[b].x;
+      if (DOTS) acc0 += ax[b].x * sum[b].x;
+      if (DOTS && MODE >= 2) acc1 += sum[b].x * sum[b].x;
       if (MODE == 3) acc2 += ax2[b].x * sum[b].x;
     }
   }
@@ -356,24 +359,25 @@ __device__ inline void slice_rows(const SDesc& d, int nrows, int rec, const doub
 template <int CNT, bool PSL, int MODE, bool NT>
 __device__ inline void slice_nb(const SDesc& d, int nrows, int rec, const double* __restrict__ pval,
                                 const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ aux,
-                                int lane, double& acc0, double& acc1, double& acc2, int dbg) {
-  if (!PSL && nrows > 128) slice_rows<CNT, 2, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, acc2, dbg);
-  else slice_rows<CNT, 1, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, acc2, dbg);
+                                const double* __restrict__ dx, int lane, double& acc0, double& acc1, double& acc2, int dbg) {
+  if (!PSL && nrows > 128) slice_rows<CNT, 2, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg);
+  else slice_rows<CNT, 1, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg);
 }
 
 template <bool PSL, int MODE, bool NT>
 __device__ inline void slice_dispatch(int cnt, const SDesc& d, int nrows, int rec, const double* __restrict__ pval,
                                       const double* __restrict__ x, double* __restrict__ y,
-                                      const double* __restrict__ aux, int lane, double& acc0, double& acc1, double& acc2, int dbg) {
+                                      const double* __restrict__ aux, const double* __restrict__ dx, int lane, double& acc0,
+                                      double& acc1, double& acc2, int dbg) {
   switch (cnt) {   // wave-uniform
-    case 1: slice_nb<1, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, acc2, dbg); break;
-    case 3: slice_nb<3, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, acc2, dbg); break;
-    case 5: slice_nb<5, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, acc2, dbg); break;
-    case 7: slice_nb<7, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, acc2, dbg); break;
-    case 2: slice_nb<2, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, acc2, dbg); break;
-    case 4: slice_nb<4, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, acc2, dbg); break;
-    case 6: slice_nb<6, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, acc2, dbg); break;
-    default: slice_nb<8, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, acc2, dbg); break;
+    case 1: slice_nb<1, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg); break;
+    case 3: slice_nb<3, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg); break;
+    case 5: slice_nb<5, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg); break;
+    case 7: slice_nb<7, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg); break;
+    case 2: slice_nb<2, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg); break;
+    case 4: slice_nb<4, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg); break;
+    case 6: slice_nb<6, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg); break;
+    default: slice_nb<8, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg); break;
   }
 }
 
@@ -389,6 +393,8 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_s(i64 nslices, const int* __rest
   __shared__ __attribute__((aligned(16))) double s_x[BLOCK / 64][512];   // G chunks: x[col] of every entry of the chunk
   __shared__ double s_red[BLOCK / 64];
   if (sc && sc[S_DONE] != 0.0) return;
+  constexpr bool DOTS = MODE >= 1 && MODE <= 3;
+  const double* __restrict__ dx = fin.dotx ? fin.dotx : x;   // operand of the (y, .) dot of modes 2 / 3
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   double* __restrict__ sv = s_val[wave];
@@ -428,9 +434,9 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_s(i64 nslices, const int* __rest
     const bool skip = ((dbg & 1) && type == SL_G) || ((dbg & 2) && type != SL_G);
     if (skip) {
     } else if (type == SL_U) {
-      slice_dispatch<false, MODE, NT>(cnt, d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, acc2, dbg);
+      slice_dispatch<false, MODE, NT>(cnt, d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg);
     } else if (type == SL_P) {
-      slice_dispatch<true, MODE, NT>(cnt, d, nrows, rec, pval, x, y, aux, lane, acc0, acc1, acc2, dbg);
+      slice_dispatch<true, MODE, NT>(cnt, d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg);
     } else {
       // packed irregular rows: same data flow as k_spmv_cw on the compact CSR, plus the row-id indirection
       Desc dd;
@@ -445,7 +451,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_s(i64 nslices, const int* __rest
       for (int j = 0; j < XV_IT; ++j) sv2[lane + 64 * j] = q.v[j];
       // the dot operands of the row ride with the gathers (issued before the LDS phase, not after it)
       const double auxr = (MODE == 1 || MODE == 3) ? aux[rid] : 0.0;
-      const double xr = MODE >= 2 ? x[rid] : 0.0;
+      const double xr = (MODE == 2 || MODE == 3) ? dx[rid] : (MODE == 4 ? x[rid] : 0.0);
       // ENTRY-parallel x gathers: lane l holds the columns of entries 4l..4l+3 (and 256 + 4l..), so neighbouring lanes
       // gather for the same or the next row and one gather instruction touches ~20 cache lines -- a row per lane (the CSR
       // kernel's way) touches 64, and the vector-memory unit serves a line per cycle.  The x values go to LDS next to the
@@ -485,9 +491,10 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_s(i64 nslices, const int* __rest
       }
       __builtin_amdgcn_wave_barrier();
       if (live) {
+        if (MODE == 4) sum = 2.0 * xr - sum;
         y[rid] = sum;
         if (MODE == 1) acc0 += auxr * sum;
-        if (MODE >= 2) {
+        if (DOTS && MODE >= 2) {
           acc0 += sum * xr;
           acc1 += sum * sum;
         }
@@ -501,11 +508,11 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_s(i64 nslices, const int* __rest
   // pstride = blocks per partial slot (the grid the Krylov workspace was sized for; >= gridDim.x).  accum: this launch
   // covers the rows left out by an earlier launch of the same product (spmv_with_halo: the rows that had to wait for
   // the halo) and adds its sums to that launch's -- which has completed: same stream.
-  if (MODE >= 1) {
+  if (DOTS) {
     const double t0 = block_sum(acc0, s_red);
     if (threadIdx.x == 0) put_partial(partials + blockIdx.x, t0, accum);
   }
-  if (MODE >= 2) {
+  if (DOTS && MODE >= 2) {
     const double t1 = block_sum(acc1, s_red);
     if (threadIdx.x == 0) put_partial(partials + pstride + blockIdx.x, t1, accum);
   }
@@ -513,7 +520,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_s(i64 nslices, const int* __rest
     const double t2 = block_sum(acc2, s_red);
     if (threadIdx.x == 0) put_partial(partials + 4 * (size_t)pstride + blockIdx.x, t2, accum);
   }
-  if (MODE >= 1) fold_scalar_phase(fin, partials, s_red, pstride);
+  if (DOTS) fold_scalar_phase(fin, partials, s_red, pstride);
 }
 
 // flags[r]: bit 0 = row r has the count and (col - row) offsets of row r-1, bit 1 = and bitwise the same values,
@@ -622,6 +629,7 @@ template <int MODE>
 bool launch_mode(int v, const CsrMatrix& A, const double* x, double* y, const double* aux, double* partials,
                  const double* sc, int grid, hipStream_t st, const FinArgs* fin) {
   if (v & 64) return launch_slices<MODE>(v, A, 0, A.nslices, x, y, aux, partials, sc, grid, grid, 0, st, fin);
+  PG_REQUIRE(MODE != 4 && !(fin && fin->dotx), "the preconditioner product and separate dot operands need the slice kernel");
   if (v != 1) ensure_csr_chunks(A);
   if (v == 1) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv<MODE>), dim3(grid), dim3(BLOCK), 0, st, A.n, A.rowptr.p, A.col.p, A.val.p, x, y,
@@ -921,6 +929,8 @@ bool build_slices_like(const CsrMatrix& T, CsrMatrix& A) {
   return true;
 }
 
+bool spmv_supports_preconditioner_product() { return (variant() & 64) != 0; }
+
 int spmv_default_grid(i64 n) {
   // resident blocks per CU: the slice kernel holds ~100 VGPRs (4 waves / SIMD), the CSR kernels 24.6 KB of LDS (6 blocks)
   static const int per_cu = getenv("PG_SPMV_BLOCKS_PER_CU") ? atoi(getenv("PG_SPMV_BLOCKS_PER_CU")) : ((variant() & 64) ? 4 : 6);
@@ -940,6 +950,7 @@ bool launch_spmv(int mode, const CsrMatrix& A, const double* x, double* y, const
   if (mode == 0) return launch_mode<0>(v, A, x, y, aux, partials, sc, grid, st, fin);
   if (mode == 1) return launch_mode<1>(v, A, x, y, aux, partials, sc, grid, st, fin);
   if (mode == 2) return launch_mode<2>(v, A, x, y, aux, partials, sc, grid, st, fin);
+  if (mode == 4) return launch_mode<4>(v, A, x, y, aux, partials, sc, grid, st, fin);
   return launch_mode<3>(v, A, x, y, aux, partials, sc, grid, st, fin);
 }
 
@@ -961,13 +972,15 @@ bool spmv_with_halo(int mode, const CsrMatrix& A, const Numbering& nb, const Sla
   const int grid2 = (int)std::max<i64>(1, std::min<i64>(grid, (nbnd + BLOCK / 64 - 1) / (BLOCK / 64)));
   halo_begin(nb, slab, x, st);                      // x's owned part is final on `st`; ghosts arrive on the comm stream
   bool folded;
+  FinArgs fin_nofold{nullptr, nullptr, PH_NONE, 0, 0, fin ? fin->dotx : nullptr};   // first launch: dot operand, no scalar phase
 #define PG_SPLIT(MODE_)                                                                                              \
-  launch_slices<MODE_>(v, A, 0, ni, x, y, aux, partials, sc, grid, grid, 0, st, nullptr);                           \
+  launch_slices<MODE_>(v, A, 0, ni, x, y, aux, partials, sc, grid, grid, 0, st, fin ? &fin_nofold : nullptr);      \
   halo_end(st);                                                                                                      \
   folded = launch_slices<MODE_>(v, A, ni, nbnd, x, y, aux, partials, sc, grid2, grid, 1, st, fin)
   if (mode == 0) { PG_SPLIT(0); }
   else if (mode == 1) { PG_SPLIT(1); }
   else if (mode == 2) { PG_SPLIT(2); }
+  else if (mode == 4) { PG_SPLIT(4); }
   else { PG_SPLIT(3); }
 #undef PG_SPLIT
   return folded;

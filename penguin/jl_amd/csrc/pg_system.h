@@ -66,6 +66,11 @@ struct CsrMatrix {
   // false when NO rank's rows reference a ghost column (e.g. one body per slab with fluid away from the slab faces):
   // the per-SpMV halo exchange is then skipped on every rank (decided collectively at assembly)
   bool halo_needed = true;
+  // true when every eigenvalue of Â provably lies in the disc |λ - 1| < 0.95 (Gershgorin on S Â S⁻¹ = D⁻¹A-like rows,
+  // columns of identity rows left out: the matrix is block triangular in them): the truncated Neumann series
+  // M⁻¹ = 2I - Â = Â⁻¹(I - (I - Â)²) is then a safe right preconditioner for BiCGStab (pg_krylov.hip).  Collective.
+  bool poly_ok = false;
+  double gersh = 0.0;   // the largest disc radius found (all ranks)
   i64 n_blk = 0;
   i64 nnz_raw = 0;   // entries of the un-preconditioned reduced matrix (what pg_solver_get_system_csr(0/1) returns)
   DevBuf<int> blk_rows, blk_idx;
@@ -89,6 +94,8 @@ void assemble_csr_preconditioned(const SysParams& P, const Slab& slab, const Num
 void assemble_csr_like(const SysParams& P, const Slab& slab, const Numbering& nb, const CsrMatrix& T, CsrMatrix& A);
 // (pg_spmv.hip) slices of A from T's when the new values still support every one of them; false: build from scratch
 bool build_slices_like(const CsrMatrix& T, CsrMatrix& A);
+// sets A.poly_ok / A.gersh (collective: every rank calls it once per assembled matrix, rowless ranks included)
+void decide_poly(CsrMatrix& A);
 // out = B⁻¹ S in over the owned rows (in != out)
 void apply_left(const CsrMatrix& A, const double* in, double* out, hipStream_t st);
 // y (padded, K*Mloc) = K_full * x (padded, K*Mloc): matrix-free application of the un-reduced operator rows
