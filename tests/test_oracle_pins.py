@@ -346,3 +346,46 @@ def test_unsteady_diphasic_advection_diffusion_reduces_to_diffusion_at_zero_velo
     assert np.allclose(bd[:M] - ba[:M], missing, rtol=0, atol=1e-13)
     with pytest.raises(ValueError):
         po.A_diph_unstead_advdiff(q[0].operator, q[1].operator, c1, c2, D, D, ic, dt, "RK4")
+
+
+def test_neumann_right_preconditioner_halves_bicgstab_iterations():
+    """What pg_krylov.hip relies on, checked on the oracle's system of a 3-D CN step (benchmark/Heat3D.jl shape at 20^3):
+    with the point-equilibrated Â = I - K, BiCGStab on Â(2I - Â) = I - K² reaches the same solution in about half the
+    iterations (same number of products with Â), and the Gershgorin radius that admits it -- columns of identity rows
+    left out, rows taken in the D⁻¹A scaling -- is below 0.95 although the plain row sums are not."""
+    import scipy.sparse as sp
+
+    n = 20
+    mesh = po.Mesh((n, n, n), (4.0, 4.0, 4.0), (0.0, 0.0, 0.0))
+    cap = po.make_capacity(Ball((2.01, 2.01, 2.01), 1.0), mesh)
+    op = po.make_diffusion_ops(cap)
+    M = (n + 1) ** 3
+    ph = po.Phase(cap, op, lambda x, y, z, t: 0.0, lambda x, y, z: 1.0)
+    bcb = po.BorderConditions({k: po.Dirichlet(1.0) for k in ("left", "right", "top", "bottom")})
+    dt = 0.75 * (4.0 / n) ** 2
+    A = po.A_mono_unstead_diff(op, cap, ph.Diffusion_coeff, po.Dirichlet(1.0), dt, "CN")
+    b = po.b_mono_unstead_diff(op, ph.source, ph.Diffusion_coeff, cap, po.Dirichlet(1.0), np.zeros(2 * M), dt, dt, "CN")
+    A, b = po.BC_border_mono(A, b, bcb, mesh, t=dt)
+    Ar, br, _ = po.remove_zero_rows_cols(A, b)
+    d = 1.0 / np.sqrt(np.abs(Ar.diagonal()))
+    Ah = (sp.diags(d) @ Ar @ sp.diags(d)).tocsr()
+    bh = d * br
+
+    class Pre:                                   # v -> Â (2v - Âv): only `@` is asked of it by bicgstab_ref
+        shape = Ah.shape
+
+        def __matmul__(self, v):
+            return Ah @ (2.0 * v - Ah @ v)
+
+    x_plain, it_plain, _ = po.bicgstab_ref(Ah, bh, reltol=1e-12)
+    y, it_pre, _ = po.bicgstab_ref(Pre(), bh, reltol=1e-12)
+    x_pre = 2.0 * y - Ah @ y                     # x = M⁻¹ y
+    assert np.linalg.norm(x_pre - x_plain) <= 1e-10 * np.linalg.norm(x_plain)
+    assert it_pre <= it_plain // 2 + 1, (it_pre, it_plain)
+    # the admissibility test of pg_precond.hip (k_gershgorin)
+    rl = np.diff(Ar.indptr)
+    ident = rl == 1
+    DA = (sp.diags(1.0 / np.abs(Ar.diagonal())) @ Ar).tocsr()
+    off_all = np.asarray(abs(DA).sum(axis=1)).ravel() - np.abs(DA.diagonal())
+    off = np.asarray(abs(DA @ sp.diags((~ident).astype(float))).sum(axis=1)).ravel() - np.abs(DA.diagonal())
+    assert off[~ident].max() < 0.95 <= off_all.max()
