@@ -156,6 +156,10 @@ def main() -> None:
     # + 8 n: every launch timed in the loop is a fused-dot launch that also reads r-hat (SURVEY's CSR figure leaves the
     # dot operand out; the CSR number below is kept as SURVEY defines it)
     b_spmv = int(sysinfo.spmv_bytes) + 8 * n_rows if os.environ.get("PG_SPMV_VARIANT", "70") in ("70", "66") else b_csr
+    if bool(sysinfo.neumann_ok) and os.environ.get("PG_POLY", "1") != "0" and b_spmv != b_csr:
+        # preconditioned loop: the bracketed launches alternate between v = A u (r-hat) and t = A u_s, whose (t, s) dot
+        # reads s as a vector of its own (+8 n on every second launch)
+        b_spmv += 4 * n_rows
     spmv_ms = run.spmv_ms_total / max(run.spmv_launches, 1)
     achieved = b_spmv / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
     iters = run.total_iters / max(run.steps, 1)
