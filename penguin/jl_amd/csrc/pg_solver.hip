@@ -207,6 +207,21 @@ __global__ void k_rhs_block(i64 nblk, int scheme, const int* __restrict__ blk_ro
 //   b̂ = S(2 mass∘(S z) + bconst) - ŷ  (CN) | S(mass∘(S z) + bconst) (BE) | S bconst (fixed rows) | as written by k_rhs_block
 //   r = r̂ = p = b̂ - ŷ,  x = z (in place),  partial sums of (r,r) and (b̂,b̂) in slots 0 / 1
 // replaces k_rhs + k_bicg_init: 9.3 instead of 14.1 vector passes, and no separate scaling kernels per step
+typedef double rd2_t __attribute__((ext_vector_type(2)));
+typedef unsigned char ruc2_t __attribute__((ext_vector_type(2)));
+
+// one element of k_rhs_init
+__device__ inline void rhs_init_one(int scheme, double z, double yh, double d, double ms, double bc, bool fx, bool blk, double bold,
+                                    double& bi, double& ri) {
+  if (blk) bi = bold;
+  else if (fx) bi = d * bc;
+  else if (scheme == PG_SCHEME_CN) bi = d * (2.0 * (ms * (d * z)) + bc) - yh;
+  else bi = d * (ms * (d * z) + bc);
+  ri = bi - yh;
+}
+
+// TWO elements per lane (16-byte accesses: half the vector-memory instructions of the 11 streams; the two flag bytes of
+// a pair come with one 2-byte load each); the odd last element and the ghost tail are handled by the same lanes
 __global__ __launch_bounds__(BLOCK) void k_rhs_init(i64 n, i64 nvec, int scheme, const double* __restrict__ z,
                                                     const double* __restrict__ yhat, const double* __restrict__ ds,
                                                     const double* __restrict__ mass, const double* __restrict__ bconst,
@@ -216,28 +231,46 @@ __global__ __launch_bounds__(BLOCK) void k_rhs_init(i64 n, i64 nvec, int scheme,
                                                     double* __restrict__ p, double* __restrict__ partials) {
   __shared__ double s_red[BLOCK / 64];
   double acc = 0.0, accb = 0.0;
-  for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < nvec; i += (i64)gridDim.x * BLOCK) {
-    if (i < n) {
+  const i64 npair = (nvec + 1) / 2;
+  for (i64 q = blockIdx.x * (i64)BLOCK + threadIdx.x; q < npair; q += (i64)gridDim.x * BLOCK) {
+    const i64 i = 2 * q;
+    if (i + 1 < n) {
       // (stream hints: the per-row data is read once per step and b̂ is only kept for inspection -- neither should
       //  displace the SpMV's matrix data from the Infinity Cache)
-      double bi;
-      const double yh = __builtin_nontemporal_load(yhat + i);
-      if (isblk[i]) {
-        bi = b[i];
-      } else {
-        const double d = __builtin_nontemporal_load(ds + i), bc = __builtin_nontemporal_load(bconst + i);
-        const double ms = __builtin_nontemporal_load(mass + i);
-        if (fixed[i]) bi = d * bc;
-        else if (scheme == PG_SCHEME_CN) bi = d * (2.0 * (ms * (d * z[i])) + bc) - yh;
-        else bi = d * (ms * (d * z[i]) + bc);
-        __builtin_nontemporal_store(bi, b + i);
-      }
-      const double ri = bi - yh;
-      r[i] = ri; rhat[i] = ri; p[i] = ri;
-      acc += ri * ri;
-      accb += bi * bi;
+      const rd2_t yh = __builtin_nontemporal_load(reinterpret_cast<const rd2_t*>(yhat + i));
+      const rd2_t d = __builtin_nontemporal_load(reinterpret_cast<const rd2_t*>(ds + i));
+      const rd2_t bc = __builtin_nontemporal_load(reinterpret_cast<const rd2_t*>(bconst + i));
+      const rd2_t ms = __builtin_nontemporal_load(reinterpret_cast<const rd2_t*>(mass + i));
+      const rd2_t zz = *reinterpret_cast<const rd2_t*>(z + i);
+      const ruc2_t fx = *reinterpret_cast<const ruc2_t*>(fixed + i);
+      const ruc2_t bk = *reinterpret_cast<const ruc2_t*>(isblk + i);
+      rd2_t bold;
+      bold.x = 0.0; bold.y = 0.0;
+      if (bk.x | bk.y) bold = *reinterpret_cast<const rd2_t*>(b + i);
+      double b0, r0, b1, r1;
+      rhs_init_one(scheme, zz.x, yh.x, d.x, ms.x, bc.x, fx.x != 0, bk.x != 0, bold.x, b0, r0);
+      rhs_init_one(scheme, zz.y, yh.y, d.y, ms.y, bc.y, fx.y != 0, bk.y != 0, bold.y, b1, r1);
+      rd2_t bi, ri;
+      bi.x = b0; bi.y = b1; ri.x = r0; ri.y = r1;
+      __builtin_nontemporal_store(bi, reinterpret_cast<rd2_t*>(b + i));
+      *reinterpret_cast<rd2_t*>(r + i) = ri;
+      *reinterpret_cast<rd2_t*>(rhat + i) = ri;
+      *reinterpret_cast<rd2_t*>(p + i) = ri;
+      acc += ri.x * ri.x + ri.y * ri.y;
+      accb += bi.x * bi.x + bi.y * bi.y;
     } else {
-      p[i] = 0.0;
+      for (i64 k = i; k < i + 2 && k < nvec; ++k) {
+        if (k < n) {
+          double bi, ri;
+          rhs_init_one(scheme, z[k], yhat[k], ds[k], mass[k], bconst[k], fixed[k] != 0, isblk[k] != 0, isblk[k] ? b[k] : 0.0, bi, ri);
+          b[k] = bi;
+          r[k] = ri; rhat[k] = ri; p[k] = ri;
+          acc += ri * ri;
+          accb += bi * bi;
+        } else {
+          p[k] = 0.0;
+        }
+      }
     }
   }
   const double t = block_sum(acc, s_red);
