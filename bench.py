@@ -289,7 +289,8 @@ def cpu_baseline(s, dt: float, cpu_steps: int, n: int) -> dict:
         "cores": 1,
         "kind": "port",
         "sample": f"{res['single_thread']['steps_timed']} CN step(s) of the same {n}^3 reduced system (n={nrow}, nnz={Ah.nnz}): "
-                  "1 SpMV + BiCGStab reltol 1e-12, oracle/krylov_ref.c, single thread (the reference's Krylov path is "
+                  "1 SpMV + plain BiCGStab reltol 1e-12 (the iteration IterativeSolvers would run; the GPU loop's Neumann right "
+                  "preconditioner is not applied here), oracle/krylov_ref.c, single thread (the reference's Krylov path is "
                   "single-threaded); all-cores OpenMP figure alongside",
         "all_cores": res["all_cores"],
         "host_cores": ncores,
