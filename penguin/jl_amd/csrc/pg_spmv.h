@@ -167,9 +167,10 @@ __device__ inline void fold_scalar_phase(const FinArgs& fin, const double* __res
   if (threadIdx.x == 0 && fin.do_derive) derive(fin.phase, fin.sc);
 }
 
-// mode 4: y = 2x - A x (u = M⁻¹x for the Neumann preconditioner M⁻¹ = 2I - Â of the BiCGStab driver), no dots, slice kernel only.
 // y = A x on rows [0, A.n).  mode 0: plain; 1: partials[0..grid) = aux . y; 2: partials[0..grid) = y . x and
-// partials[grid..2grid) = y . y; 3: mode 2 plus partials[4grid..5grid) = aux . y.  `sc` (may be NULL): kernels return immediately when sc[S_DONE] != 0.
+// partials[grid..2grid) = y . y; 3: mode 2 plus partials[4grid..5grid) = aux . y (the operand of the (y, .) dot of modes
+// 2 / 3 is fin->dotx when set); 4 (slice kernel only): y = 2x - A x, i.e. u = M⁻¹x for the Neumann preconditioner
+// M⁻¹ = 2I - Â of the BiCGStab driver, no dots.  `sc` (may be NULL): kernels return immediately when sc[S_DONE] != 0.
 // `grid` must be the value used to size `partials` (KrylovWork::grid) for modes 1/2.
 // `fin` (optional): scalar phase evaluated by the last block of the launch; returns true when the launched kernel
 // does that (the stencil-slice kernel), false when the caller still has to launch the scalar kernel itself.

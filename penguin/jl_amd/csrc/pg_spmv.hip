@@ -19,7 +19,8 @@
 //   70   k_spmv_s    stencil slices (default): see "stencil slices" below.  0.25 GB instead of 0.99 GB at 512^3.
 //
 // The dots that follow an SpMV in BiCGStab / CG are fused into the epilogue (one partial per block, summed in a fixed
-// order: deterministic); the slice kernel's last-arriving block can also evaluate the scalar phase (pg_spmv.h).
+// order: deterministic); the slice kernel's last-arriving block can also evaluate the scalar phase (pg_spmv.h).  The slice
+// kernel has one more epilogue, y = 2x - A x: the product with the Neumann preconditioner 2I - A of pg_krylov.hip.
 #include <algorithm>
 #include <cstdlib>
 #include <thread>
