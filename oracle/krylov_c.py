@@ -18,7 +18,7 @@ def lib():
         if not _LIB.exists():
             subprocess.run(["make", "-C", str(_HERE), "-s"], check=True)
         _lib = C.CDLL(str(_LIB))
-        for f in (_lib.krylov_ref_bicgstab, _lib.krylov_ref_cg):
+        for f in (_lib.krylov_ref_bicgstab, _lib.krylov_ref_bicgstab_neumann, _lib.krylov_ref_cg):
             f.restype = C.c_int
     return _lib
 
@@ -37,7 +37,8 @@ def solve(A, b, method="bicgstab", reltol=1e-12, abstol=0.0, maxiter=10000, nthr
     b = np.ascontiguousarray(b, dtype=np.float64)
     x = np.zeros(n)
     res = C.c_double()
-    fn = lib().krylov_ref_bicgstab if method == "bicgstab" else lib().krylov_ref_cg
+    fn = {"bicgstab": lib().krylov_ref_bicgstab, "bicgstab_neumann": lib().krylov_ref_bicgstab_neumann,
+          "cg": lib().krylov_ref_cg}[method]
     P = C.POINTER(C.c_double)
     it = fn(C.c_int64(n), rp.ctypes.data_as(C.POINTER(C.c_int64)), ci.ctypes.data_as(C.POINTER(C.c_int32)),
             v.ctypes.data_as(P), b.ctypes.data_as(P), x.ctypes.data_as(P), C.c_double(reltol), C.c_double(abstol),

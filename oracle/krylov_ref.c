@@ -99,6 +99,76 @@ int krylov_ref_bicgstab(int64_t n, const int64_t* rp, const int32_t* ci, const d
   return it;
 }
 
+/* The iteration pg_krylov.hip runs where its Gershgorin test admits it: BiCGStab right-preconditioned with the Neumann
+ * polynomial M^-1 = 2I - A (u = 2p - Ap; v = Au; ... x += alpha u + omega u_s).  Not something the reference does --
+ * here so that bench.py can time the SAME algorithm on the host cores next to the plain iteration. */
+int krylov_ref_bicgstab_neumann(int64_t n, const int64_t* rp, const int32_t* ci, const double* v, const double* b, double* x,
+                                double reltol, double abstol, int maxiter, int nthreads, double* resnorm_out) {
+#ifdef _OPENMP
+  omp_set_num_threads(nthreads > 0 ? nthreads : 1);
+#endif
+  double* r = (double*)malloc(sizeof(double) * n);
+  double* rh = (double*)malloc(sizeof(double) * n);
+  double* p = (double*)calloc(n, sizeof(double));
+  double* vv = (double*)calloc(n, sizeof(double));
+  double* t = (double*)malloc(sizeof(double) * n);
+  double* u = (double*)malloc(sizeof(double) * n);
+  double* us = (double*)malloc(sizeof(double) * n);
+  double* w = (double*)malloc(sizeof(double) * n);
+  for (int64_t i = 0; i < n; ++i) { x[i] = 0.0; r[i] = b[i]; rh[i] = b[i]; }
+  const double bb = dot(n, b, b);
+  double tol2 = reltol * reltol * bb;
+  if (abstol * abstol > tol2) tol2 = abstol * abstol;
+  double rr = bb, rho_old = 1.0, alpha = 1.0, omega = 1.0, rho = bb, rhat2 = bb;
+  int it = 0, restart = 0;
+  while (rr > tol2 && it < maxiter) {
+    ++it;
+    if (restart) {
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < n; ++i) p[i] = r[i];
+      restart = 0;
+    } else {
+      const double beta = (rho / rho_old) * (alpha / omega);
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < n; ++i) p[i] = r[i] + beta * (p[i] - omega * vv[i]);
+    }
+    spmv(n, rp, ci, v, p, w);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) u[i] = 2.0 * p[i] - w[i];
+    spmv(n, rp, ci, v, u, vv);
+    const double den = dot(n, rh, vv);
+    const int force = den == 0.0;
+    alpha = force ? 0.0 : rho / den;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) r[i] -= alpha * vv[i]; /* r holds s */
+    spmv(n, rp, ci, v, r, w);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) us[i] = 2.0 * r[i] - w[i];
+    spmv(n, rp, ci, v, us, t);
+    const double tt = dot(n, t, t);
+    omega = tt != 0.0 ? dot(n, t, r) / tt : 0.0;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+      x[i] += alpha * u[i] + omega * us[i];
+      r[i] -= omega * t[i];
+    }
+    rho_old = rho;
+    rho = dot(n, rh, r);
+    rr = dot(n, r, r);
+    if (rr <= tol2) break;
+    if (omega == 0.0 || force || rho * rho < 1e-20 * rhat2 * rr) {
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < n; ++i) rh[i] = r[i];
+      rho = rhat2 = rr;
+      alpha = omega = 1.0;
+      restart = 1;
+    }
+  }
+  if (resnorm_out) *resnorm_out = sqrt(rr);
+  free(r); free(rh); free(p); free(vv); free(t); free(u); free(us); free(w);
+  return it;
+}
+
 int krylov_ref_cg(int64_t n, const int64_t* rp, const int32_t* ci, const double* v, const double* b, double* x,
                   double reltol, double abstol, int maxiter, int nthreads, double* resnorm_out) {
 #ifdef _OPENMP

@@ -389,3 +389,35 @@ def test_neumann_right_preconditioner_halves_bicgstab_iterations():
     off_all = np.asarray(abs(DA).sum(axis=1)).ravel() - np.abs(DA.diagonal())
     off = np.asarray(abs(DA @ sp.diags((~ident).astype(float))).sum(axis=1)).ravel() - np.abs(DA.diagonal())
     assert off[~ident].max() < 0.95 <= off_all.max()
+
+
+def test_c_krylov_port_matches_the_numpy_restatement():
+    """oracle/krylov_ref.c (what bench.py times on the host cores) against oracle/penguin_oracle.py on a cut-cell system:
+    plain BiCGStab takes the same number of iterations as bicgstab_ref, the Neumann-preconditioned variant about half and
+    the same solution; OpenMP threads do not change the iteration count."""
+    import scipy.sparse as sp
+
+    from oracle import krylov_c
+
+    n = 16
+    mesh = po.Mesh((n, n, n), (4.0, 4.0, 4.0), (0.0, 0.0, 0.0))
+    cap = po.make_capacity(Ball((2.01, 2.01, 2.01), 1.0), mesh)
+    op = po.make_diffusion_ops(cap)
+    M = (n + 1) ** 3
+    ph = po.Phase(cap, op, lambda x, y, z, t: 0.0, lambda x, y, z: 1.0)
+    bcb = po.BorderConditions({k: po.Dirichlet(1.0) for k in ("left", "right", "top", "bottom")})
+    s = po.DiffusionUnsteadyMono(ph, bcb, po.Dirichlet(1.0), 0.75 * (4.0 / n) ** 2, np.zeros(2 * M), "CN")
+    Ar, br, _ = po.remove_zero_rows_cols(s.A, s.b)
+    d = 1.0 / np.sqrt(np.abs(Ar.diagonal()))
+    Ah = (sp.diags(d) @ Ar @ sp.diags(d)).tocsr()
+    bh = d * br
+    x_ref, it_ref, _ = po.bicgstab_ref(Ah, bh, reltol=1e-12)
+    x_c, it_c, res_c = krylov_c.solve(Ah, bh, "bicgstab", reltol=1e-12)
+    assert it_c == it_ref and np.linalg.norm(x_c - x_ref) <= 1e-10 * np.linalg.norm(x_ref)
+    x_n, it_n, res_n = krylov_c.solve(Ah, bh, "bicgstab_neumann", reltol=1e-12)
+    assert it_n <= it_ref // 2 + 1 and res_n <= 1e-12 * np.linalg.norm(bh)
+    assert np.linalg.norm(x_n - x_ref) <= 1e-10 * np.linalg.norm(x_ref)
+    _, it_n4, _ = krylov_c.solve(Ah, bh, "bicgstab_neumann", reltol=1e-12, nthreads=4)
+    assert abs(it_n4 - it_n) <= 1
+    y = krylov_c.spmv(Ah, bh, nthreads=2)
+    assert np.allclose(y, Ah @ bh, rtol=1e-14, atol=1e-14 * np.abs(bh).max())
