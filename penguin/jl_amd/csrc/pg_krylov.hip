@@ -176,6 +176,12 @@ __global__ __launch_bounds__(BLOCK) void k_finalize(int phase, int slot0, int ns
   if (do_derive && threadIdx.x == 0) derive(phase, sc);
 }
 
+// fresh scalar block of a solve: everything zero but the squared tolerances
+__global__ void k_sc_reset(double* sc, double reltol2, double abstol2) {
+  const int i = threadIdx.x;
+  if (i < S_COUNT) sc[i] = i == S_RELTOL2 ? reltol2 : (i == S_ABSTOL2 ? abstol2 : 0.0);
+}
+
 __global__ void k_derive(int phase, double* sc, int check_done) {
   if (check_done && sc[S_DONE] != 0.0) return;
   derive(phase, sc);
@@ -302,12 +308,8 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
     // IterativeSolvers default: size of the system (global)
     maxiter = 100000;
   }
-  // tolerances -> device scalars
-  double hs[S_COUNT];
-  std::memset(hs, 0, sizeof(hs));
-  hs[S_RELTOL2] = opts.reltol * opts.reltol;
-  hs[S_ABSTOL2] = opts.abstol * opts.abstol;
-  PG_HIP(hipMemcpyAsync(w.sc.p, hs, sizeof(hs), hipMemcpyHostToDevice, st));
+  // tolerances -> device scalars (a one-thread kernel: a host-to-device copy out of pageable memory stalls the stream)
+  hipLaunchKernelGGL(k_sc_reset, dim3(1), dim3(S_COUNT), 0, st, w.sc.p, opts.reltol * opts.reltol, opts.abstol * opts.abstol);
   SpmvTimer timer(cx.profiling);
 
   const bool cg = opts.method == PG_METHOD_CG;
