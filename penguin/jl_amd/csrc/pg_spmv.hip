@@ -614,7 +614,7 @@ namespace {
 template <int MODE>
 bool launch_slices(int v, const CsrMatrix& A, i64 s0, i64 ns, const double* x, double* y, const double* aux, double* partials,
                    const double* sc, int grid, int pstride, int accum, hipStream_t st, const FinArgs* fin) {
-  FinArgs fa{nullptr, nullptr, PH_NONE, 0, 0};
+  FinArgs fa{nullptr, nullptr, PH_NONE, 0, 0, nullptr};
   if (fin && MODE >= 1) fa = *fin;
   const int* rec = A.srec.p + SL_REC * s0;
   if (v & 4)
