@@ -1,5 +1,6 @@
 """world_size-2 gloo test (CPU) of the N>1 ALGORITHM the HIP path implements: 1-D slab partition of the reduced
-system by planes (pg_partition_planes), one ghost chunk per neighbour and SpMV, dot products all-reduced --
+system by planes (pg_partition_planes), one ghost chunk per neighbour and SpMV, dot products all-reduced, the collective admission test and the iteration of the
+Neumann right preconditioner --
 restated here with the oracle's matrix in numpy and torch.distributed(gloo) so that it runs without a GPU.
 The device implementation of the same plan is verified on the GPU box by tests/test_gpu_virtual_ranks.py."""
 import os
@@ -81,7 +82,61 @@ WORKER = textwrap.dedent('''
     err = np.linalg.norm(x[:nloc] - xs[own]) / np.linalg.norm(xs)
     assert err < 1e-10, err
     assert its < 100          # (the serial oracle also restarts on breakdown, so counts need not be equal)
-    print(f"rank {rank}: rows {nloc} ghosts {len(ghost)} iters {its} (serial {its_s}) err {err:.2e}", flush=True)
+
+    # ---- the Neumann-preconditioned slab iteration (pg_krylov.hip default): admission is a COLLECTIVE decision (max of the
+    # per-rank Gershgorin radii, identity-row columns left out; here every column's row length is known globally), each
+    # half step exchanges two halos (p then u = 2p - Ap) and all-reduces the same dots ----
+    rl = np.diff(A.indptr)
+    ident = rl == 1
+    Aown = A[own, :].tocsr()
+    rad = 0.0
+    for q in range(nloc):
+        a, e = Aown.indptr[q], Aown.indptr[q + 1]
+        if e - a <= 1:
+            continue
+        cj, vj = Aown.indices[a:e], Aown.data[a:e]
+        gi = own[q]
+        offm = (cj != gi) & ~ident[cj]
+        rad = max(rad, abs(1.0 - vj[cj == gi].sum()) + float(np.sum(np.abs(vj[offm]) * ds[gi] / ds[cj[offm]])))
+    tr = torch.tensor([rad], dtype=torch.float64); dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+    assert float(tr) < 0.95, float(tr)          # same answer on every rank: the preconditioner is admitted
+
+    def vec(owned):
+        o = np.zeros(nloc + len(ghost)); o[:nloc] = owned; halo(o); return o
+
+    # (with T0 = 0 the right-hand side lives on identity rows and (r̂, r) collapses after a step: restart with r̂ := r,
+    #  the rule of pg_krylov.hip and of the oracle's bicgstab_ref)
+    x2 = np.zeros(nloc); r = bl.copy(); rh = r.copy(); p = np.zeros(nloc); v = np.zeros(nloc)
+    rho_old = alpha = omega = 1.0; rho = rhat2 = dot(rh, r); its2 = 0; restart = False
+    while its2 < 500:
+        its2 += 1
+        if restart:
+            p = r.copy(); restart = False
+        else:
+            p = r + (rho / rho_old) * (alpha / omega) * (p - omega * v)
+        u = 2.0 * p - Al @ vec(p)
+        v = Al @ vec(u)
+        den = dot(rh, v)
+        force = den == 0.0
+        alpha = 0.0 if force else rho / den
+        sv = r - alpha * v
+        us = 2.0 * sv - Al @ vec(sv)
+        t = Al @ vec(us)
+        tt = dot(t, t)
+        omega = dot(t, sv) / tt if tt != 0.0 else 0.0
+        x2 += alpha * u + omega * us
+        r = sv - omega * t
+        rho_old, rho = rho, dot(rh, r)
+        rr = dot(r, r)
+        if rr <= 1e-26 * bb:
+            break
+        if omega == 0.0 or force or rho * rho < 1e-20 * rhat2 * rr:
+            rh = r.copy(); rho = rhat2 = rr; alpha = omega = 1.0; restart = True
+    err2 = np.linalg.norm(x2 - xs[own]) / np.linalg.norm(xs)
+    assert err2 < 1e-10, err2
+    assert its2 <= its // 2 + 1, (its2, its)
+    print(f"rank {rank}: rows {nloc} ghosts {len(ghost)} iters {its} (serial {its_s}) err {err:.2e}; "
+          f"Neumann-preconditioned: iters {its2} err {err2:.2e} gershgorin {float(tr):.3f}", flush=True)
     dist.destroy_process_group()
 ''')
 
@@ -97,4 +152,4 @@ def test_slab_bicgstab_world2_gloo(tmp_path):
                         "127.0.0.1", "--master-port", str(port), str(script)], capture_output=True, text=True, env=env,
                        timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    assert r.stdout.count("iters") == 2
+    assert r.stdout.count("Neumann-preconditioned: iters") == 2
