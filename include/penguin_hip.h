@@ -84,6 +84,9 @@ typedef struct {
   int32_t warm_start;  /* != 0: pg_solver_step starts BiCGStab from the previous time level instead of zero
                           (IterativeSolvers starts from zero; same solution to reltol, fewer iterations) */
   int32_t restart;     /* GMRES only: Krylov vectors per restart cycle (<= 0: 20, IterativeSolvers' default) */
+  int32_t precond;     /* BiCGStab only: polynomial right preconditioner in Â (DESIGN.md "Krylov driver").  0: automatic
+                          (on where Gershgorin bounds the spectrum, degree chosen by the library); -1: off (the plain
+                          iteration IterativeSolvers runs); m >= 1: m products with Â per application where admissible */
 } pg_krylov_opts;
 
 typedef struct {
@@ -104,6 +107,8 @@ typedef struct {
   /* profiling (pg_set_profiling(1)): HIP-event time of every SpMV launch in the run           */
   double spmv_ms_total;
   int64_t spmv_launches;
+  int64_t unconverged_steps; /* solves of this run that ended without meeting the tolerance (maxiter / breakdown) */
+  double worst_relres;       /* max over the run's solves of ||r|| / ||b|| at exit                                */
 } pg_run_info;
 
 typedef struct {
@@ -231,6 +236,9 @@ int32_t pg_solver_system_info(const pg_solver* s, int32_t which, pg_system_info*
    plus b (n_own) and the map idx[n_own] -> index in the full 2M/4M vector (the reference's common_idx). */
 int32_t pg_solver_get_system_csr(const pg_solver* s, int32_t which, int64_t* rowptr, int64_t* col, double* val,
                                  double* b, int64_t* idx);
+/* S = diag(|a_ii|^-1/2) of system `which` (0 constructor, 1 run): the weights of the convergence test
+   ||S r̂|| <= reltol ||S b̂|| (DESIGN.md "Krylov driver") and the map x = S y of the preconditioned system.  ds: n_own. */
+int32_t pg_solver_get_row_scaling(const pg_solver* s, int32_t which, double* ds);
 /* bench helper: `reps` launches of y = A x on the run matrix, HIP-event timed on the library stream. */
 int32_t pg_solver_time_spmv(pg_solver* s, int32_t which, int32_t reps, double* avg_ms);
 

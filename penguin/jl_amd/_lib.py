@@ -53,7 +53,7 @@ class pg_jump_desc(C.Structure):
 
 class pg_krylov_opts(C.Structure):
     _fields_ = [("method", C.c_int32), ("reltol", C.c_double), ("abstol", C.c_double), ("maxiter", C.c_int32),
-                ("check_every", C.c_int32), ("warm_start", C.c_int32), ("restart", C.c_int32)]
+                ("check_every", C.c_int32), ("warm_start", C.c_int32), ("restart", C.c_int32), ("precond", C.c_int32)]
 
 
 class pg_step_info(C.Structure):
@@ -63,7 +63,8 @@ class pg_step_info(C.Structure):
 
 class pg_run_info(C.Structure):
     _fields_ = [("steps", C.c_int64), ("total_iters", C.c_int64), ("t_final", C.c_double), ("extremum", C.c_double),
-                ("solve_ms", C.c_double), ("spmv_ms_total", C.c_double), ("spmv_launches", C.c_int64)]
+                ("solve_ms", C.c_double), ("spmv_ms_total", C.c_double), ("spmv_launches", C.c_int64),
+                ("unconverged_steps", C.c_int64), ("worst_relres", C.c_double)]
 
 
 class pg_system_info(C.Structure):

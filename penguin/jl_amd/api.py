@@ -14,6 +14,7 @@ from __future__ import annotations
 import ctypes as C
 import inspect
 import math
+import warnings
 from dataclasses import dataclass
 from typing import Callable, Dict, Optional, Sequence, Union
 
@@ -513,6 +514,7 @@ class Solver:
         self._nunk = 0
         self._initial_done = False
         self.last_run: Optional[L.pg_run_info] = None
+        self.unconverged = 0          # solves that ended without meeting the tolerance (see _check_converged)
 
     # reduced system of the constructor (which=0) or of the loop (which=1): (A_csr, b, idx)
     def system(self, which: int = 0):
@@ -615,6 +617,19 @@ def _border_values(bc_b: BorderConditions, mesh: Mesh, t: Optional[float]) -> np
     return out
 
 
+def _check_converged(s: "Solver", converged: bool, what: str, relres: float) -> None:
+    """The device Krylov solve stands in for the reference's direct `\\` as well: a solve that stopped at maxiter or
+    broke down must not pass silently (IterativeSolvers would hand back `ch.isconverged == false`)."""
+    s.unconverged += 0 if converged else 1
+    if not converged:
+        warnings.warn(f"penguin.jl_amd: {what} did not converge (||r||/||b|| = {relres:.3e}); the state is not a "
+                      "solution to the requested tolerance", RuntimeWarning, stacklevel=3)
+
+
+def _step_info_check(s: "Solver", info: L.pg_step_info, what: str) -> None:
+    _check_converged(s, bool(info.converged), what, info.resnorm / info.bnorm if info.bnorm > 0 else info.resnorm)
+
+
 def _krylov_opts(method, kwargs) -> L.pg_krylov_opts:
     """method may be "bicgstab" / "cg" / "gmres" or a callable named like IterativeSolvers' (bicgstabl, cg, gmres...).
     gmres -> restarted GMRES on the device (restart kwarg, default 20); cg -> CG; `\\`, bicgstabl and anything else ->
@@ -624,7 +639,8 @@ def _krylov_opts(method, kwargs) -> L.pg_krylov_opts:
     m = L.PG_METHOD.get(name, L.PG_METHOD["bicgstab"])
     return L.pg_krylov_opts(m, float(kwargs.get("reltol", 1e-12)), float(kwargs.get("abstol", 0.0)),
                             int(kwargs.get("maxiter", 0)), int(kwargs.get("check_every", 4)),
-                            int(bool(kwargs.get("warm_start", True))), int(kwargs.get("restart", 0)))
+                            int(bool(kwargs.get("warm_start", True))), int(kwargs.get("restart", 0)),
+                            int(kwargs.get("precond", 0)))
 
 
 def DiffusionUnsteadyMono(phase: Phase, bc_b: BorderConditions, bc_i, Δt: float, Tᵢ: np.ndarray, scheme: str,
@@ -689,22 +705,26 @@ def DiffusionUnsteadyMono(phase: Phase, bc_b: BorderConditions, bc_i, Δt: float
     return s
 
 
-def _time_dependent(fn, coords, t0, t1, nspace) -> bool:
-    """Is data(fn) different at two times?  (constant-in-time data lets the whole loop run on the device)."""
-    if not callable(fn):
+def _time_dependent(fn, nspace: int, time_independent: bool = False) -> bool:
+    """May data(fn) change from one step to the next?  The reference re-evaluates every closure and re-applies the
+    border rows on every step (diffusion.jl:286-296), so nothing is guessed from samples: any callable that accepts
+    a time argument (nspace + 1 positional arguments) is time dependent and takes the host-driven loop.  Only
+    constants, callables without a t parameter, or an explicit `time_independent=True` from the caller let the
+    whole loop run on the device (pg_solver_run)."""
+    if not callable(fn) or time_independent:
         return False
-    a, b = _eval(fn, coords, t0, nspace), _eval(fn, coords, t1, nspace)
-    if isinstance(a, float) and isinstance(b, float):
-        return a != b
-    return not np.array_equal(np.asarray(a), np.asarray(b))
+    return _accepts(fn, nspace + 1)
 
 
 def solve_DiffusionUnsteadyMono_b(s: Solver, phase: Phase, Δt: float, Tₑ: float, bc_b: BorderConditions, bc,
                                   scheme: str, method="bicgstab", algorithm=None, save_states: bool = True,
-                                  verbose: bool = False, max_steps: Optional[int] = None, **kwargs):
+                                  verbose: bool = False, max_steps: Optional[int] = None,
+                                  time_independent: bool = False, **kwargs):
     """solve_DiffusionUnsteadyMono!(s, phase, Δt, Tₑ, bc_b, bc, scheme; method, algorithm, kwargs...)
     -- src/solver/diffusion.jl:268-301, quirks kept: the first solve uses the constructor's system and is
-    states[1]; A is rebuilt once with `scheme`; `while t < Tₑ` with fp64 `t += Δt`; data at t+Δt."""
+    states[1]; A is rebuilt once with `scheme`; `while t < Tₑ` with fp64 `t += Δt`; data at t+Δt.
+    `time_independent=True` (not in the reference): the caller asserts that no closure depends on t, which lets the
+    loop stay on the device although the closures have a t parameter."""
     if s is None or not s._h:
         raise PenguinHipError("Solver is not initialized. Call a solver constructor first.")  # :269-271
     opts = _krylov_opts(method, kwargs)
@@ -714,6 +734,7 @@ def solve_DiffusionUnsteadyMono_b(s: Solver, phase: Phase, Δt: float, Tₑ: flo
     t = 0.0
     info = L.pg_step_info()
     L.check(L.lib().pg_solver_initial_solve(s._h, C.byref(opts), C.byref(info)))   # :275
+    _step_info_check(s, info, "the first solve")
     s._initial_done = True
     if log:
         s.ch.append({"iters": info.iters, "resnorm": info.resnorm, "isconverged": bool(info.converged)})
@@ -723,11 +744,10 @@ def solve_DiffusionUnsteadyMono_b(s: Solver, phase: Phase, Δt: float, Tₑ: flo
     if verbose:
         print("Time: ", t)
         print("Solver Extremum: ", info.extremum)
-    # is any closure time dependent?  sample t = Δt and 2Δt
-    dyn_f = _time_dependent(phase.source, cap._cw, Δt, 2 * Δt, 3)
-    dyn_g = _time_dependent(bc.value, cap._cg, Δt, 2 * Δt, 3) if callable(bc.value) else False
-    dyn_b = any(_time_dependent(getattr(c, "value", None), np.zeros((1, mesh.N)), Δt, 2 * Δt, mesh.N)
-                for c in bc_b.borders.values())
+    # closures with a time parameter are re-evaluated every step, as the reference does (never sampled and guessed)
+    dyn_f = _time_dependent(phase.source, 3, time_independent)
+    dyn_g = _time_dependent(bc.value, 3, time_independent)
+    dyn_b = any(_time_dependent(getattr(c, "value", None), mesh.N, time_independent) for c in bc_b.borders.values())
     steps = 0
     if not (dyn_f or dyn_g or dyn_b):
         if save_states or verbose or log:
@@ -738,6 +758,7 @@ def solve_DiffusionUnsteadyMono_b(s: Solver, phase: Phase, Δt: float, Tₑ: flo
                 if verbose:
                     print("Time: ", t)
                 L.check(L.lib().pg_solver_step(s._h, C.c_int32(sch), C.byref(opts), C.byref(info)))
+                _step_info_check(s, info, "a time-step solve")
                 s._have_run = True
                 if log:
                     s.ch.append({"iters": info.iters, "resnorm": info.resnorm, "isconverged": bool(info.converged)})
@@ -753,6 +774,8 @@ def solve_DiffusionUnsteadyMono_b(s: Solver, phase: Phase, Δt: float, Tₑ: flo
                                           C.c_int64(-1 if max_steps is None else max_steps), C.c_int32(0), C.byref(run)))
             s._have_run = True
             s.last_run = run
+            if run.unconverged_steps:
+                _check_converged(s, False, f"{run.unconverged_steps} of {run.steps} time-step solves", run.worst_relres)
             s.x = s._fetch_state()
         return s
     # time-dependent data: host-driven loop, closures evaluated at the reference's points and times
@@ -776,6 +799,7 @@ def solve_DiffusionUnsteadyMono_b(s: Solver, phase: Phase, Δt: float, Tₑ: flo
         if dyn_b:
             L.check(L.lib().pg_solver_set_border_values(s._h, L.dptr(_border_values(bc_b, mesh, t))))   # :292
         L.check(L.lib().pg_solver_step(s._h, C.c_int32(sch), C.byref(opts), C.byref(info)))            # :294
+        _step_info_check(s, info, "a time-step solve")
         s._have_run = True
         if log:
             s.ch.append({"iters": info.iters, "resnorm": info.resnorm, "isconverged": bool(info.converged)})
@@ -845,19 +869,21 @@ def DiffusionUnsteadyDiph(phase1: Phase, phase2: Phase, bc_b: BorderConditions, 
 def solve_DiffusionUnsteadyDiph_b(s: Solver, phase1: Phase, phase2: Phase, Δt: float, Tₑ: float,
                                   bc_b: BorderConditions, ic: InterfaceConditions, scheme: str, method="bicgstab",
                                   algorithm=None, save_states: bool = True, verbose: bool = False,
-                                  max_steps: Optional[int] = None, **kwargs):
-    """solve_DiffusionUnsteadyDiph!(...) -- src/solver/diffusion.jl:422-454 (constant-in-time sources)."""
+                                  max_steps: Optional[int] = None, time_independent: bool = False, **kwargs):
+    """solve_DiffusionUnsteadyDiph!(...) -- src/solver/diffusion.jl:422-454.  Sources with a time parameter are
+    re-evaluated every step (`time_independent=True`: the caller asserts they are constant in time)."""
     if s is None or not s._h:
         raise PenguinHipError("Solver is not initialized. Call a solver constructor first.")
     opts = _krylov_opts(method, kwargs)
     M = s._ctx["M"]
     sch = L.PG_SCHEME[scheme] if scheme in L.PG_SCHEME else L.PG_SCHEME["BE"]
-    dyn = any(_time_dependent(ph.source, ph.capacity._cw, Δt, 2 * Δt, 3) for ph in (phase1, phase2))
+    dyn = any(_time_dependent(ph.source, 3, time_independent) for ph in (phase1, phase2))
     t = 0.0
     info = L.pg_step_info()
     if verbose:
         print("Time: ", t)
     L.check(L.lib().pg_solver_initial_solve(s._h, C.byref(opts), C.byref(info)))
+    _step_info_check(s, info, "the first solve")
     s._initial_done = True
     s.x = s._fetch_state()
     if save_states:
@@ -879,6 +905,7 @@ def solve_DiffusionUnsteadyDiph_b(s: Solver, phase1: Phase, phase2: Phase, Δt: 
                 L.check(L.lib().pg_solver_set_source(s._h, q, L.dptr(fn if fn is not None else zero),
                                                      L.dptr(fn1 if fn1 is not None else zero)))
         L.check(L.lib().pg_solver_step(s._h, C.c_int32(sch), C.byref(opts), C.byref(info)))
+        _step_info_check(s, info, "a time-step solve")
         s._have_run = True
         s.x = s._fetch_state()
         if save_states:
@@ -954,6 +981,7 @@ def _solve_steady(s: Solver, method, kwargs, banner: str, verbose: bool):
     opts = _krylov_opts(method, kwargs)
     info = L.pg_step_info()
     L.check(L.lib().pg_solver_initial_solve(s._h, C.byref(opts), C.byref(info)))   # solve_system!(s; ...)
+    _step_info_check(s, info, "the first solve")
     s._initial_done = True
     s.x = s._fetch_state()
     s.ch.append(dict(iters=info.iters, converged=bool(info.converged), resnorm=info.resnorm, bnorm=info.bnorm))

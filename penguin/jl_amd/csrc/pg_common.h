@@ -153,6 +153,24 @@ struct Laps {
   }
 };
 
+// two HIP events that are destroyed on every exit path (timed regions whose body may throw)
+struct EventPair {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  EventPair() {
+    PG_HIP(hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) {
+      (void)hipEventDestroy(e0);
+      throw Error("hipEventCreate failed");
+    }
+  }
+  ~EventPair() {
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+  }
+  EventPair(const EventPair&) = delete;
+  EventPair& operator=(const EventPair&) = delete;
+};
+
 inline int grid_for(i64 n, int block, int cap = 256 * 8) {
   i64 g = (n + block - 1) / block;
   if (g < 1) g = 1;

@@ -76,10 +76,9 @@ void rank_main(const VArgs& a, int rank, LocalComm* lc, int device, std::string*
     for (int k = 0; k < a.nkeys; ++k) borders[k] = pg_border_desc{a.keys[k], PG_BC_DIRICHLET, a.border_value};
     int64_t M = 1;
     for (int d = 0; d < a.N; ++d) M *= a.n[d] + 1;
-    // x_out == NULL: full-size smoke runs (8 x 512^3 slabs: 2M doubles = 17 GB per rank) keep T0 = zeros implicit
-    std::vector<double> T0(a.x_out ? 2 * M : 0, 0.0);
-    check(pg_solver_create_unsteady_mono(cap, ops, &bc, borders.data(), a.nkeys, nullptr, nullptr, a.dt,
-                                         a.x_out ? T0.data() : nullptr, a.scheme_ctor, &sol), "solver");
+    // T0 = zeros stays implicit (NULL): 2M doubles per rank would be 17 GB of host memory at 8 x 512^3
+    check(pg_solver_create_unsteady_mono(cap, ops, &bc, borders.data(), a.nkeys, nullptr, nullptr, a.dt, nullptr,
+                                         a.scheme_ctor, &sol), "solver");
     pg_krylov_opts o{g_method, 1e-13, 0.0, 0, 4, g_method == PG_METHOD_BICGSTAB ? 1 : 0, g_restart};
     pg_run_info info{};
     check(pg_solver_run(sol, 1e300, a.scheme_run, &o, 1, a.steps, 0, &info), "run");

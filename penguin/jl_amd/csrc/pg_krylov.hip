@@ -32,22 +32,26 @@ namespace {
 
 // ---- fused vector kernels ---------------------------------------------------------------------------
 // x0 == nullptr: zero initial guess (IterativeSolvers' default).  Otherwise x = x0 and r = b - Ax0 (warm start with
-// the previous time level; Ax0 is the SpMV the CN right-hand side needs anyway).  partials: slot 0 = r.r, slot 1 = b.b
+// the previous time level; Ax0 is the SpMV the CN right-hand side needs anyway).  partials: slot 0 = r.r, slot 1 =
+// (b,b)_W, slot 2 = (r,r)_W with the weights ds² of the convergence test (pg_spmv.h; ds == nullptr: unweighted)
 __global__ __launch_bounds__(BLOCK) void k_bicg_init(i64 n, i64 nvec, const double* __restrict__ b,
                                                      const double* __restrict__ x0, const double* __restrict__ Ax0,
                                                      double* __restrict__ x, double* __restrict__ r,
                                                      double* __restrict__ rhat, double* __restrict__ p,
-                                                     double* __restrict__ v, double* __restrict__ partials) {
+                                                     double* __restrict__ v, double* __restrict__ partials,
+                                                     const double* __restrict__ ds) {
   __shared__ double s_red[BLOCK / 64];
-  double acc = 0.0, accb = 0.0;
+  double acc = 0.0, accb = 0.0, accw = 0.0;
   for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < nvec; i += (i64)gridDim.x * BLOCK) {
     if (i < n) {
       const double bi = b[i];
       const double ri = x0 ? bi - Ax0[i] : bi;
+      const double d = ds ? ds[i] : 1.0;
       x[i] = x0 ? x0[i] : 0.0;
       r[i] = ri; rhat[i] = ri; p[i] = ri; v[i] = 0.0;   // p₀ = r₀ (β = 0)
       acc += ri * ri;
-      accb += bi * bi;
+      accb += (d * bi) * (d * bi);
+      accw += (d * ri) * (d * ri);
     } else {
       x[i] = 0.0; p[i] = 0.0;
     }
@@ -56,6 +60,8 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_init(i64 n, i64 nvec, const doub
   if (threadIdx.x == 0) partials[blockIdx.x] = t;
   const double tb = block_sum(accb, s_red);
   if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = tb;
+  const double tw = block_sum(accw, s_red);
+  if (threadIdx.x == 0) partials[2 * (size_t)gridDim.x + blockIdx.x] = tw;
 }
 
 // s = r - αv written over r (r is not needed again: r_new = s - ωt); partials slots 2, 3 = (r̂,s), (s,s): they are
@@ -82,7 +88,8 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_s(i64 n, const double* __restric
   if (threadIdx.x == 0) partials[3 * (size_t)gridDim.x + blockIdx.x] = t1;
 }
 
-// x += αp + ωs;  r = s - ωt;  p = r + β(p - ωv)  (restart: p = r̂ = r);  partial slot 1 = (r,r).
+// x += αp + ωs;  r = s - ωt;  p = r + β(p - ωv)  (restart: p = r̂ = r);  partial slot 1 = (r,r)_W (convergence, weights
+// ds²: pg_spmv.h), slot 2 = (r,r) (restart bookkeeping).
 // β is known before r exists because ρ_new = (r̂,r) = (r̂,s) - ω(r̂,t) comes out of the dots of k_bicg_s and of the
 // second SpMV: the classical p-update kernel (4 vector passes) and one scalar kernel per iteration disappear.
 // POLY: the search directions of the preconditioned iteration are u = M⁻¹p and us = M⁻¹s (x += αu + ωus)
@@ -91,12 +98,13 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_xrp(i64 n, double* sc, const dou
                                                     const double* __restrict__ v, double* __restrict__ x,
                                                     double* __restrict__ r, double* __restrict__ p,
                                                     double* __restrict__ rhat, double* __restrict__ partials,
-                                                    const double* __restrict__ u, const double* __restrict__ us) {
+                                                    const double* __restrict__ u, const double* __restrict__ us,
+                                                    const double* __restrict__ ds) {
   __shared__ double s_red[BLOCK / 64];
   if (sc[S_DONE] != 0.0) return;
   const double alpha = sc[S_ALPHA], omega = sc[S_OMEGA], beta = sc[S_BETA];
   const bool restart = sc[S_RESTART] != 0.0;
-  double a0 = 0.0;
+  double a0 = 0.0, aw = 0.0;
   for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) {
     const double si = r[i], pi = p[i];
     const double du = POLY ? (NTV ? __builtin_nontemporal_load(u + i) : u[i]) : pi;
@@ -112,46 +120,57 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_xrp(i64 n, double* sc, const dou
       p[i] = ri + beta * (pi - omega * (NTV ? __builtin_nontemporal_load(v + i) : v[i]));
     }
     a0 += ri * ri;
+    const double wr = ds[i] * ri;
+    aw += wr * wr;
   }
-  // slot 1: summed together with the next SpMV's (r̂,v) in slot 0 (or alone, before a host poll)
+  // slots 1, 2: summed together with the next SpMV's (r̂,v) in slot 0 (or alone, before a host poll)
+  const double tw = block_sum(aw, s_red);
+  if (threadIdx.x == 0) partials[(size_t)gridDim.x + blockIdx.x] = tw;
   const double t0 = block_sum(a0, s_red);
-  if (threadIdx.x == 0) partials[(size_t)gridDim.x + blockIdx.x] = t0;
+  if (threadIdx.x == 0) partials[2 * (size_t)gridDim.x + blockIdx.x] = t0;
   if (blockIdx.x == 0 && threadIdx.x == 0) sc[S_PENDING3] = 1.0;   // (only the scalar kernels read it)
 }
 
 __global__ __launch_bounds__(BLOCK) void k_cg_init(i64 n, i64 nvec, const double* __restrict__ b, double* __restrict__ x,
                                                    double* __restrict__ r, double* __restrict__ p,
-                                                   double* __restrict__ partials) {
+                                                   double* __restrict__ partials, const double* __restrict__ ds) {
   __shared__ double s_red[BLOCK / 64];
-  double acc = 0.0;
+  double acc = 0.0, accw = 0.0;
   for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < nvec; i += (i64)gridDim.x * BLOCK) {
     if (i < n) {
       const double bi = b[i];
       x[i] = 0.0; r[i] = bi; p[i] = bi;
       acc += bi * bi;
+      accw += (ds[i] * bi) * (ds[i] * bi);
     } else {
       x[i] = 0.0; p[i] = 0.0;
     }
   }
   const double t = block_sum(acc, s_red);
   if (threadIdx.x == 0) partials[blockIdx.x] = t;
+  const double tw = block_sum(accw, s_red);
+  if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = tw;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_cg_xr(i64 n, const double* __restrict__ sc, const double* __restrict__ p,
                                                  const double* __restrict__ q, double* __restrict__ x,
-                                                 double* __restrict__ r, double* __restrict__ partials) {
+                                                 double* __restrict__ r, double* __restrict__ partials,
+                                                 const double* __restrict__ ds) {
   __shared__ double s_red[BLOCK / 64];
   if (sc[S_DONE] != 0.0) return;
   const double alpha = sc[S_ALPHA];
-  double a0 = 0.0;
+  double a0 = 0.0, aw = 0.0;
   for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) {
     x[i] += alpha * p[i];
     const double ri = r[i] - alpha * q[i];
     r[i] = ri;
     a0 += ri * ri;
+    aw += (ds[i] * ri) * (ds[i] * ri);
   }
   const double t0 = block_sum(a0, s_red);
   if (threadIdx.x == 0) partials[blockIdx.x] = t0;
+  const double tw = block_sum(aw, s_red);
+  if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = tw;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_cg_p(i64 n, const double* __restrict__ sc, const double* __restrict__ r,
@@ -217,6 +236,23 @@ struct SpmvTimer {
   int cur = 0;
   bool armed = false;
   explicit SpmvTimer(bool on_) : on(on_) {}
+  // events are recycled through a per-thread pool: nothing is created or destroyed inside the time loop after the
+  // first profiled solve
+  static std::vector<hipEvent_t>& pool() {
+    static thread_local std::vector<hipEvent_t> p;
+    return p;
+  }
+  static hipEvent_t take() {
+    auto& p = pool();
+    if (!p.empty()) {
+      hipEvent_t e = p.back();
+      p.pop_back();
+      return e;
+    }
+    hipEvent_t e;
+    PG_HIP(hipEventCreate(&e));
+    return e;
+  }
   void begin(hipStream_t st, int iteration) {
     cur = iteration;
     // every `sample`-th launch is bracketed (PG_PROFILE_SAMPLE, default 3 -- odd, so the two fused-dot modes of a
@@ -226,8 +262,8 @@ struct SpmvTimer {
     static thread_local unsigned long long counter = 0;
     armed = on && (counter++ % sample == 0);
     if (!armed) return;
-    PG_HIP(hipEventCreate(&e0));
-    PG_HIP(hipEventCreate(&e1));
+    e0 = take();
+    e1 = take();
     PG_HIP(hipEventRecord(e0, st));
   }
   void end(hipStream_t st) {
@@ -247,8 +283,8 @@ struct SpmvTimer {
         s.spmv_ms += ms;
         s.spmv_launches += 1;
       }
-      (void)hipEventDestroy(pr.first);
-      (void)hipEventDestroy(pr.second);
+      pool().push_back(pr.first);
+      pool().push_back(pr.second);
     }
     pairs.clear();
     iter_of.clear();
@@ -316,7 +352,7 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
   static const bool ntv = getenv("PG_KRYLOV_NT") ? atoi(getenv("PG_KRYLOV_NT")) != 0 : true;
   static const bool poly_env = getenv("PG_POLY") ? atoi(getenv("PG_POLY")) != 0 : true;
   // Neumann preconditioner: BiCGStab on the slice kernel, where Gershgorin bounds the spectrum inside |λ - 1| < 0.95
-  const bool poly = poly_env && !cg && A.poly_ok && spmv_supports_preconditioner_product() && n > 0;
+  const bool poly = poly_env && opts.precond >= 0 && !cg && A.poly_ok && spmv_supports_preconditioner_product() && n > 0;
   if (poly && w.u.n < nvec) {
     w.u.alloc(nvec);
     w.us.alloc(nvec);
@@ -327,11 +363,11 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
   if (!cg) {
     if (!preinit)
       hipLaunchKernelGGL(k_bicg_init, dim3(G), dim3(BLOCK), 0, st, n, nvec, b, x0, Ax0, x, w.r.p, w.rhat.p, w.p.p, w.v.p,
-                       w.partials.p);
-    finalize(PH_INIT, 2, w, st, false);
+                       w.partials.p, (const double*)A.ds.p);
+    finalize(PH_INIT, 3, w, st, false);
   } else {
-    hipLaunchKernelGGL(k_cg_init, dim3(G), dim3(BLOCK), 0, st, n, nvec, b, x, w.r.p, w.p.p, w.partials.p);
-    finalize(PH_CG_INIT, 1, w, st, false);
+    hipLaunchKernelGGL(k_cg_init, dim3(G), dim3(BLOCK), 0, st, n, nvec, b, x, w.r.p, w.p.p, w.partials.p, (const double*)A.ds.p);
+    finalize(PH_CG_INIT, 2, w, st, false);
   }
   PG_HIP(hipGetLastError());
 
@@ -357,11 +393,11 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
         // the scalar phase that follows an SpMV is evaluated by the last block of that launch (stencil-slice kernel);
         // with several ranks the halo exchange of p overlaps the rows that need no ghost value (spmv_with_halo)
         const int derive_here = (cx.nranks == 1 && !cx.comm) ? 1 : 0;
-        const FinArgs f1{w.ticket.p, w.sc.p, PH_BICG_1, 2, derive_here, nullptr};
+        const FinArgs f1{w.ticket.p, w.sc.p, PH_BICG_1, 3, derive_here, nullptr};
         const bool folded1 = spmv_with_halo(1, A, nb, slab, dir_p, w.v.p, w.rhat.p, w.partials.p, w.sc.p, G, st, &f1);   // v = Â p, (r̂,v)
         timer.end(st);
         // previous iteration's (r,r): convergence / restart; then α
-        if (folded1) finalize_folded(PH_BICG_1, 2, w, st); else finalize(PH_BICG_1, 2, w, st, true);
+        if (folded1) finalize_folded(PH_BICG_1, 3, w, st); else finalize(PH_BICG_1, 3, w, st, true);
         if (ntv) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_s<true>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_s<false>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p);
         double* dir_s = w.r.p;     // r holds s
@@ -377,7 +413,7 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
         if (folded2) finalize_folded(PH_BICG_2, 5, w, st); else finalize(PH_BICG_2, 5, w, st, true);   // ω, ρ, β / restart
 #define PG_LAUNCH_X(NTV_, POLY_)                                                                                        \
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_xrp<NTV_, POLY_>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.t.p, w.v.p, x, w.r.p, \
-                     w.p.p, w.rhat.p, w.partials.p, (const double*)w.u.p, (const double*)w.us.p)
+                     w.p.p, w.rhat.p, w.partials.p, (const double*)w.u.p, (const double*)w.us.p, (const double*)A.ds.p)
         if (ntv) { if (poly) PG_LAUNCH_X(true, true); else PG_LAUNCH_X(true, false); }
         else { if (poly) PG_LAUNCH_X(false, true); else PG_LAUNCH_X(false, false); }
 #undef PG_LAUNCH_X
@@ -386,12 +422,12 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
         spmv_with_halo(2, A, nb, slab, w.p.p, w.v.p, nullptr, w.partials.p, w.sc.p, G, st);   // v = A p ; (v.p), (v.v)
         timer.end(st);
         finalize(PH_CG_1, 1, w, st, true);
-        hipLaunchKernelGGL(k_cg_xr, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.p.p, w.v.p, x, w.r.p, w.partials.p);
-        finalize(PH_CG_2, 1, w, st, true);
+        hipLaunchKernelGGL(k_cg_xr, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.p.p, w.v.p, x, w.r.p, w.partials.p, (const double*)A.ds.p);
+        finalize(PH_CG_2, 2, w, st, true);
         hipLaunchKernelGGL(k_cg_p, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.r.p, w.p.p);
       }
     }
-    if (!cg) finalize(PH_BICG_3, 1, w, st, true, 1);   // the last iteration's (r,r), not yet folded into a next one
+    if (!cg) finalize(PH_BICG_3, 2, w, st, true, 1);   // the last iteration's (r,r), not yet folded into a next one
     PG_HIP(hipGetLastError());
     launched += batch;
     PG_HIP(hipMemcpyAsync(w.h_sc, w.sc.p, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, st));
@@ -405,7 +441,7 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
   stats.iters = (int)w.h_sc[S_ITERS];
   w.last_iters = stats.iters;
   stats.converged = w.h_sc[S_DONE] == 1.0 ? 1 : 0;
-  stats.resnorm = std::sqrt(w.h_sc[S_RR]);
+  stats.resnorm = std::sqrt(cg ? w.h_sc[S_RRW] : w.h_sc[S_RR]);   // the weighted norms of the convergence test
   stats.bnorm = std::sqrt(w.h_sc[S_BB]);
   timer.collect(stats, stats.iters);
 }

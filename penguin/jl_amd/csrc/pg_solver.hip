@@ -230,7 +230,7 @@ __global__ __launch_bounds__(BLOCK) void k_rhs_init(i64 n, i64 nvec, int scheme,
                                                     double* __restrict__ r, double* __restrict__ rhat,
                                                     double* __restrict__ p, double* __restrict__ partials) {
   __shared__ double s_red[BLOCK / 64];
-  double acc = 0.0, accb = 0.0;
+  double acc = 0.0, accb = 0.0, accw = 0.0;   // (r,r), (b,b)_W, (r,r)_W: slots 0, 1, 2 as k_bicg_init (weights ds²)
   const i64 npair = (nvec + 1) / 2;
   for (i64 q = blockIdx.x * (i64)BLOCK + threadIdx.x; q < npair; q += (i64)gridDim.x * BLOCK) {
     const i64 i = 2 * q;
@@ -257,7 +257,8 @@ __global__ __launch_bounds__(BLOCK) void k_rhs_init(i64 n, i64 nvec, int scheme,
       *reinterpret_cast<rd2_t*>(rhat + i) = ri;
       *reinterpret_cast<rd2_t*>(p + i) = ri;
       acc += ri.x * ri.x + ri.y * ri.y;
-      accb += bi.x * bi.x + bi.y * bi.y;
+      accb += (d.x * bi.x) * (d.x * bi.x) + (d.y * bi.y) * (d.y * bi.y);
+      accw += (d.x * ri.x) * (d.x * ri.x) + (d.y * ri.y) * (d.y * ri.y);
     } else {
       for (i64 k = i; k < i + 2 && k < nvec; ++k) {
         if (k < n) {
@@ -266,7 +267,8 @@ __global__ __launch_bounds__(BLOCK) void k_rhs_init(i64 n, i64 nvec, int scheme,
           b[k] = bi;
           r[k] = ri; rhat[k] = ri; p[k] = ri;
           acc += ri * ri;
-          accb += bi * bi;
+          accb += (ds[k] * bi) * (ds[k] * bi);
+          accw += (ds[k] * ri) * (ds[k] * ri);
         } else {
           p[k] = 0.0;
         }
@@ -277,6 +279,8 @@ __global__ __launch_bounds__(BLOCK) void k_rhs_init(i64 n, i64 nvec, int scheme,
   if (threadIdx.x == 0) partials[blockIdx.x] = t;
   const double tb = block_sum(accb, s_red);
   if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = tb;
+  const double tw = block_sum(accw, s_red);
+  if (threadIdx.x == 0) partials[2 * (size_t)gridDim.x + blockIdx.x] = tw;
 }
 
 // z refers to S_old: re-express it with S_new (x = S_old z = S_new z')
@@ -577,6 +581,7 @@ pg_krylov_opts default_opts() {
   o.check_every = 4;
   o.warm_start = 1;
   o.restart = 0;
+  o.precond = 0;
   return o;
 }
 
@@ -827,32 +832,34 @@ int32_t pg_solver_run(pg_solver* s, double Tend, int32_t scheme, const pg_krylov
   PG_REQUIRE(s, "Solver is not initialized. Call a solver constructor first.");
   PG_REQUIRE(scheme == PG_SCHEME_BE || scheme == PG_SCHEME_CN, "scheme must be BE or CN");
   hipStream_t stream = ctx().stream;
-  hipEvent_t e0, e1;
-  PG_HIP(hipEventCreate(&e0));
-  PG_HIP(hipEventCreate(&e1));
-  PG_HIP(hipEventRecord(e0, stream));
+  EventPair ev;                     // destroyed on every exit path (do_step may throw)
+  PG_HIP(hipEventRecord(ev.e0, stream));
   SolveStats tot;
-  i64 steps = 0, iters = 0;
+  i64 steps = 0, iters = 0, unconverged = 0;
+  double worst = 0.0;
+  auto account = [&](const SolveStats& st) {
+    iters += st.iters; tot.spmv_ms += st.spmv_ms; tot.spmv_launches += st.spmv_launches;
+    if (!st.converged) ++unconverged;
+    if (st.bnorm > 0.0) worst = std::max(worst, st.resnorm / st.bnorm);
+  };
   if (do_initial_flag) {
     SolveStats st;
     do_initial(s, opts, st);
-    iters += st.iters; tot.spmv_ms += st.spmv_ms; tot.spmv_launches += st.spmv_launches;
+    account(st);
     if (save_every > 0) keep_state(s);
   }
   while (s->t < Tend) {             // diffusion.jl:286
     if (max_steps >= 0 && steps >= max_steps) break;
     SolveStats st;
     do_step(s, scheme, opts, st);
-    iters += st.iters; tot.spmv_ms += st.spmv_ms; tot.spmv_launches += st.spmv_launches;
+    account(st);
     ++steps;
     if (save_every > 0 && steps % save_every == 0) keep_state(s);
   }
-  PG_HIP(hipEventRecord(e1, stream));
-  PG_HIP(hipEventSynchronize(e1));
+  PG_HIP(hipEventRecord(ev.e1, stream));
+  PG_HIP(hipEventSynchronize(ev.e1));
   float ms = 0.f;
-  PG_HIP(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
+  PG_HIP(hipEventElapsedTime(&ms, ev.e0, ev.e1));
   if (info) {
     info->steps = steps;
     info->total_iters = iters;
@@ -861,6 +868,8 @@ int32_t pg_solver_run(pg_solver* s, double Tend, int32_t scheme, const pg_krylov
     info->solve_ms = ms;
     info->spmv_ms_total = tot.spmv_ms;
     info->spmv_launches = tot.spmv_launches;
+    info->unconverged_steps = unconverged;
+    info->worst_relres = worst;
   }
   PG_API_END
 }
@@ -980,6 +989,16 @@ int32_t pg_solver_get_system_csr(const pg_solver* s, int32_t which, int64_t* row
   PG_API_END
 }
 
+int32_t pg_solver_get_row_scaling(const pg_solver* s, int32_t which, double* ds) {
+  PG_API_BEGIN
+  require_init();
+  PG_REQUIRE(s && ds, "pg_solver_get_row_scaling: NULL argument");
+  if ((which & 1) == 1) PG_REQUIRE(s->have_run, "run matrix not assembled yet");
+  const CsrMatrix& A = (which & 1) == 0 ? s->A_ctor : run_matrix(s);
+  if (s->nb.n_own > 0) A.ds.download(ds, s->nb.n_own);
+  PG_API_END
+}
+
 // max |y_a - y_b| between two SpMV kernel variants applied to the same deterministic test vector
 __global__ void k_test_vector(i64 n, double* x) {
   for (i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
@@ -1025,24 +1044,20 @@ int32_t pg_solver_time_spmv(pg_solver* s, int32_t which, int32_t reps, double* a
   if (sel == 1) PG_REQUIRE(s->have_run, "run matrix not assembled yet");
   const CsrMatrix& A = sel == 0 ? s->A_ctor : run_matrix(s);
   hipStream_t st = ctx().stream;
-  hipEvent_t e0, e1;
-  PG_HIP(hipEventCreate(&e0));
-  PG_HIP(hipEventCreate(&e1));
+  EventPair ev;
   KrylovWork& w = s->work;
   auto one = [&]() {
     if (mode == 0) spmv(A, s->z.p, s->y.p, st);
     else launch_spmv(mode, A, s->z.p, s->y.p, w.rhat.p, w.partials.p, nullptr, w.grid, st);
   };
   for (int i = 0; i < 3; ++i) one();
-  PG_HIP(hipEventRecord(e0, st));
+  PG_HIP(hipEventRecord(ev.e0, st));
   for (int i = 0; i < reps; ++i) one();
-  PG_HIP(hipEventRecord(e1, st));
-  PG_HIP(hipEventSynchronize(e1));
+  PG_HIP(hipEventRecord(ev.e1, st));
+  PG_HIP(hipEventSynchronize(ev.e1));
   PG_HIP(hipGetLastError());
   float ms = 0.f;
-  PG_HIP(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
+  PG_HIP(hipEventElapsedTime(&ms, ev.e0, ev.e1));
   *avg_ms = ms / reps;
   PG_API_END
 }

@@ -185,6 +185,38 @@ def test_time_dependent_data_and_variable_coefficient(pj):
         assert rel_l2(s.x, so.x) <= TOL_T
 
 
+def test_data_that_switches_on_late_is_not_guessed_constant(pj):
+    """The reference re-evaluates f, g and the border values on every step (diffusion.jl:286-296).  Data that two early
+    samples cannot tell from a constant -- a border value that vanishes at the origin, a source that switches on after
+    several steps, an interface value that changes once -- must still reach the solve: closures with a time parameter
+    always take the host-driven loop."""
+    n = 20
+    M = (n + 1) ** 2
+    dt = 0.4 * (4.0 / n) ** 2
+    t_on = 3.5 * dt
+    f = lambda x, y, z, t: np.where(t > t_on, 2.0 + 0.0 * x, 0.0 * x)          # off for the first steps
+    g = lambda x, y, z, t: 1.0 if t < 5.5 * dt else 1.5                      # scalar-valued, changes late
+    bv = lambda x, y, t: x * t                                              # zero at the origin for every t
+    u0 = np.concatenate([0.1 * np.ones(M), np.ones(M)])
+    for scheme in ("BE", "CN"):
+        (s, ph, bcb, bci), (so, oph, obcb, obci) = _mono_pair(
+            pj, 2, n, 4.0, (2.01, 2.01), 1.6, pj.Dirichlet(g), po.Dirichlet(g),
+            {k: pj.Dirichlet(bv) for k in HEAT_BORDERS}, {k: po.Dirichlet(bv) for k in HEAT_BORDERS}, dt, u0, scheme, f=f)
+        pj.solve_DiffusionUnsteadyMono_b(s, ph, dt, 8 * dt, bcb, bci, scheme, reltol=1e-13)
+        po.solve_DiffusionUnsteadyMono(so, oph, dt, 8 * dt, obcb, obci, scheme, method="\\")
+        assert len(s.states) == len(so.states)
+        for a, b in zip(s.states, so.states):
+            assert rel_l2(a, b) <= TOL_T
+        # and the late data did matter: the last state differs from a run that keeps the early data
+        f0 = lambda x, y, z, t: 0.0 * x
+        g0 = lambda x, y, z, t: 1.0
+        (s0, ph0, bcb0, bci0), _ = _mono_pair(
+            pj, 2, n, 4.0, (2.01, 2.01), 1.6, pj.Dirichlet(g0), po.Dirichlet(g0),
+            {k: pj.Dirichlet(bv) for k in HEAT_BORDERS}, {k: po.Dirichlet(bv) for k in HEAT_BORDERS}, dt, u0, scheme, f=f0)
+        pj.solve_DiffusionUnsteadyMono_b(s0, ph0, dt, 8 * dt, bcb0, bci0, scheme, reltol=1e-13)
+        assert rel_l2(s0.x, s.x) > 1e-3
+
+
 @pytest.mark.parametrize("bc_kind", ["robin", "neumann"])
 def test_robin_and_neumann_interface(pj, bc_kind):
     """Iᵦ != 0: blocks 3-4 live, genuinely 2x2 non-symmetric system."""
