@@ -127,6 +127,8 @@ typedef struct {
   int64_t neumann_ok;     /* 1: the spectrum of the preconditioned matrix is provably inside |z - 1| < 0.95, BiCGStab
                              runs right-preconditioned with M^-1 = 2I - A (half the iterations, same SpMV count) */
   double gershgorin;      /* the largest Gershgorin radius that decision rests on (all ranks)     */
+  int64_t spmv_units;     /* marching units (DESIGN.md "SpMV"): <= 11 planes x 126 uniform stencil rows each      */
+  int64_t rows_marched;   /* rows covered by them (counted in rows_uniform too; they are in no slice)             */
 } pg_system_info;
 
 /* ---- library / device -------------------------------------------------------------------- */

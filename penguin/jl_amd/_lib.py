@@ -71,7 +71,8 @@ class pg_system_info(C.Structure):
     _fields_ = [("n_own", C.c_int64), ("nnz", C.c_int64), ("n_ghost", C.c_int64), ("n_omega", C.c_int64),
                 ("n_gamma", C.c_int64), ("M_global", C.c_int64), ("spmv_bytes", C.c_int64), ("spmv_slices", C.c_int64),
                 ("rows_uniform", C.c_int64), ("rows_pattern", C.c_int64), ("rows_irregular", C.c_int64),
-                ("neumann_ok", C.c_int64), ("gershgorin", C.c_double)]
+                ("neumann_ok", C.c_int64), ("gershgorin", C.c_double), ("spmv_units", C.c_int64),
+                ("rows_marched", C.c_int64)]
 
 
 def declared_symbols() -> list[str]:

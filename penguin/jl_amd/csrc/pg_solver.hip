@@ -926,6 +926,8 @@ int32_t pg_solver_system_info(const pg_solver* s, int32_t which, pg_system_info*
   out->rows_irregular = A.rows_g;
   out->neumann_ok = A.poly_ok ? 1 : 0;
   out->gershgorin = A.gersh;
+  out->spmv_units = A.nunits;
+  out->rows_marched = A.rows_m;
   PG_API_END
 }
 
@@ -1040,15 +1042,35 @@ int32_t pg_solver_time_spmv(pg_solver* s, int32_t which, int32_t reps, double* a
   PG_API_BEGIN
   require_init();
   PG_REQUIRE(s && avg_ms && reps > 0, "pg_solver_time_spmv: bad arguments");
-  const int sel = which & 1, mode = (which >> 4) & 3;   // bits 4-5: fused-dot mode of the launch (0 plain, 1, 2, 3)
+  const int sel = which & 1, mode = (which >> 4) & 7;   // bits 4-6: mode of the launch (0 plain, 1, 2, 3 fused dots, 4: 2x - Ax)
+  PG_REQUIRE(mode <= 4, "pg_solver_time_spmv: unknown launch mode");
   if (sel == 1) PG_REQUIRE(s->have_run, "run matrix not assembled yet");
   const CsrMatrix& A = sel == 0 ? s->A_ctor : run_matrix(s);
   hipStream_t st = ctx().stream;
   EventPair ev;
   KrylovWork& w = s->work;
+  // bit 8: "cold" launches -- every launch gets another input / output / dot-operand vector out of a ring of 7 (1.7 GB at
+  // 512^3: nothing of the previous launch's vectors survives in the 256 MB Infinity Cache), which is how the launches of
+  // the Krylov loop see memory; without it the same x and y stay cache resident from launch to launch
+  const bool cold = (which & 256) != 0;
+  constexpr int RING = 7;
+  std::vector<DevBuf<double>> ring;
+  const i64 nv = s->nb.n_vec();
+  if (cold) {
+    ring.resize(RING);
+    for (auto& b : ring) {
+      b.alloc(nv > 0 ? nv : 1);
+      if (nv > 0) PG_HIP(hipMemcpyAsync(b.p, s->z.p, sizeof(double) * (size_t)nv, hipMemcpyDeviceToDevice, st));
+    }
+  }
+  int it = 0;
   auto one = [&]() {
-    if (mode == 0) spmv(A, s->z.p, s->y.p, st);
-    else launch_spmv(mode, A, s->z.p, s->y.p, w.rhat.p, w.partials.p, nullptr, w.grid, st);
+    const double* xin = cold ? ring[it % RING].p : s->z.p;
+    double* yout = cold ? ring[(it + 3) % RING].p : s->y.p;
+    const double* ax = cold ? ring[(it + 5) % RING].p : w.rhat.p;
+    ++it;
+    if (mode == 0) spmv(A, xin, yout, st);
+    else launch_spmv(mode, A, xin, yout, ax, w.partials.p, nullptr, w.grid, st);
   };
   for (int i = 0; i < 3; ++i) one();
   PG_HIP(hipEventRecord(ev.e0, st));

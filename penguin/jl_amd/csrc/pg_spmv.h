@@ -173,6 +173,7 @@ struct FinArgs {
   int nslots;         // partial slots [0, nslots) to sum into S_RED0..
   int do_derive;      // 0: sums only (several ranks: an all-reduce follows)
   const double* dotx; // operand of the (y, .) dot of modes 2 / 3; nullptr: the input vector x itself
+  double pc0 = 2.0, pc1 = -1.0;   // mode 4: y = pc0 x + pc1 A x  (default: the Neumann product 2x - Âx)
 };
 
 // executed by every block at the end of a producing launch (after its partials are stored); nparts = partial sums per

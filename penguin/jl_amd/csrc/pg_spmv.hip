@@ -275,12 +275,17 @@ __device__ inline d2_t load_pair(const double* p) {
   return r;
 }
 
+// epilogue of mode 4: y = pc0 x + pc1 (A x) -- one factor I - τÂ (pc0 = 1, pc1 = -τ) of the polynomial preconditioner's
+// residual polynomial, or 2x - Âx (pg_krylov.hip); the ONE expression every path of the kernel uses
+__device__ inline double mode4_out(double xown, double ax, double pc0, double pc1) { return pc0 * xown + pc1 * ax; }
+
 // rows of one U (PSL = false) or P (PSL = true) slice with CNT stencil slots; rec = the slice's record (lane & 31).
 // NB batches of 128 rows: every load of the slice is issued before the first FMA (one exposed latency per slice).
 template <int CNT, int NB, bool PSL, int MODE, bool NT>
 __device__ inline void slice_rows(const SDesc& d, int nrows, int rec, const double* __restrict__ pval,
                                   const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ aux,
-                                  const double* __restrict__ dx, int lane, double& acc0, double& acc1, double& acc2, int dbg) {
+                                  const double* __restrict__ dx, int lane, double& acc0, double& acc1, double& acc2, int dbg,
+                                  double pc0, double pc1) {
   constexpr bool DOTS = MODE >= 1 && MODE <= 3;   // MODE 4: y = 2x - Ax (the Neumann preconditioner), no dots
   int o[CNT];
 #pragma unroll
@@ -336,7 +341,7 @@ __device__ inline void slice_rows(const SDesc& d, int nrows, int rec, const doub
   }
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    if (MODE == 4) { sum[b].x = 2.0 * ax[b].x - sum[b].x; sum[b].y = 2.0 * ax[b].y - sum[b].y; }
+    if (MODE == 4) { sum[b].x = mode4_out(ax[b].x, sum[b].x, pc0, pc1); sum[b].y = mode4_out(ax[b].y, sum[b].y, pc0, pc1); }
     const bool st = !(dbg & 8) || sum[b].x == 1.2345e-300;
     double* yp = y + d.r0 + l0[b];
     if (live1[b]) {
@@ -360,36 +365,186 @@ __device__ inline void slice_rows(const SDesc& d, int nrows, int rec, const doub
 template <int CNT, bool PSL, int MODE, bool NT>
 __device__ inline void slice_nb(const SDesc& d, int nrows, int rec, const double* __restrict__ pval,
                                 const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ aux,
-                                const double* __restrict__ dx, int lane, double& acc0, double& acc1, double& acc2, int dbg) {
-  if (!PSL && nrows > 128) slice_rows<CNT, 2, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg);
-  else slice_rows<CNT, 1, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg);
+                                const double* __restrict__ dx, int lane, double& acc0, double& acc1, double& acc2, int dbg,
+                                  double pc0, double pc1) {
+  if (!PSL && nrows > 128) slice_rows<CNT, 2, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg, pc0, pc1);
+  else slice_rows<CNT, 1, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg, pc0, pc1);
 }
 
 template <bool PSL, int MODE, bool NT>
 __device__ inline void slice_dispatch(int cnt, const SDesc& d, int nrows, int rec, const double* __restrict__ pval,
                                       const double* __restrict__ x, double* __restrict__ y,
                                       const double* __restrict__ aux, const double* __restrict__ dx, int lane, double& acc0,
-                                      double& acc1, double& acc2, int dbg) {
+                                      double& acc1, double& acc2, int dbg, double pc0, double pc1) {
   switch (cnt) {   // wave-uniform
-    case 1: slice_nb<1, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg); break;
-    case 3: slice_nb<3, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg); break;
-    case 5: slice_nb<5, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg); break;
-    case 7: slice_nb<7, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg); break;
-    case 2: slice_nb<2, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg); break;
-    case 4: slice_nb<4, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg); break;
-    case 6: slice_nb<6, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg); break;
-    default: slice_nb<8, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg); break;
+    case 1: slice_nb<1, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg, pc0, pc1); break;
+    case 3: slice_nb<3, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg, pc0, pc1); break;
+    case 5: slice_nb<5, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg, pc0, pc1); break;
+    case 7: slice_nb<7, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg, pc0, pc1); break;
+    case 2: slice_nb<2, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg, pc0, pc1); break;
+    case 4: slice_nb<4, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg, pc0, pc1); break;
+    case 6: slice_nb<6, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg, pc0, pc1); break;
+    default: slice_nb<8, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg, pc0, pc1); break;
   }
 }
 
+
+// ---- marching units (M): the uniform interior of a 2-D / 3-D stencil ----------------------------------------------
+// What bounds the U path is bytes through the L1 / texture-address path: 7 loads of x per row (80 B per row with the dot
+// operands and the store) while only 8 B per row have to come from memory.  A U run of a 3-D problem is a piece of a grid
+// line, and the +-1 taps of a row are its neighbours in the SAME load, the +-plane taps the rows of the next / previous
+// line of the chain of runs that face each other across the slowest stencil direction (col - row offsets o[0] / o[cnt-1]
+// lead from a row to the row of the same lateral position one plane down / up).  So one wave MARCHES along such a chain:
+// it keeps the lines of planes k-1, k, k+1 in registers, lane l holding elements 2l, 2l+1 of a window of 128 consecutive
+// elements; per plane it loads ONE new line of the chain plus the two lateral neighbour lines (3-D only), computes the
+// 126 rows 1..126 of the window -- row 2l+1 from (2l, 2l+1, 2l+2), row 2l+2 from (2l+1, 2l+2, 2l+3), the elements of lane
+// l+1 arriving by a lane shift -- and stores them: 3 loads of x per 126 rows instead of 7 per 128 (1 instead of 5 in
+// 2-D), 24 instead of 56 bytes of x through L1 per row.  The products are accumulated in the rows' entry order as
+// everywhere else: y is bitwise the CSR kernels' y.
+//
+// One 256-byte record per UNIT (<= MARCH_K consecutive planes of one chain x one window), read with one vector load:
+//   dword 0            K | cnt << 8 | active lanes << 16   (planes in the unit, MARCH_K or MARCH_KS: shorter units are closed by empty
+//                                               planes; 7 = 3-D stencil, 5 = 2-D stencil)
+//   dword 1            first computed row (sort key only)
+//   dwords 2..15       the cnt values of the rows (all rows of a unit share them bitwise), in the entry order of the
+//                      assembled rows: +1, -1, [+lateral, -lateral,] +plane, -plane, diagonal (eval_row, pg_stencil.h)
+//   dword 16, 17       row index held by lane 0 (.x) in the line below the first / above the last plane of the unit
+//   dwords 18 + 4i..   plane i: row index held by lane 0 (.x); offset to the lower / upper lateral neighbour line
+//                      (col - row; 3-D only); lo | hi << 8 = window-relative range [lo, hi) of the rows computed here
+// build_march_units() forms chains and units on the host from the same row flags the slices are cut from.
+#ifndef PG_MARCH_K
+#define PG_MARCH_K 4
+#endif
+constexpr int MARCH_K = PG_MARCH_K, MARCH_KS = 2, MARCH_REC = 64, MARCH_W = 126;   // planes per unit: full / short units
+static_assert(MARCH_K > MARCH_KS && 18 + 4 * MARCH_K <= MARCH_REC, "unit record layout");
+
+__device__ inline double lane_up(double v) {   // the value lane l + 1 holds (lane 63: unspecified)
+  return __shfl_down(v, 1, 64);
+}
+
+struct MarchSide {   // per-plane operands besides the chain's own lines: lateral neighbour lines, dot operands
+  d2_t ym, yp, ax, ax2;
+};
+
+// rows 2l+1, 2l+2 of one plane from the lines in registers; returns lane l+1's xc.x (the next plane's xm_n)
+template <int CNT, int MODE>
+__device__ __forceinline__ double march_plane(const double (&c)[CNT], int rng, int l2, double* __restrict__ yrow, const d2_t& xm,
+                                              double xm_n, const d2_t& xc, const d2_t& xp, const MarchSide& sd, double pc0,
+                                              double pc1, double& acc0, double& acc1, double& acc2, int dbg) {
+  constexpr bool DOTS = MODE >= 1 && MODE <= 3;
+  constexpr bool Y = CNT == 7;
+  const double xc_nx = lane_up(xc.x), xc_ny = lane_up(xc.y), xp_n = lane_up(xp.x);
+  // entry order of the assembled rows (eval_row, pg_stencil.h): +1, -1, [+lateral, -lateral,] +plane, -plane, diagonal
+  double s1 = 0.0, s2 = 0.0;
+  int j = 0;
+  s1 += c[j] * xc_nx; s2 += c[j] * xc_ny; ++j;
+  s1 += c[j] * xc.x;  s2 += c[j] * xc.y;  ++j;
+  if (Y) {
+    s1 += c[j] * sd.yp.x; s2 += c[j] * sd.yp.y; ++j;
+    s1 += c[j] * sd.ym.x; s2 += c[j] * sd.ym.y; ++j;
+  }
+  s1 += c[j] * xp.y;  s2 += c[j] * xp_n;  ++j;
+  s1 += c[j] * xm.y;  s2 += c[j] * xm_n;  ++j;
+  s1 += c[j] * xc.y;  s2 += c[j] * xc_nx;
+  if (MODE == 4) {   // the row's own x: elements 2l+1, 2l+2 of the centre line
+    s1 = mode4_out(xc.y, s1, pc0, pc1);
+    s2 = mode4_out(xc_nx, s2, pc0, pc1);
+  }
+  const int lo = rng & 255, hi = rng >> 8;
+  const bool nost = (dbg & 32) && s1 != 1.2345e-300;   // diagnostics: no stores
+  const bool allst = (dbg & 512) != 0;                  // diagnostics: every lane stores its pair (whole windows)
+  const bool v1 = ((l2 + 1 >= lo && l2 + 1 < hi) || allst) && !nost, v2 = ((l2 + 2 >= lo && l2 + 2 < hi) || allst) && !nost;
+  if (v1 && v2) {
+    d2u_t out;
+    out.x = s1; out.y = s2;
+    if (dbg & 256) __builtin_nontemporal_store(out, reinterpret_cast<d2u_t*>(yrow));   // diagnostics: stream hint
+    else *reinterpret_cast<d2u_t*>(yrow) = out;
+  } else if (v1) {
+    yrow[0] = s1;
+  } else if (v2) {
+    yrow[1] = s2;
+  }
+  if (DOTS) {
+    const double w1 = v1 ? s1 : 0.0, w2 = v2 ? s2 : 0.0;
+    acc0 += (v1 ? sd.ax.x : 0.0) * w1 + (v2 ? sd.ax.y : 0.0) * w2;
+    if (MODE >= 2) acc1 += w1 * w1 + w2 * w2;
+    if (MODE == 3) acc2 += (v1 ? sd.ax2.x : 0.0) * w1 + (v2 ? sd.ax2.y : 0.0) * w2;
+  }
+  return xc_nx;
+}
+
+// One unit of exactly KK planes (the builder closes shorter ones with empty planes), fully unrolled: EVERY load of the
+// unit -- KK + 2 lines of the chain, 2 KK lateral lines, the dot operands -- is independent of the arithmetic, so the
+// compiler issues them up front (as far as registers allow) and the wave pays ONE memory round trip per unit.  A loop
+// over the planes with prefetch registers did not get there: the registers carried around the back edge are copied,
+// and a copy waits for the load that fills it (2.2 us per plane, measured).
+template <int CNT, int MODE, int KK>
+__device__ __forceinline__ void march_unit(int rec, int lane, const double* __restrict__ x, double* __restrict__ y,
+                                  const double* __restrict__ aux, const double* __restrict__ dx, double pc0, double pc1,
+                                  double& acc0, double& acc1, double& acc2, int dbg) {
+  constexpr bool Y = CNT == 7;
+  const int amask = (dbg & 128) ? ~1 : ~0;          // diagnostics: every access 16-byte aligned (wrong results)
+  const int one = (dbg & 128) ? 0 : 1;
+  const bool nolat = (dbg & 64) != 0;               // diagnostics: no lateral lines
+  double c[CNT];
+#pragma unroll
+  for (int j = 0; j < CNT; ++j) c[j] = __hiloint2double(rlane(rec, 3 + 2 * j), rlane(rec, 2 + 2 * j));
+  const int l2 = 2 * lane;
+  int rb[KK];
+  d2_t ln[KK + 2];          // lines -1 .. KK of the chain
+  MarchSide sd[KK];
+  // lanes beyond the widest plane of the unit load nothing (a window at the end of a chord is mostly empty: what a load
+  // costs the CU's memory pipe goes with its active lanes); they run the arithmetic on zeros and store nothing
+  const bool act = lane < (rlane(rec, 0) >> 16);
+  d2_t zero;
+  zero.x = zero.y = 0.0;
+#pragma unroll
+  for (int q = 0; q < KK + 2; ++q) ln[q] = zero;
+#pragma unroll
+  for (int q = 0; q < KK; ++q) {
+    rb[q] = rlane(rec, 18 + 4 * q) & amask;
+    sd[q].ym = sd[q].yp = sd[q].ax = sd[q].ax2 = zero;
+  }
+  if (act) {
+    ln[0] = load_pair<false>(x + (rlane(rec, 16) & amask) + l2);
+#pragma unroll
+    for (int q = 0; q < KK; ++q) ln[q + 1] = load_pair<false>(x + rb[q] + l2);
+    ln[KK + 1] = load_pair<false>(x + (rlane(rec, 17) & amask) + l2);
+#pragma unroll
+    for (int q = 0; q < KK; ++q) {
+      if (Y && !nolat) {
+        sd[q].ym = load_pair<false>(x + rb[q] + (rlane(rec, 19 + 4 * q) & amask) + l2 + one);
+        sd[q].yp = load_pair<false>(x + rb[q] + (rlane(rec, 20 + 4 * q) & amask) + l2 + one);
+      }
+      if (MODE == 1) sd[q].ax = load_pair<false>(aux + rb[q] + l2 + one);
+      if (MODE == 2 || MODE == 3) sd[q].ax = load_pair<false>(dx + rb[q] + l2 + one);
+      if (MODE == 3) sd[q].ax2 = load_pair<false>(aux + rb[q] + l2 + one);
+    }
+  }
+  double xm_n = lane_up(ln[0].x);
+#pragma unroll
+  for (int q = 0; q < KK; ++q)
+    xm_n = march_plane<CNT, MODE>(c, rlane(rec, 21 + 4 * q), l2, y + rb[q] + l2 + one, ln[q], xm_n, ln[q + 1], ln[q + 2], sd[q], pc0,
+                                  pc1, acc0, acc1, acc2, dbg);
+}
+
+template <int CNT, int MODE>
+__device__ __forceinline__ void march_dispatch(int rec, int lane, const double* __restrict__ x, double* __restrict__ y,
+                                      const double* __restrict__ aux, const double* __restrict__ dx, double pc0, double pc1,
+                                      double& acc0, double& acc1, double& acc2, int dbg) {
+  if ((rlane(rec, 0) & 255) == MARCH_K) march_unit<CNT, MODE, MARCH_K>(rec, lane, x, y, aux, dx, pc0, pc1, acc0, acc1, acc2, dbg);
+  else march_unit<CNT, MODE, MARCH_KS>(rec, lane, x, y, aux, dx, pc0, pc1, acc0, acc1, acc2, dbg);
+}
+
 template <int MODE, bool NT>
-__global__ __launch_bounds__(BLOCK) void k_spmv_s(i64 nslices, const int* __restrict__ srec,
+__global__ __launch_bounds__(BLOCK, 4) void k_spmv_s(i64 nslices, const int* __restrict__ srec,
                                                   const double* __restrict__ pval, const int* __restrict__ g_rowid,
                                                   const int* __restrict__ g_rowptr, const int* __restrict__ g_col,
                                                   const double* __restrict__ g_val, const double* __restrict__ x,
                                                   double* __restrict__ y, const double* __restrict__ aux,
                                                   double* __restrict__ partials, const double* __restrict__ sc, int xcd,
-                                                  FinArgs fin, int pstride, int accum) {
+                                                  FinArgs fin, int pstride, int accum, const int* __restrict__ mrec,
+                                                  i64 nunits) {
   __shared__ __attribute__((aligned(16))) double s_val[BLOCK / 64][512];
   __shared__ __attribute__((aligned(16))) double s_x[BLOCK / 64][512];   // G chunks: x[col] of every entry of the chunk
   __shared__ double s_red[BLOCK / 64];
@@ -404,9 +559,41 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_s(i64 nslices, const int* __rest
   d2_t* sx2 = reinterpret_cast<d2_t*>(sx);
   double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
   // diagnostics (PG_SPMV_XCD bits 8..; results are wrong with any of them): 1 skip G chunks, 2 skip U/P slices,
-  // 4 every x load hits one line, 8 no y stores in U/P slices
+  // 4 every x load hits one line, 8 no y stores in U/P slices, 16 skip the marching units, 32 no y stores in the units,
+  // 64 no lateral lines in the units, 128 every access of the units 16-byte aligned, 256 non-temporal y stores in the
+  // units, 512 the units store whole windows
   const int dbg = xcd >> 8;
   xcd &= 255;
+  // ---- marching units first (the bulk of the rows), then the slices.  (Alternating units and slices in every wave, so
+  // that the latency-bound irregular chunks of some waves overlap the streaming of others, measured no faster, and one
+  // merged loop costs registers: the live ranges of both bodies add up -- 144 VGPRs, a wave per SIMD less.)
+  xcd &= 1;
+  if (nunits > 0) {
+    i64 ucur, ustride, uhi;
+    if (xcd && gridDim.x >= 8) {
+      const int xid = blockIdx.x & 7;
+      const i64 nbx = ((i64)gridDim.x + 7 - xid) >> 3;
+      uhi = nunits * (xid + 1) / 8;
+      ucur = nunits * xid / 8 + (i64)(blockIdx.x >> 3) * (BLOCK / 64) + wave;
+      ustride = nbx * (BLOCK / 64);
+    } else {
+      ucur = (i64)blockIdx.x * (BLOCK / 64) + wave;
+      ustride = (i64)gridDim.x * (BLOCK / 64);
+      uhi = nunits;
+    }
+    int urec = ucur < uhi ? mrec[MARCH_REC * ucur + lane] : 0;
+    for (; ucur < uhi; ucur += ustride) {
+      const i64 un = ucur + ustride;
+      const int urec_n = mrec[MARCH_REC * (un < uhi ? un : ucur) + lane];   // the next unit's record is in flight meanwhile
+      if (!(dbg & 16)) {
+        if (((rlane(urec, 0) >> 8) & 255) == 7)
+          march_dispatch<7, MODE>(urec, lane, x, y, aux, dx, fin.pc0, fin.pc1, acc0, acc1, acc2, dbg);
+        else
+          march_dispatch<5, MODE>(urec, lane, x, y, aux, dx, fin.pc0, fin.pc1, acc0, acc1, acc2, dbg);
+      }
+      urec = urec_n;
+    }
+  }
   i64 first, wstride, hi;
   if (xcd && gridDim.x >= 8) {
     const int xid = blockIdx.x & 7;
@@ -435,9 +622,9 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_s(i64 nslices, const int* __rest
     const bool skip = ((dbg & 1) && type == SL_G) || ((dbg & 2) && type != SL_G);
     if (skip) {
     } else if (type == SL_U) {
-      slice_dispatch<false, MODE, NT>(cnt, d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg);
+      slice_dispatch<false, MODE, NT>(cnt, d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg, fin.pc0, fin.pc1);
     } else if (type == SL_P) {
-      slice_dispatch<true, MODE, NT>(cnt, d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg);
+      slice_dispatch<true, MODE, NT>(cnt, d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg, fin.pc0, fin.pc1);
     } else {
       // packed irregular rows: same data flow as k_spmv_cw on the compact CSR, plus the row-id indirection
       Desc dd;
@@ -492,7 +679,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_s(i64 nslices, const int* __rest
       }
       __builtin_amdgcn_wave_barrier();
       if (live) {
-        if (MODE == 4) sum = 2.0 * xr - sum;
+        if (MODE == 4) sum = mode4_out(xr, sum, fin.pc0, fin.pc1);
         y[rid] = sum;
         if (MODE == 1) acc0 += auxr * sum;
         if (DOTS && MODE >= 2) {
@@ -613,16 +800,19 @@ namespace {
 // slices [s0, s0 + ns) of the slice image (the whole image: 0, A.nslices); `grid` blocks, partial slots `pstride` apart
 template <int MODE>
 bool launch_slices(int v, const CsrMatrix& A, i64 s0, i64 ns, const double* x, double* y, const double* aux, double* partials,
-                   const double* sc, int grid, int pstride, int accum, hipStream_t st, const FinArgs* fin) {
+                   const double* sc, int grid, int pstride, int accum, hipStream_t st, const FinArgs* fin, bool units = true) {
   FinArgs fa{nullptr, nullptr, PH_NONE, 0, 0, nullptr};
   if (fin && MODE >= 1) fa = *fin;
   const int* rec = A.srec.p + SL_REC * s0;
+  const i64 nu = units ? A.nunits : 0;   // the marching units ride with the launch that covers the interior slices
   if (v & 4)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_s<MODE, true>), dim3(grid), dim3(BLOCK), 0, st, ns, rec, A.pval.p,
-                       A.g_rowid.p, A.g_rowptr.p, A.g_col.p, A.g_val.p, x, y, aux, partials, sc, xcd_map(), fa, pstride, accum);
+                       A.g_rowid.p, A.g_rowptr.p, A.g_col.p, A.g_val.p, x, y, aux, partials, sc, xcd_map(), fa, pstride, accum,
+                       (const int*)A.mrec.p, nu);
   else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_s<MODE, false>), dim3(grid), dim3(BLOCK), 0, st, ns, rec, A.pval.p,
-                       A.g_rowid.p, A.g_rowptr.p, A.g_col.p, A.g_val.p, x, y, aux, partials, sc, xcd_map(), fa, pstride, accum);
+                       A.g_rowid.p, A.g_rowptr.p, A.g_col.p, A.g_val.p, x, y, aux, partials, sc, xcd_map(), fa, pstride, accum,
+                       (const int*)A.mrec.p, nu);
   return fa.ticket != nullptr;
 }
 
@@ -654,6 +844,220 @@ struct Slice {
   int bnd;   // 1: some row references a ghost column (the slice waits for the halo exchange)
 };
 
+struct MRun {
+  int r0, len, cnt;   // rows [r0, r0 + len) with one stencil (offsets and values), cnt = 5 / 7 entries
+};
+
+constexpr int RUN_INFO = 24;   // dwords per run: 8 offsets, 8 values (lo, hi)
+
+// col - row offsets and values of the first row of every run
+__global__ void k_run_info(i64 nruns, const int* __restrict__ run_r0, const int* __restrict__ rowptr,
+                           const int* __restrict__ col, const double* __restrict__ val, int* __restrict__ out) {
+  for (i64 q = blockIdx.x * (i64)blockDim.x + threadIdx.x; q < nruns; q += (i64)gridDim.x * blockDim.x) {
+    const int r = run_r0[q], a = rowptr[r], len = rowptr[r + 1] - a;
+    for (int k = 0; k < 8; ++k) {
+      out[RUN_INFO * q + k] = k < len ? col[a + k] - r : 0;
+      const double v = k < len ? val[a + k] : 0.0;
+      out[RUN_INFO * q + 8 + 2 * k] = __double2loint(v);
+      out[RUN_INFO * q + 9 + 2 * k] = __double2hiint(v);
+    }
+  }
+}
+
+// values (dwords 2..15) of every unit record from its first computed row (dword 1)
+__global__ void k_fill_units(i64 nunits, int* __restrict__ mrec, const int* __restrict__ rowptr,
+                             const double* __restrict__ val) {
+  for (i64 q = blockIdx.x * (i64)blockDim.x + threadIdx.x; q < nunits; q += (i64)gridDim.x * blockDim.x) {
+    int* rec = mrec + MARCH_REC * q;
+    const int cnt = (rec[0] >> 8) & 255, a = rowptr[rec[1]];
+    for (int k = 0; k < cnt; ++k) {
+      rec[2 + 2 * k] = __double2loint(val[a + k]);
+      rec[3 + 2 * k] = __double2hiint(val[a + k]);
+    }
+  }
+}
+
+// do the rows of every unit still share one stencil?  (rows after the first of a plane repeat their predecessor --
+// row flags -- and the first row of every plane carries the values of the unit's first row)
+__global__ void k_units_invalid(i64 nunits, const int* __restrict__ mrec, const int* __restrict__ rowptr,
+                                const double* __restrict__ val, const unsigned char* __restrict__ flags,
+                                unsigned long long* __restrict__ out) {
+  unsigned long long c = 0;
+  for (i64 q = blockIdx.x; q < nunits; q += gridDim.x) {
+    const int* rec = mrec + MARCH_REC * q;
+    const int K = rec[0] & 255, cnt = (rec[0] >> 8) & 255, a0 = rowptr[rec[1]];
+    for (int i = 0; i < K; ++i) {
+      const int rb = rec[18 + 4 * i], lo = rec[21 + 4 * i] & 255, hi = rec[21 + 4 * i] >> 8;
+      for (int l = lo + threadIdx.x; l < hi; l += blockDim.x) {
+        const int r = rb + l;
+        if (l > lo) {
+          c += (flags[r] & 3) != 3 ? 1 : 0;
+        } else {
+          const int a = rowptr[r];
+          bool same = rowptr[r + 1] - a == cnt;
+          for (int k = 0; same && k < cnt; ++k)
+            same = __double_as_longlong(val[a + k]) == __double_as_longlong(val[a0 + k]);
+          c += same ? 0 : 1;
+        }
+      }
+    }
+  }
+  if (c) atomicAdd(out, c);
+}
+
+void emit_u_rows(std::vector<Slice>& up, i64 a, i64 b, int cnt) {
+  for (i64 r = a; r < b; r += SL_MAXROWS_U) {
+    const int rows = (int)std::min<i64>(SL_MAXROWS_U, b - r);
+    up.push_back(Slice{(int)r, rows | (SL_U << 8) | (cnt << 16), 0, 0, (int)r, 0});
+  }
+}
+
+// Chains of runs that face each other across the slowest stencil direction, cut into windows of MARCH_W computed rows
+// and units of <= MARCH_K planes (see "marching units").  mrec: the unit records, sorted by first row; rows that cannot
+// march (no -1 / 0 / +1 middle, windows that would read outside the vector) are appended to `up` as U slices.
+void build_march_units(CsrMatrix& A, const std::vector<MRun>& runs, std::vector<int>& mrec, std::vector<Slice>& up) {
+  A.rows_m = 0;
+  const i64 nr = (i64)runs.size();
+  if (nr == 0) return;
+  hipStream_t st = ctx().stream;
+  std::vector<int> info((size_t)RUN_INFO * nr);
+  {
+    std::vector<int> r0s(nr);
+    for (i64 i = 0; i < nr; ++i) r0s[i] = runs[i].r0;
+    DevBuf<int> d_r0(nr), d_info(RUN_INFO * nr);
+    d_r0.upload(r0s.data(), nr);
+    hipLaunchKernelGGL(k_run_info, dim3(grid_for(nr, 256)), dim3(256), 0, st, nr, d_r0.p, A.rowptr.p, A.col.p, A.val.p, d_info.p);
+    PG_HIP(hipGetLastError());
+    d_info.download(info.data(), RUN_INFO * nr);
+  }
+  auto off = [&](i64 i, int k) { return info[RUN_INFO * i + k]; };
+  auto same_values = [&](i64 i, i64 j, int cnt) {
+    for (int k = 0; k < 2 * cnt; ++k)
+      if (info[RUN_INFO * i + 8 + k] != info[RUN_INFO * j + 8 + k]) return false;
+    return true;
+  };
+  // entries of a marching row, in the order eval_row emits them: +1, -1, [+Y, -Y,] +Z, -Z, 0 with 1 < Y < Z
+  std::vector<char> ok(nr, 0);
+  for (i64 i = 0; i < nr; ++i) {
+    const int cnt = runs[i].cnt;
+    bool good = off(i, 0) == 1 && off(i, 1) == -1 && off(i, cnt - 1) == 0;
+    const int up_e = cnt - 3, dn_e = cnt - 2;
+    good = good && off(i, up_e) > 1 && off(i, dn_e) < -1;
+    if (cnt == 7) good = good && off(i, 2) > 1 && off(i, 2) < off(i, up_e) && off(i, 3) < -1 && off(i, 3) > off(i, dn_e);
+    ok[i] = good;
+    if (!ok[i]) emit_u_rows(up, runs[i].r0, (i64)runs[i].r0 + runs[i].len, cnt);
+  }
+  // successor of run i: the run that holds most of the rows r + o[cnt - 1], r in run i, if it mirrors the offset and
+  // carries the same values; every run has at most one predecessor
+  std::vector<int> succ(nr, -1), pred(nr, -1);
+  for (i64 i = 0; i < nr; ++i) {
+    if (!ok[i]) continue;
+    const int cnt = runs[i].cnt, up_off = off(i, cnt - 3);
+    const i64 lo = (i64)runs[i].r0 + up_off, hi = lo + runs[i].len;
+    i64 j = std::upper_bound(runs.begin(), runs.end(), lo, [](i64 v, const MRun& r) { return v < (i64)r.r0; }) - runs.begin();
+    if (j > 0) --j;
+    i64 best = -1, best_ov = 0;
+    for (; j < nr && (i64)runs[j].r0 < hi; ++j) {
+      const i64 a = runs[j].r0, b = a + runs[j].len;
+      if (b <= lo || j == i || !ok[j] || pred[j] >= 0 || runs[j].cnt != cnt || off(j, cnt - 2) != -up_off || !same_values(i, j, cnt)) continue;
+      const i64 ov = std::min(hi, b) - std::max(lo, a);
+      if (ov > best_ov) { best_ov = ov; best = j; }
+    }
+    if (best >= 0) { succ[i] = (int)best; pred[best] = (int)i; }
+  }
+  struct Unit { int key; std::vector<int> rec; };
+  std::vector<Unit> units;
+  const i64 n = A.n;
+  static const int kmax = getenv("PG_SPMV_MARCH_K") ? std::max(1, std::min(MARCH_K, atoi(getenv("PG_SPMV_MARCH_K")))) : MARCH_K;
+  auto safe = [&](i64 idx0) { return idx0 >= 0 && idx0 + 130 <= n + 8; };
+  std::vector<i64> chain, B;
+  for (i64 h = 0; h < nr; ++h) {
+    if (!ok[h] || pred[h] >= 0) continue;
+    chain.clear(); B.clear();
+    const int cnt = runs[h].cnt;
+    const bool Y = cnt == 7;
+    i64 base = runs[h].r0;
+    const int up_e = cnt - 3, dn_e = cnt - 2;   // entries of the +plane / -plane taps
+    for (i64 i = h; i >= 0; i = succ[i]) {
+      chain.push_back(i);
+      B.push_back(base);
+      base += off(i, up_e);
+    }
+    const i64 L = (i64)chain.size();
+    i64 cmin = 0, cmax = 0;
+    for (i64 k = 0; k < L; ++k) {
+      const i64 a = runs[chain[k]].r0 - B[k], b = a + runs[chain[k]].len;
+      cmin = k == 0 ? a : std::min(cmin, a);
+      cmax = k == 0 ? b : std::max(cmax, b);
+    }
+    for (i64 W = cmin - 1; W + 1 < cmax; W += MARCH_W) {
+      auto range = [&](i64 k, i64& lo, i64& hi) {
+        const i64 a = runs[chain[k]].r0 - B[k], b = a + runs[chain[k]].len;
+        lo = std::max(a, W + 1);
+        hi = std::min(b, W + 1 + MARCH_W);
+        return lo < hi;
+      };
+      i64 k = 0;
+      while (k < L) {
+        i64 lo, hi;
+        if (!range(k, lo, hi)) { ++k; continue; }
+        i64 k1 = k;
+        while (k1 < L && k1 - k < kmax && range(k1, lo, hi)) ++k1;
+        const int K = (int)(k1 - k);
+        bool fits = safe(B[k] + off(chain[k], dn_e) + W) && safe(B[k1 - 1] + off(chain[k1 - 1], up_e) + W);
+        for (i64 q = k; q < k1 && fits; ++q) {
+          fits = safe(B[q] + W);
+          if (Y) fits = fits && safe(B[q] + W + off(chain[q], 2)) && safe(B[q] + W + off(chain[q], 3));
+        }
+        if (!fits) {
+          for (i64 q = k; q < k1; ++q) {
+            range(q, lo, hi);
+            emit_u_rows(up, B[q] + lo, B[q] + hi, cnt);
+          }
+          k = k1;
+          continue;
+        }
+        Unit u;
+        u.rec.assign(MARCH_REC, 0);
+        range(k, lo, hi);
+        u.key = (int)(B[k] + lo);
+        const int Kp = K <= MARCH_KS ? MARCH_KS : MARCH_K;   // the kernel's two unit sizes: shorter units end with empty planes
+        u.rec[0] = Kp | (cnt << 8);   // | active lanes << 16, below
+        u.rec[1] = u.key;
+        for (int q = 0; q < 2 * cnt; ++q) u.rec[2 + q] = info[RUN_INFO * chain[k] + 8 + q];
+        u.rec[16] = (int)(B[k] + off(chain[k], dn_e) + W);
+        u.rec[17] = (int)(B[k1 - 1] + off(chain[k1 - 1], up_e) + W);
+        int hi_max = 0;
+        for (int i = 0; i < K; ++i) {
+          const i64 q = k + i;
+          range(q, lo, hi);
+          hi_max = std::max(hi_max, (int)(hi - W));
+          u.rec[18 + 4 * i] = (int)(B[q] + W);
+          u.rec[19 + 4 * i] = Y ? off(chain[q], 3) : 0;   // -lateral
+          u.rec[20 + 4 * i] = Y ? off(chain[q], 2) : 0;   // +lateral
+          u.rec[21 + 4 * i] = (int)(lo - W) | ((int)(hi - W) << 8);
+          A.rows_m += hi - lo;
+        }
+        // rows < hi_max need elements <= hi_max of the lines: lanes 0 .. hi_max / 2
+        u.rec[0] |= std::min(64, hi_max / 2 + 1) << 16;
+        for (int i = K; i < Kp; ++i) {
+          // closing planes compute nothing (lo = hi); their line is the one ABOVE the last real plane -- the line that
+          // plane's +plane tap reads, and a valid address for every load of the closing plane
+          u.rec[18 + 4 * i] = u.rec[17];
+          u.rec[19 + 4 * i] = 0;
+          u.rec[20 + 4 * i] = 0;
+          u.rec[21 + 4 * i] = 1 | (1 << 8);
+        }
+        units.push_back(std::move(u));
+        k = k1;
+      }
+    }
+  }
+  std::sort(units.begin(), units.end(), [](const Unit& a, const Unit& b) { return a.key < b.key; });
+  mrec.reserve(units.size() * MARCH_REC);
+  for (auto& u : units) mrec.insert(mrec.end(), u.rec.begin(), u.rec.end());
+}
+
 // stencil-slice image of A (see "stencil slices" above); rp = host copy of A.rowptr
 void build_slices(CsrMatrix& A, const int* rp) {
   hipStream_t st = ctx().stream;
@@ -672,10 +1076,22 @@ void build_slices(CsrMatrix& A, const int* rp) {
   struct Part {
     std::vector<Slice> up;      // U and P slices
     std::vector<int> grows;     // irregular rows, ascending
+    std::vector<MRun> runs;     // U runs of 2-D / 3-D stencil rows: candidates for marching units
     i64 rows_u = 0, rows_p = 0, nnz_p = 0;
   };
+  static const bool march_on = getenv("PG_SPMV_MARCH") ? atoi(getenv("PG_SPMV_MARCH")) != 0 : true;
   auto classify = [&](i64 lo, i64 hi, Part& out) {
     auto emit = [&](int type, i64 a, i64 b, int cnt) {
+      if (march_on && type == SL_U && (cnt == 5 || cnt == 7)) {
+        // a piece of a grid line with one stencil: kept whole, turned into marching units (or U slices) below
+        bool ghost = false;
+        for (i64 q = a; q < b; ++q) ghost = ghost || ((fl[q] >> 2) & 1);
+        if (!ghost) {
+          out.runs.push_back(MRun{(int)a, (int)(b - a), cnt});
+          out.rows_u += b - a;
+          return;
+        }
+      }
       const i64 maxrows = type == SL_U ? SL_MAXROWS_U : SL_MAXROWS_P;
       for (i64 r = a; r < b; r += maxrows) {
         const int rows = (int)std::min<i64>(maxrows, b - r);
@@ -735,19 +1151,29 @@ void build_slices(CsrMatrix& A, const int* rp) {
   }
   std::vector<Slice> up;
   std::vector<int> grows;
+  std::vector<MRun> runs;
   A.rows_u = A.rows_p = A.rows_g = A.nnz_p = A.nnz_g = 0;
   {
-    size_t nu = 0, ngr = 0;
-    for (auto& pt : parts) { nu += pt.up.size(); ngr += pt.grows.size(); }
+    size_t nu = 0, ngr = 0, nr = 0;
+    for (auto& pt : parts) { nu += pt.up.size(); ngr += pt.grows.size(); nr += pt.runs.size(); }
     up.reserve(nu);
     grows.reserve(ngr);
+    runs.reserve(nr);
     for (auto& pt : parts) {
       up.insert(up.end(), pt.up.begin(), pt.up.end());
       grows.insert(grows.end(), pt.grows.begin(), pt.grows.end());
+      runs.insert(runs.end(), pt.runs.begin(), pt.runs.end());
       A.rows_u += pt.rows_u; A.rows_p += pt.rows_p; A.nnz_p += pt.nnz_p;
     }
   }
   laps.lap("    slices: host classification");
+  // marching units out of the stencil runs; what cannot march comes back as U slices
+  std::vector<int> mrec;
+  build_march_units(A, runs, mrec, up);
+  A.nunits = (i64)mrec.size() / MARCH_REC;
+  A.mrec.alloc(std::max<i64>((i64)mrec.size(), 1));
+  if (!mrec.empty()) A.mrec.upload(mrec.data(), (i64)mrec.size());
+  laps.lap("    slices: marching units");
   // P value bases
   {
     i64 pbase = 0;
@@ -817,10 +1243,10 @@ void build_slices(CsrMatrix& A, const int* rp) {
   }
   PG_HIP(hipStreamSynchronize(st));
   laps.lap("    slices: packing + records");
-  A.spmv_bytes = 4 * SL_REC * A.nslices + 8 * A.nnz_p + 12 * A.nnz_g + 8 * ng + 16 * n;
+  A.spmv_bytes = 4 * SL_REC * A.nslices + 4 * MARCH_REC * A.nunits + 8 * A.nnz_p + 12 * A.nnz_g + 8 * ng + 16 * n;
   if (getenv("PG_DEBUG"))
-    fprintf(stderr, "[pg_spmv] slices %lld (%lld wait for the halo): rows U %lld P %lld G %lld of %lld; nnz P %lld G %lld of %lld; bytes/launch %lld (CSR %lld)\n",
-            (long long)A.nslices, (long long)(A.nslices - A.nslices_int), (long long)A.rows_u, (long long)A.rows_p, (long long)A.rows_g,
+    fprintf(stderr, "[pg_spmv] slices %lld (%lld wait for the halo), marching units %lld (%lld rows): rows U %lld P %lld G %lld of %lld; nnz P %lld G %lld of %lld; bytes/launch %lld (CSR %lld)\n",
+            (long long)A.nslices, (long long)(A.nslices - A.nslices_int), (long long)A.nunits, (long long)A.rows_m, (long long)A.rows_u, (long long)A.rows_p, (long long)A.rows_g,
             (long long)n, (long long)A.nnz_p, (long long)A.nnz_g, (long long)A.nnz, (long long)A.spmv_bytes,
             (long long)(12 * A.nnz + 20 * n));
 }
@@ -897,6 +1323,9 @@ bool build_slices_like(const CsrMatrix& T, CsrMatrix& A) {
   if (T.nslices > 0)
     hipLaunchKernelGGL(k_slices_invalid, dim3((unsigned)std::min<i64>(T.nslices, 16384)), dim3(64), 0, st, T.nslices, T.srec.p,
                        A.rowflags.p, diff.p);
+  if (T.nunits > 0)
+    hipLaunchKernelGGL(k_units_invalid, dim3((unsigned)std::min<i64>(T.nunits, 16384)), dim3(64), 0, st, T.nunits, T.mrec.p,
+                       A.rowptr.p, A.val.p, A.rowflags.p, diff.p);
   PG_HIP(hipGetLastError());
   unsigned long long h = 0;
   diff.download(&h, 1);
@@ -908,6 +1337,10 @@ bool build_slices_like(const CsrMatrix& T, CsrMatrix& A) {
   A.nslices_int = T.nslices_int;
   A.rows_u = T.rows_u; A.rows_p = T.rows_p; A.rows_g = T.rows_g; A.nnz_p = T.nnz_p; A.nnz_g = T.nnz_g;
   A.spmv_bytes = T.spmv_bytes;
+  A.nunits = T.nunits; A.rows_m = T.rows_m;
+  clone_buf(A.mrec, T.mrec, st);
+  if (A.nunits > 0)
+    hipLaunchKernelGGL(k_fill_units, dim3(grid_for(A.nunits, 256)), dim3(256), 0, st, A.nunits, A.mrec.p, A.rowptr.p, A.val.p);
   clone_buf(A.srec, T.srec, st);
   clone_buf(A.g_rowid, T.g_rowid, st);
   clone_buf(A.g_rowptr, T.g_rowptr, st);
@@ -965,7 +1398,7 @@ bool spmv_with_halo(int mode, const CsrMatrix& A, const Numbering& nb, const Sla
   const int v = variant();
   static const bool overlap = getenv("PG_HALO_OVERLAP") ? atoi(getenv("PG_HALO_OVERLAP")) != 0 : true;
   const i64 ni = A.nslices_int, nbnd = A.nslices - A.nslices_int;
-  if (!(v & 64) || !overlap || ni == 0 || nbnd == 0) {
+  if (!(v & 64) || !overlap || (ni == 0 && A.nunits == 0) || nbnd == 0) {
     halo_exchange(nb, slab, x, st);
     return launch_spmv(mode, A, x, y, aux, partials, sc, grid, st, fin);
   }
@@ -974,10 +1407,11 @@ bool spmv_with_halo(int mode, const CsrMatrix& A, const Numbering& nb, const Sla
   halo_begin(nb, slab, x, st);                      // x's owned part is final on `st`; ghosts arrive on the comm stream
   bool folded;
   FinArgs fin_nofold{nullptr, nullptr, PH_NONE, 0, 0, fin ? fin->dotx : nullptr};   // first launch: dot operand, no scalar phase
+  if (fin) { fin_nofold.pc0 = fin->pc0; fin_nofold.pc1 = fin->pc1; }
 #define PG_SPLIT(MODE_)                                                                                              \
   launch_slices<MODE_>(v, A, 0, ni, x, y, aux, partials, sc, grid, grid, 0, st, fin ? &fin_nofold : nullptr);      \
   halo_end(st);                                                                                                      \
-  folded = launch_slices<MODE_>(v, A, ni, nbnd, x, y, aux, partials, sc, grid2, grid, 1, st, fin)
+  folded = launch_slices<MODE_>(v, A, ni, nbnd, x, y, aux, partials, sc, grid2, grid, 1, st, fin, false)
   if (mode == 0) { PG_SPLIT(0); }
   else if (mode == 1) { PG_SPLIT(1); }
   else if (mode == 2) { PG_SPLIT(2); }

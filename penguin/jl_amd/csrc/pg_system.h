@@ -58,6 +58,10 @@ struct CsrMatrix {
   DevBuf<double> pval;
   DevBuf<int> g_rowid, g_rowptr, g_col;
   DevBuf<double> g_val;
+  // marching units (pg_spmv.hip "marching units"): one 256-byte record per <= 11 planes x 126 rows of uniform 2-D / 3-D
+  // stencil rows; these rows are in no slice
+  DevBuf<int> mrec;
+  i64 nunits = 0, rows_m = 0;
   i64 nslices = 0;
   i64 nslices_int = 0;   // slices [0, nslices_int) reference no ghost column (computable before the halo of x has landed)
   DevBuf<unsigned char> rowflags;   // k_row_same flags the slices were cut from (structure reuse, assemble_csr_like)

@@ -603,10 +603,34 @@ def _spmv_compare(pj, s, which, va, vb):
     return d.value, m.value
 
 
-@pytest.mark.parametrize("case", ["mono3d_dyadic", "mono3d_nondyadic", "mono3d_generic", "mono2d_robin", "diph2d"])
+@pytest.mark.parametrize("case", ["mono3d_dyadic", "mono3d_nondyadic", "mono3d_generic", "mono2d_robin", "diph2d",
+                                  "mono3d_march", "mono3d_march_offcentre", "mono2d_march", "mono3d_march_two_balls"])
 def test_spmv_stencil_slices_bitwise_equal_csr_kernels(pj, case):
-    """The stencil-sliced SpMV (U / P slices + packed irregular rows) gives bitwise the y of the CSR kernels."""
-    if case == "mono3d_dyadic":
+    """The stencil-sliced SpMV (marching units, U / P slices + packed irregular rows) gives bitwise the y of the CSR kernels."""
+    if case == "mono3d_march":
+        # chords of up to 150 cells: chains of runs across the planes, two windows per line in the middle of the ball
+        mesh = pj.Mesh((176, 160, 168), (4.0, 4.0, 4.0))
+        cap = pj.Capacity(pj.Sphere((2.01, 2.01, 2.01), 1.7), mesh)
+        bcb = pj.BorderConditions({k: pj.Dirichlet(1.0) for k in ("left", "right", "top", "bottom")})
+        s = pj.DiffusionUnsteadyMono(pj.Phase(cap, pj.DiffusionOps(cap), 0.0, 1.0), bcb, pj.Dirichlet(1.0), 3e-4, None, "CN")
+    elif case == "mono3d_march_offcentre":
+        # the ball leaves the box on three sides: chains start and end at border rows, fluid touches the borders
+        mesh = pj.Mesh((96, 80, 72), (2.0, 1.7, 1.5), (0.1, -0.2, 0.05))
+        cap = pj.Capacity(pj.Sphere((0.5, 0.3, 0.4), 0.9), mesh)
+        bcb = pj.BorderConditions({"left": pj.Dirichlet(0.0), "top": pj.Dirichlet(2.0), "backward": pj.Dirichlet(1.0)})
+        s = pj.DiffusionUnsteadyMono(pj.Phase(cap, pj.DiffusionOps(cap), 0.0, 1.0), bcb, pj.Dirichlet(1.0), 1e-4, None, "BE")
+    elif case == "mono2d_march":
+        mesh = pj.Mesh((400, 304), (4.0, 4.0))
+        cap = pj.Capacity(pj.Sphere((2.01, 2.01), 1.6), mesh)
+        bcb = pj.BorderConditions({k: pj.Dirichlet(0.0) for k in HEAT_BORDERS})
+        s = pj.DiffusionUnsteadyMono(pj.Phase(cap, pj.DiffusionOps(cap), 0.0, 1.0), bcb, pj.Dirichlet(1.0), 1e-4, None, "CN")
+    elif case == "mono3d_march_two_balls":
+        # two balls along x: two runs per grid line, chains side by side
+        mesh = pj.Mesh((192, 64, 64), (6.0, 2.0, 2.0))
+        cap = pj.Capacity(pj.MultiSphere([(1.5, 1.0, 1.0), (4.4, 1.02, 0.97)], 0.9), mesh)
+        bcb = pj.BorderConditions({k: pj.Dirichlet(1.0) for k in ("left", "right", "top", "bottom")})
+        s = pj.DiffusionUnsteadyMono(pj.Phase(cap, pj.DiffusionOps(cap), 0.0, 1.0), bcb, pj.Dirichlet(1.0), 3e-4, None, "CN")
+    elif case == "mono3d_dyadic":
         mesh = pj.Mesh((48, 48, 48), (4.0, 4.0, 4.0))
         cap = pj.Capacity(pj.Sphere((2.01, 2.01, 2.01), 1.0), mesh)
         bcb = pj.BorderConditions({k: pj.Dirichlet(1.0) for k in ("left", "right", "top", "bottom")})
@@ -639,6 +663,8 @@ def test_spmv_stencil_slices_bitwise_equal_csr_kernels(pj, case):
     assert info.spmv_bytes > 0 and info.spmv_slices > 0
     if case in ("mono3d_dyadic", "mono3d_nondyadic"):
         assert info.rows_uniform > 0.3 * info.n_own          # uniform mesh: interior rows share their stencil exactly
+    if "march" in case:
+        assert info.spmv_units > 0 and info.rows_marched > 0.5 * info.n_own, (info.spmv_units, info.rows_marched, info.n_own)
     for other in (38, 2, 1):
         diff, mx = _spmv_compare(pj, s, 0, 70, other)
         assert mx > 0.0
