@@ -2,22 +2,28 @@
 """bench.py -- BASELINE.json's headline metric on MI355X:
     time-steps/sec + SpMV GB/s (% HBM roofline), 3D mono diffusion 512^3   (benchmark/Heat3D.jl shape)
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 512]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 512] [--strong]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over the resident problem: one Crank-Nicolson time step of
-solve_DiffusionUnsteadyMono! = right-hand side (1 SpMV + fused vector kernel) + BiCGStab solve to
-reltol 1e-12 + un-scaling, all on the GPU through the C ABI.  Inputs (capacities, CSR system, state) are
-resident in HBM when the timed region starts.
+solve_DiffusionUnsteadyMono! = right-hand side (1 SpMV + fused vector kernel) + BiCGStab solve to reltol 1e-12 (tested in
+the units of x: ||S r|| <= reltol ||S b||) + recovery of x, all on the GPU through the C ABI.  Inputs (capacities, CSR
+system, state) are resident in HBM when the timed region starts.
 
-N > 1 is weak scaling: grid (n, n, n*N), domain (4, 4, 4N), one sphere per slab,
-slab-decomposed along z with RCCL halo exchange + dot all-reduce inside libpenguin_hip.so; `value` is the
-aggregate n^3-subdomain time-steps per second (N x global steps/s).
+N > 1: one process per GPU.  Invoked WITHOUT torch.distributed.run (`python bench.py --gpus N`, as the driver may do), the
+script starts the N ranks itself as child processes (`python -m torch.distributed.run ...`) before anything touches a
+GPU and relays rank 0's JSON line.  Default = weak scaling: grid (n, n, n*N), domain (4, 4, 4N),
+one sphere per slab; every rank owns one n^3 sphere problem, the fluid stays away from the slab faces, so NO halo is
+exchanged (the matrix has no ghost columns) and the only collective in the loop is the all-reduce of the Krylov scalars;
+`value` = n^3-subdomain time-steps per second summed over the ranks.  `--strong`: the SAME n^3 problem cut into N slabs
+(balanced by active rows): every SpMV exchanges one ghost plane with each neighbour (RCCL send/recv over xGMI,
+overlapped with the interior rows).  No multi-GPU run of either kind has been measured yet (no multi-GPU box was
+available to the author): the slab code is verified with virtual ranks on one GPU (tests/test_gpu_config4.py).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = the
-SpMV, HIP-event timed on the library stream inside the timed region), `step_roofline` (the whole time step's
-algorithmic bytes over its wall time) and `cpu_baseline` (the oracle's C
-restatement of the same Krylov loop on the same matrix, on the host cores of this box; rank 0, N=1 only).
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = the SpMV launch,
+HIP-event timed on the library stream inside the timed region), `step_roofline` (the whole time step's algorithmic
+bytes over its wall time) and `cpu_baseline` (the oracle's C restatement of the same Krylov loop on the same matrix, on
+the host cores of this box; rank 0, N=1 only).
 """
 from __future__ import annotations
 
@@ -25,6 +31,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -38,6 +45,23 @@ if str(ROOT) not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (nothing in this process
+    has touched the GPU) and hand back their exit code; rank 0's JSON line goes to our stdout through the children."""
+    port = int(os.environ.get("MASTER_PORT", "29541"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()),
+           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--n", str(args.n)]
+    if args.strong:
+        cmd.append("--strong")
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this image
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env, cwd=str(ROOT)).returncode
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -48,16 +72,16 @@ def main() -> None:
                     help="strong scaling (SURVEY 8d, config 4): the SAME n^3 problem slab-decomposed over the ranks "
                          "(default: weak scaling, one n^3 sphere problem per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=6,
-                    help="time-steps the CPU baseline times per thread count (6 single-thread steps ~ 10 s, + 6 on all cores)")
+    ap.add_argument("--cpu-steps", type=int, default=4,
+                    help="time-steps the CPU baseline times per variant (4 single-thread plain solves ~ 10 s)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N with N > 1 must be launched through torch.distributed.run (one rank per GPU)")
+        if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+            raise SystemExit(spawn_ranks(args))
         args.gpus = world
 
     import torch  # device sync + torch.distributed control plane (rendezvous, barrier, max-over-ranks)
@@ -110,15 +134,16 @@ def main() -> None:
     dt = 0.75 * (4.0 / n) ** 2                         # benchmark/Heat3D.jl:69
     s = pj.DiffusionUnsteadyMono(phase, bcb, bci, dt, None, "BE")   # BE first (Heat3D.jl:72)
     setup_s = time.time() - t0
-    opts = L.pg_krylov_opts(L.PG_METHOD["bicgstab"], 1e-12, 0.0, 0, 4, int(os.environ.get("PG_WARM_START", "1")))
+    warm = int(os.environ.get("PG_WARM_START", "1"))
+    opts = L.pg_krylov_opts(L.PG_METHOD["bicgstab"], 1e-12, 0.0, 0, 4, warm, 0, 0)
     info = L.pg_step_info()
     L.check(lib.pg_solver_initial_solve(s._h, C.byref(opts), C.byref(info)))
+    assert info.converged, "the first (BE) solve did not converge"
     CN = L.PG_SCHEME["CN"]                             # then CN (Heat3D.jl:74)
-    run = L.pg_run_info()
 
-    def steps(k: int) -> L.pg_run_info:
+    def steps(k: int, o=opts) -> L.pg_run_info:
         r = L.pg_run_info()
-        L.check(lib.pg_solver_run(s._h, C.c_double(1e30), C.c_int32(CN), C.byref(opts), C.c_int32(0), C.c_int64(k),
+        L.check(lib.pg_solver_run(s._h, C.c_double(1e30), C.c_int32(CN), C.byref(o), C.c_int32(0), C.c_int64(k),
                                   C.c_int32(0), C.byref(r)))
         return r
 
@@ -129,13 +154,16 @@ def main() -> None:
         L.check(lib.pg_device_synchronize())
 
     steps(args.warmup)
-    L.check(lib.pg_set_profiling(1))                   # HIP events around every SpMV launch on the library stream
+    L.check(lib.pg_set_profiling(1))                   # HIP events around sampled SpMV launches on the library stream
     sync()
     t0 = time.perf_counter()
     run = steps(args.steps)
     sync()
     elapsed = time.perf_counter() - t0
     L.check(lib.pg_set_profiling(0))
+    # a step that did not meet the tolerance is not a valid step: the number below would be meaningless
+    assert run.unconverged_steps == 0, f"{run.unconverged_steps} of {run.steps} timed solves did not converge"
+    assert run.steps == args.steps
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -144,34 +172,39 @@ def main() -> None:
     sysinfo = s.system_info(3)                         # the run matrix as the SpMV streams it (preconditioned)
     n_rows, nnz = int(sysinfo.n_own), int(sysinfo.nnz)
     if world > 1:
-        tot = torch.tensor([n_rows, nnz], dtype=torch.int64, device="cuda")
+        tot = torch.tensor([n_rows, nnz, int(sysinfo.n_ghost)], dtype=torch.int64, device="cuda")
         dist.all_reduce(tot)
-        n_rows_g, nnz_g = int(tot[0].item()), int(tot[1].item())
+        n_rows_g, nnz_g, ghosts_g = int(tot[0].item()), int(tot[1].item()), int(tot[2].item())
     else:
-        n_rows_g, nnz_g = n_rows, nnz
+        n_rows_g, nnz_g, ghosts_g = n_rows, nnz, int(sysinfo.n_ghost)
     b_csr = 12 * nnz + 20 * n_rows                     # algorithmic bytes of one plain-CSR SpMV (this rank)
-    # the kernel in the loop streams the stencil-sliced image of the same matrix: its algorithmic bytes are the
-    # bytes of THAT format (records + P/G streams + x and y once) -- pricing it with the CSR figure would credit
-    # bytes it never has to move (DESIGN.md "SpMV")
-    # + 8 n: every launch timed in the loop is a fused-dot launch that also reads r-hat (SURVEY's CSR figure leaves the
-    # dot operand out; the CSR number below is kept as SURVEY defines it)
-    b_spmv = int(sysinfo.spmv_bytes) + 8 * n_rows if os.environ.get("PG_SPMV_VARIANT", "70") in ("70", "66") else b_csr
-    if bool(sysinfo.neumann_ok) and os.environ.get("PG_POLY", "1") != "0" and b_spmv != b_csr:
-        # preconditioned loop: the bracketed launches alternate between v = A u (r-hat) and t = A u_s, whose (t, s) dot
-        # reads s as a vector of its own (+8 n on every second launch)
-        b_spmv += 4 * n_rows
-    spmv_ms = run.spmv_ms_total / max(run.spmv_launches, 1)
-    achieved = b_spmv / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
+    # the kernel in the loop streams the stencil-sliced image of the same matrix: its algorithmic bytes are the bytes of
+    # THAT format (unit + slice records, P/G streams, x and y once) -- pricing it with the CSR figure would credit bytes
+    # it never has to move (DESIGN.md "SpMV")
+    sliced = os.environ.get("PG_SPMV_VARIANT", "70") in ("70", "66")
+    b_fmt = int(sysinfo.spmv_bytes) if sliced else b_csr
+    m = int(run.poly_degree)                           # products per application of the preconditioned operator (0: plain)
+    # launches timed in the loop: LEAN (a factor of the preconditioner polynomial: x in, y out, the matrix) and CLOSING
+    # launches (fused dots: + r-hat and the chain's input vector, read as the subtrahend / dot operand: + 16 n)
+    lean_ms = run.spmv_lean_ms_total / max(run.spmv_lean_launches, 1)
+    dots_ms = run.spmv_ms_total / max(run.spmv_launches, 1)
+    b_dots = b_fmt + (16 if m else 12) * n_rows        # plain iteration: r-hat in both launches, s in every second one
+    dominant_lean = m >= 2 and run.spmv_lean_launches > 0
+    k_ms, k_bytes = (lean_ms, b_fmt) if dominant_lean else (dots_ms, b_dots)
+    achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    # Krylov iterations: an iteration that ended at its half step ran one application of the operator, not two
     iters = run.total_iters / max(run.steps, 1)
+    iters_eff = (run.total_iters - 0.5 * run.half_exits) / max(run.steps, 1)
 
     traffic = None
-    tf = ROOT / "profiles" / "r01_spmv_traffic.json"
+    tf = ROOT / "profiles" / "r02_spmv_traffic.json"
     if tf.exists():
         try:
             traffic = json.loads(tf.read_text()).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
 
+    halo = ghosts_g > 0
     out = {
         "metric": "time-steps/sec + SpMV GB/s (% HBM roofline), 3D mono diffusion 512^3",
         "value": g * args.steps / elapsed,
@@ -190,12 +223,17 @@ def main() -> None:
         "config": {
             "workload": f"3D monophasic unsteady diffusion {n}^3 per GPU (grid {n}x{n}x{n * g}), sphere r=1 per slab, "
                         "Dirichlet(1) interface, Dirichlet(1) on :left/:right/:top/:bottom, BE first solve then CN steps "
-                        "(benchmark/Heat3D.jl shape), BiCGStab reltol 1e-12 on the equilibrated, cell-block-preconditioned reduced CSR system",
+                        "(benchmark/Heat3D.jl shape), BiCGStab reltol 1e-12 in the units of x (||S r|| <= reltol ||S b||) on the "
+                        "equilibrated, cell-block-preconditioned reduced system, warm start",
             "grid": [n, n, n * g],
             "rows_global": n_rows_g, "nnz_global": nnz_g, "rows_rank0": n_rows, "nnz_rank0": nnz,
-            "krylov_iters_per_step": iters,
-            "spmv_per_step": run.spmv_launches / max(run.steps, 1),
-            "parallelism": f"slab-z x{world}, RCCL halo + dot all-reduce",
+            "krylov_iters_per_step": iters, "krylov_iters_per_step_counting_half_steps_as_half": iters_eff,
+            "polynomial_preconditioner_degree": m,
+            "spmv_timed_per_step": (run.spmv_launches + run.spmv_lean_launches) / max(run.steps, 1),
+            "timed_window": f"steps {args.warmup + 1}..{args.warmup + args.steps} after the BE solve (iterations per step fall as the field settles)",
+            "parallelism": (f"slab-z x{world}: " + ("one ghost plane per neighbour per SpMV (RCCL send/recv, overlapped) + " if halo else
+                            "no halo traffic (no row references a ghost column) + ") + "all-reduce of the Krylov scalars") if world > 1
+                           else "1 GPU",
             "value_is": "global time-steps/s" if g == 1 else f"{n}^3-slab time-steps/s summed over the {world} slabs "
                         f"(= {world} x {args.steps / elapsed:.1f} global steps/s)",
             "setup_s": setup_s, "capacity_kernels_ms": cap_ms,
@@ -205,45 +243,50 @@ def main() -> None:
             "device": pj.device_name(),
         },
         "roofline": {
-            "kernel": "k_spmv_s (stencil-sliced CSR: uniform / pattern slices + packed irregular rows, fp64)",
+            "kernel": "k_spmv_s (marching units + stencil slices + packed irregular rows, fp64): " +
+                      ("lean launch w <- w - tau A w of the preconditioner polynomial (x in, y out, matrix)" if dominant_lean
+                       else "launch with fused dots"),
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
-            "bytes_per_launch": b_spmv,
+            "bytes_per_launch": k_bytes,
+            "avg_launch_ms": k_ms,
+            "launches_timed": int(run.spmv_lean_launches if dominant_lean else run.spmv_launches),
+            "closing_launches": {"what": "last product of a chain: + the chain's input vector and r-hat, fused dots, in-launch scalar phase",
+                                 "bytes_per_launch": b_dots, "avg_launch_ms": dots_ms, "launches_timed": int(run.spmv_launches),
+                                 "achieved": b_dots / (dots_ms * 1e-3) / 1e9 if dots_ms > 0 else 0.0,
+                                 "frac": b_dots / (dots_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if dots_ms > 0 else 0.0},
             "csr_bytes_per_launch": b_csr,
-            "csr_equivalent_GBs": b_csr / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0,
+            "csr_equivalent_GBs": b_csr / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0,
+            "rows_marched": int(sysinfo.rows_marched), "march_units": int(sysinfo.spmv_units),
             "rows_uniform": int(sysinfo.rows_uniform), "rows_pattern": int(sysinfo.rows_pattern),
             "rows_irregular": int(sysinfo.rows_irregular), "slices": int(sysinfo.spmv_slices),
-            "avg_launch_ms": spmv_ms,
-            "launches_timed": int(run.spmv_launches),
         },
     }
 
     # The whole SpMV-bound time step against the same roofline (north star: ">= 60 % of the HBM roofline on the SpMV-bound
     # time-step"): algorithmic bytes of one CN step of THIS loop on this rank -- every kernel's operand vectors once, the
     # matrix in the format that is streamed --
-    #   per BiCGStab iteration: 2 SpMV (format bytes, x and y included) + r-hat in both (2 x 8n) + k_bicg_s (r, v, r-hat -> s:
-    #   4 x 8n) + k_bicg_xrp (x, p, s, t, v -> x, r, p: 8 x 8n)  = 2 spmv_bytes + 112 n
-    #   per step: + the right-hand side's SpMV (spmv_bytes) + k_rhs_init (74 n)
+    #   per application of the operator (2 per iteration, 1 in an iteration that ends at its half step):
+    #       (m - 1) lean launches (b_fmt) + the closing launch (b_fmt + 16 n);  plain iteration: one launch, b_fmt + 8 n (+ 8 n)
+    #   per iteration: k_bicg_s (r, v, r-hat, S -> s: 5 x 8 n) + k_bicg_xrp (y, p, s: read + written, t, v, S: 9 x 8 n)
+    #   per step: the right-hand side's SpMV (b_fmt) + k_rhs_init (74 n) + y = 0 (8 n) + the recovery x = x0 + q(A) y:
+    #       (m - 1) launches that also update x (b_fmt + 16 n) + the last term (24 n)
     # divided by the measured wall time of the step (launch gaps, host polls and the per-step kernels included).
-    b_fmt = int(sysinfo.spmv_bytes)
-    neumann = bool(sysinfo.neumann_ok) and os.environ.get("PG_POLY", "1") != "0"
-    if neumann:
-        # right-preconditioned iteration (M^-1 = 2I - A): 4 SpMVs (two of them with the 2x - Ax epilogue, no r-hat), the
-        # separate (t, s) operand, k_bicg_s (4 vectors) and k_bicg_xrp with u and u_s (10 vectors):
-        # 4 spmv_bytes + (2 + 1 + 4 + 10) x 8 n = 4 spmv_bytes + 136 n
-        step_bytes = (4.0 * iters + 1.0) * b_fmt + iters * 136.0 * n_rows + 74.0 * n_rows
+    if m >= 2:
+        per_apply = (m - 1) * b_fmt + (b_fmt + 16.0 * n_rows)
+        step_bytes = (2.0 * iters_eff) * per_apply + iters * (40.0 + 72.0) * n_rows + b_fmt + (74.0 + 8.0) * n_rows \
+            + (m - 1) * (b_fmt + 16.0 * n_rows) + 24.0 * n_rows
     else:
-        step_bytes = (2.0 * iters + 1.0) * b_fmt + iters * 112.0 * n_rows + 74.0 * n_rows
+        step_bytes = (2.0 * iters + 1.0) * b_fmt + iters * (12.0 + 40.0 + 72.0) * n_rows + 74.0 * n_rows
     step_gbs = step_bytes / (elapsed / args.steps) / 1e9
     out["step_roofline"] = {
-        "what": ("one CN time step of the loop on rank 0: (4 iters + 1) SpMV format bytes + iters x 136 n" if neumann else
-                 "one CN time step of the loop on rank 0: (2 iters + 1) SpMV format bytes + iters x 112 n") +
-                " (BiCGStab vector kernels and the dot operands) + 74 n (right-hand side), over the wall time per step",
-        "neumann_preconditioner": neumann, "gershgorin_radius": float(sysinfo.gershgorin),
+        "what": "one CN time step of the loop on rank 0: every launch's operand vectors once and the matrix in the streamed "
+                "format (formula in bench.py), over the wall time per step",
+        "polynomial_preconditioner_degree": m, "gershgorin_radius": float(sysinfo.gershgorin),
         "bound": "hbm", "bytes_per_step": step_bytes, "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": step_gbs / HBM_PEAK_GBS,
         "survey_8d_bytes_per_step": iters * (2.0 * b_csr + 168.0 * n_rows) + 48.0 * n_rows + 16.0 * n_rows,
@@ -251,7 +294,11 @@ def main() -> None:
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(s, dt, args.cpu_steps, n)
+            # the GPU loop's iteration count from a zero initial guess, for the comparison with the (cold-start) CPU figures
+            cold = L.pg_krylov_opts(L.PG_METHOD["bicgstab"], 1e-12, 0.0, 0, 4, 0, 0, 0)
+            rc = steps(3, cold)
+            out["cpu_baseline"] = cpu_baseline(s, args.cpu_steps, n, m, float(sysinfo.gershgorin))
+            out["cpu_baseline"]["gpu_cold_start_iters_per_step"] = rc.total_iters / max(rc.steps, 1)
         except Exception as e:   # the GPU metric above must still be reported (e.g. the host lacks memory for the 65 M-entry copy)
             out["cpu_baseline"] = {"value": None, "unit": "time-steps/s", "cores": 1, "kind": "port",
                                    "sample": f"not measured: {type(e).__name__}: {e}"}
@@ -262,53 +309,48 @@ def main() -> None:
         dist.destroy_process_group()
 
 
-def cpu_baseline(s, dt: float, cpu_steps: int, n: int) -> dict:
-    """The oracle's C restatement of the same loop (oracle/krylov_ref.c) on the SAME reduced system, timed on
-    this box's host cores.  The reference itself (Julia) cannot run here; kind = "port"."""
-    import scipy.sparse as sp
-
+def cpu_baseline(s, cpu_steps: int, n: int, m: int, gersh: float) -> dict:
+    """The oracle's C restatement of the same loop (oracle/krylov_ref.c) on the SAME reduced system, timed on this box's
+    host cores.  The reference itself (Julia) cannot run here; kind = "port".  Every CPU solve starts from zero (the host
+    side has no time loop of its own): `gpu_cold_start_iters_per_step` is the GPU loop's count under the same condition."""
     from oracle import krylov_c
+    from penguin.jl_amd import _lib as L
 
     Ah, bh, idx = s.system(3)          # the preconditioned run system (B^-1 S A S, B^-1 S b) the GPU iterates on
     nrow = Ah.shape[0]
     Ah = Ah[:, :nrow].tocsr()
+    wts = np.empty(nrow)
+    L.check(L.lib().pg_solver_get_row_scaling(s._h, 1, L.dptr(wts)))   # the weights of the convergence test
     try:
         ncores = len(os.sched_getaffinity(0))
     except AttributeError:
         ncores = os.cpu_count() or 1
     ncores = max(1, min(ncores, 16))   # a 1-GPU box's CPU share
     res = {}
-    for label, nt, reps in (("single_thread", 1, cpu_steps), ("all_cores", ncores, max(cpu_steps, 2))):
+    variants = (("single_thread", 1, cpu_steps, 0), ("all_cores", ncores, max(cpu_steps, 2), 0),
+                ("all_cores_same_algorithm_as_gpu", ncores, max(cpu_steps, 2), m))
+    for label, nt, reps, deg in variants:
         t0 = time.perf_counter()
-        its = 0
+        its = nmv = 0
         for _ in range(reps):
-            y = krylov_c.spmv(Ah, bh, nthreads=nt)          # the CN right-hand side's SpMV
-            x, it, rn = krylov_c.solve(Ah, bh, "bicgstab", reltol=1e-12, maxiter=10000, nthreads=nt)
+            krylov_c.spmv(Ah, bh, nthreads=nt)          # the CN right-hand side's SpMV
+            x, it, rn, mv = krylov_c.solve_poly(Ah, bh, deg, gersh, weights=wts, reltol=1e-12, maxiter=10000, nthreads=nt)
             its += it
+            nmv += mv
         el = time.perf_counter() - t0
-        res[label] = {"value": reps / el, "cores": nt, "iters_per_step": its / reps, "steps_timed": reps}
-    # the same algorithm the GPU loop runs (Neumann right preconditioner), on all host cores: an apples-to-apples figure
-    # next to the reference-like plain iteration above
-    t0 = time.perf_counter()
-    its = 0
-    reps = max(cpu_steps, 2)
-    for _ in range(reps):
-        y = krylov_c.spmv(Ah, bh, nthreads=ncores)
-        x, it, rn = krylov_c.solve(Ah, bh, "bicgstab_neumann", reltol=1e-12, maxiter=10000, nthreads=ncores)
-        its += it
-    el = time.perf_counter() - t0
-    res["all_cores_neumann"] = {"value": reps / el, "cores": ncores, "iters_per_step": its / reps, "steps_timed": reps}
+        res[label] = {"value": reps / el, "cores": nt, "iters_per_step": its / reps, "products_per_step": nmv / reps,
+                      "steps_timed": reps, "polynomial_degree": deg}
     return {
         "value": res["single_thread"]["value"],
         "unit": "time-steps/s",
         "cores": 1,
         "kind": "port",
         "sample": f"{res['single_thread']['steps_timed']} CN step(s) of the same {n}^3 reduced system (n={nrow}, nnz={Ah.nnz}): "
-                  "1 SpMV + plain BiCGStab reltol 1e-12 (the iteration IterativeSolvers would run; the GPU loop's Neumann right "
-                  "preconditioner is not applied here), oracle/krylov_ref.c, single thread (the reference's Krylov path is "
-                  "single-threaded); all-cores OpenMP figure alongside",
+                  "1 SpMV + plain BiCGStab from a zero initial guess to the same test (||S r|| <= 1e-12 ||S b||): the iteration "
+                  "IterativeSolvers would run, oracle/krylov_ref.c, single thread (the reference's Krylov path is single-threaded); "
+                  "all-cores OpenMP figures alongside, plain and with the GPU loop's polynomial preconditioner",
         "all_cores": res["all_cores"],
-        "all_cores_same_algorithm_as_gpu": res["all_cores_neumann"],
+        "all_cores_same_algorithm_as_gpu": res["all_cores_same_algorithm_as_gpu"],
         "host_cores": ncores,
     }
 

@@ -104,11 +104,17 @@ typedef struct {
   double t_final;
   double extremum;
   double solve_ms;          /* wall time of the whole run on this rank                          */
-  /* profiling (pg_set_profiling(1)): HIP-event time of every SpMV launch in the run           */
+  /* profiling (pg_set_profiling(1)): HIP-event time of the sampled SpMV launches that carry fused dots (the plain
+     iteration's only kind; with the polynomial preconditioner the launch that closes each chain of products)      */
   double spmv_ms_total;
   int64_t spmv_launches;
   int64_t unconverged_steps; /* solves of this run that ended without meeting the tolerance (maxiter / breakdown) */
   double worst_relres;       /* max over the run's solves of ||r|| / ||b|| at exit                                */
+  double spmv_lean_ms_total; /* profiling: the sampled LEAN launches -- factors of the preconditioner polynomial, one   */
+  int64_t spmv_lean_launches;/* vector in, one out, no dots (DESIGN.md "Krylov driver")                                 */
+  int64_t poly_degree;       /* products with Â per application of the preconditioned operator in the last solve (0: plain) */
+  int64_t half_exits;        /* solves that met the tolerance after the first half of their last iteration (such an
+                                iteration counts as one in total_iters but runs only one application of the operator)  */
 } pg_run_info;
 
 typedef struct {
@@ -124,8 +130,8 @@ typedef struct {
   int64_t rows_uniform;   /* rows in U slices (shared offsets and values, nothing streamed)      */
   int64_t rows_pattern;   /* rows in P slices (shared offsets, 8 B/entry value stream)           */
   int64_t rows_irregular; /* rows in G chunks (packed CSR, 12 B/entry)                           */
-  int64_t neumann_ok;     /* 1: the spectrum of the preconditioned matrix is provably inside |z - 1| < 0.95, BiCGStab
-                             runs right-preconditioned with M^-1 = 2I - A (half the iterations, same SpMV count) */
+  int64_t neumann_ok;     /* 1: the spectrum of the preconditioned matrix is provably inside |z - 1| < 0.95: BiCGStab
+                             runs right-preconditioned with a Chebyshev polynomial in Â (pg_krylov_opts.precond)   */
   double gershgorin;      /* the largest Gershgorin radius that decision rests on (all ranks)     */
   int64_t spmv_units;     /* marching units (DESIGN.md "SpMV"): <= 11 planes x 126 uniform stencil rows each      */
   int64_t rows_marched;   /* rows covered by them (counted in rows_uniform too; they are in no slice)             */

@@ -99,31 +99,82 @@ int krylov_ref_bicgstab(int64_t n, const int64_t* rp, const int32_t* ci, const d
   return it;
 }
 
-/* The iteration pg_krylov.hip runs where its Gershgorin test admits it: BiCGStab right-preconditioned with the Neumann
- * polynomial M^-1 = 2I - A (u = 2p - Ap; v = Au; ... x += alpha u + omega u_s).  Not something the reference does --
- * here so that bench.py can time the SAME algorithm on the host cores next to the plain iteration. */
-int krylov_ref_bicgstab_neumann(int64_t n, const int64_t* rp, const int32_t* ci, const double* v, const double* b, double* x,
-                                double reltol, double abstol, int maxiter, int nthreads, double* resnorm_out) {
+/* The iteration pg_krylov.hip runs where its Gershgorin test admits it (not something the reference does -- here so that
+ * tests can check the algorithm on the host and bench.py can time the SAME algorithm on the host cores): BiCGStab on
+ *     C y = b - A x0,   C = A q(A) = I - R(A),   x = x0 + q(A) y,
+ * R(A) = prod_k (I - tau_k A) the Chebyshev residual polynomial of degree m on [1 - g, 1 + g] in product form (roots taken
+ * from both ends of the interval in turn), convergence tested on the weighted residual ||w .* r|| <= reltol ||w .* b|| (w =
+ * the row scaling S of the equilibrated system: the residual in units of x; NULL: unweighted) after both halves of an
+ * iteration.  m = 0: the plain iteration with the same tests.  Returns iterations (an accepted half step counts as one);
+ * *nmv = products with A. */
+static void poly_taus(int m, double g, double* tau) {
+  double lam[16];
+  for (int k = 0; k < m; ++k) lam[k] = 1.0 + g * cos(M_PI * (2.0 * k + 1.0) / (2.0 * m));
+  for (int k = 0, lo = 0, hi = m - 1; k < m; ++k) tau[k] = 1.0 / ((k & 1) ? lam[hi--] : lam[lo++]);
+}
+
+static double wdot(int64_t n, const double* w, const double* a) {
+  double s = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : s)
+  for (int64_t i = 0; i < n; ++i) { const double t = (w ? w[i] : 1.0) * a[i]; s += t * t; }
+  return s;
+}
+
+/* out = C in = in - R(A) in; wa, wb: work vectors */
+static void apply_c(int64_t n, const int64_t* rp, const int32_t* ci, const double* v, int m, const double* tau, const double* in,
+                    double* out, double* wa, double* wb, int64_t* nmv) {
+  if (m == 0) { spmv(n, rp, ci, v, in, out); *nmv += 1; return; }
+  const double* src = in;
+  for (int k = 0; k < m; ++k) {
+    double* dst = k + 1 == m ? out : ((k & 1) ? wb : wa);
+    spmv(n, rp, ci, v, src, dst);
+    *nmv += 1;
+    const double tk = tau[k];
+    if (k + 1 < m) {
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < n; ++i) dst[i] = src[i] - tk * dst[i];
+    } else {
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < n; ++i) dst[i] = in[i] - (src[i] - tk * dst[i]);
+    }
+    src = dst;
+  }
+}
+
+int krylov_ref_bicgstab_poly(int64_t n, const int64_t* rp, const int32_t* ci, const double* v, const double* b, double* x,
+                             const double* x0, const double* wts, int m, double g, double reltol, double abstol, int maxiter,
+                             int nthreads, double* resnorm_out, int64_t* nmv_out) {
 #ifdef _OPENMP
   omp_set_num_threads(nthreads > 0 ? nthreads : 1);
 #endif
+  if (m < 2) m = 0;
+  if (m > 16) m = 16;
+  double tau[16];
+  if (m) poly_taus(m, g, tau);
   double* r = (double*)malloc(sizeof(double) * n);
   double* rh = (double*)malloc(sizeof(double) * n);
   double* p = (double*)calloc(n, sizeof(double));
   double* vv = (double*)calloc(n, sizeof(double));
   double* t = (double*)malloc(sizeof(double) * n);
-  double* u = (double*)malloc(sizeof(double) * n);
-  double* us = (double*)malloc(sizeof(double) * n);
-  double* w = (double*)malloc(sizeof(double) * n);
-  for (int64_t i = 0; i < n; ++i) { x[i] = 0.0; r[i] = b[i]; rh[i] = b[i]; }
-  const double bb = dot(n, b, b);
-  double tol2 = reltol * reltol * bb;
+  double* y = (double*)calloc(n, sizeof(double));
+  double* wa = (double*)malloc(sizeof(double) * n);
+  double* wb = (double*)malloc(sizeof(double) * n);
+  int64_t nmv = 0;
+  if (x0) {
+    spmv(n, rp, ci, v, x0, r);
+    nmv += 1;
+    for (int64_t i = 0; i < n; ++i) { x[i] = x0[i]; r[i] = b[i] - r[i]; rh[i] = r[i]; }
+  } else {
+    for (int64_t i = 0; i < n; ++i) { x[i] = 0.0; r[i] = b[i]; rh[i] = b[i]; }
+  }
+  double tol2 = reltol * reltol * wdot(n, wts, b);
   if (abstol * abstol > tol2) tol2 = abstol * abstol;
-  double rr = bb, rho_old = 1.0, alpha = 1.0, omega = 1.0, rho = bb, rhat2 = bb;
+  double rrw = wdot(n, wts, r), rr = dot(n, r, r);
+  double rho_old = 1.0, alpha = 1.0, omega = 1.0, rho = rr, rhat2 = rr;
   int it = 0, restart = 0;
-  while (rr > tol2 && it < maxiter) {
+  while (rrw > tol2 && it < maxiter) {
     ++it;
-    if (restart) {
+    if (it == 1 || restart) {
 #pragma omp parallel for schedule(static)
       for (int64_t i = 0; i < n; ++i) p[i] = r[i];
       restart = 0;
@@ -132,30 +183,31 @@ int krylov_ref_bicgstab_neumann(int64_t n, const int64_t* rp, const int32_t* ci,
 #pragma omp parallel for schedule(static)
       for (int64_t i = 0; i < n; ++i) p[i] = r[i] + beta * (p[i] - omega * vv[i]);
     }
-    spmv(n, rp, ci, v, p, w);
-#pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i < n; ++i) u[i] = 2.0 * p[i] - w[i];
-    spmv(n, rp, ci, v, u, vv);
+    apply_c(n, rp, ci, v, m, tau, p, vv, wa, wb, &nmv);
     const double den = dot(n, rh, vv);
     const int force = den == 0.0;
     alpha = force ? 0.0 : rho / den;
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i) r[i] -= alpha * vv[i]; /* r holds s */
-    spmv(n, rp, ci, v, r, w);
+    rrw = wdot(n, wts, r);
+    if (rrw <= tol2) { /* half step accepted */
 #pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i < n; ++i) us[i] = 2.0 * r[i] - w[i];
-    spmv(n, rp, ci, v, us, t);
+      for (int64_t i = 0; i < n; ++i) y[i] += alpha * p[i];
+      break;
+    }
+    apply_c(n, rp, ci, v, m, tau, r, t, wa, wb, &nmv);
     const double tt = dot(n, t, t);
     omega = tt != 0.0 ? dot(n, t, r) / tt : 0.0;
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i) {
-      x[i] += alpha * u[i] + omega * us[i];
+      y[i] += alpha * p[i] + omega * r[i];
       r[i] -= omega * t[i];
     }
     rho_old = rho;
     rho = dot(n, rh, r);
     rr = dot(n, r, r);
-    if (rr <= tol2) break;
+    rrw = wdot(n, wts, r);
+    if (rrw <= tol2) break;
     if (omega == 0.0 || force || rho * rho < 1e-20 * rhat2 * rr) {
 #pragma omp parallel for schedule(static)
       for (int64_t i = 0; i < n; ++i) rh[i] = r[i];
@@ -164,8 +216,28 @@ int krylov_ref_bicgstab_neumann(int64_t n, const int64_t* rp, const int32_t* ci,
       restart = 1;
     }
   }
-  if (resnorm_out) *resnorm_out = sqrt(rr);
-  free(r); free(rh); free(p); free(vv); free(t); free(u); free(us); free(w);
+  /* x = x0 + q(A) y,  q(A) y = sum_k tau_k w_(k-1),  w_0 = y,  w_k = w_(k-1) - tau_k A w_(k-1) */
+  if (m == 0) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) x[i] += y[i];
+  } else {
+    const double* src = y;
+    for (int k = 0; k < m; ++k) {
+      const double tk = tau[k];
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < n; ++i) x[i] += tk * src[i];
+      if (k + 1 == m) break;
+      double* dst = (k & 1) ? wb : wa;
+      spmv(n, rp, ci, v, src, dst);
+      nmv += 1;
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < n; ++i) dst[i] = src[i] - tk * dst[i];
+      src = dst;
+    }
+  }
+  if (resnorm_out) *resnorm_out = sqrt(rrw);
+  if (nmv_out) *nmv_out = nmv;
+  free(r); free(rh); free(p); free(vv); free(t); free(y); free(wa); free(wb);
   return it;
 }
 

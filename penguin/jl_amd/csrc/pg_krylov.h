@@ -13,7 +13,9 @@ struct KrylovWork {
   int grid = 1;
   DevBuf<unsigned> ticket;              // arrival counter of the in-launch scalar phases (pg_spmv.h)
   int last_iters = 0;                   // iterations of the previous solve (sizes the first launch batch)
-  DevBuf<double> u, us;                 // M⁻¹p and M⁻¹s of the Neumann-preconditioned BiCGStab (n_vec each; on first use)
+  // polynomial right preconditioner (pg_krylov.hip), n_vec each, on first use: the accumulated solution of the
+  // preconditioned system (x = x0 + q(Â) ya) and the two work vectors the chain of products alternates between
+  DevBuf<double> ya, wa, wb;
   // GMRES(m) only, allocated on first use (pg_gmres.hip): m+1 basis vectors, H / rotations / g, per-block partial sums
   DevBuf<double> gm_basis, gm, gm_partials;
   int gm_m = -1;
@@ -25,8 +27,12 @@ struct SolveStats {
   int iters = 0;
   int converged = 0;
   double resnorm = 0.0, bnorm = 0.0;
-  double spmv_ms = 0.0;
-  i64 spmv_launches = 0;
+  // profiling: HIP-event time of the sampled SpMV launches, by kind -- launches that carry fused dots (and their operand
+  // vectors) and lean ones (plain products and the factors of the preconditioner polynomial: x, y and the matrix only)
+  double spmv_ms = 0.0, spmv_lean_ms = 0.0;
+  i64 spmv_launches = 0, spmv_lean_launches = 0;
+  int poly_degree = 0;      // products with Â per application of the preconditioned operator (0: plain iteration)
+  int half_exit = 0;        // 1: the solve ended at the half step of its last iteration (counted as an iteration)
 };
 
 // halo exchange of the ghost segments of `vec` (no-op on one rank)

@@ -14,14 +14,20 @@
 //   k_bicg_xrp (x += αp + ωs; r = s - ωt; p = r + β(p - ωv); (r,r))
 // With several ranks the SpMV's last block leaves the local sums, an RCCL all-reduce and k_derive follow.
 //
-// Neumann preconditioner (default where admissible, CsrMatrix::poly_ok; PG_POLY=0 turns it off): the equilibrated systems
-// of the time loop are Â = I - K with ρ(K) ≈ 0.7, so M⁻¹ = I + K = 2I - Â is a right preconditioner that costs one SpMV
-// and squares the contraction: Â M⁻¹ = I - K².  BiCGStab then needs HALF the iterations (14 -> 7 on the oracle at 32^3,
-// 10.5 -> 5.2 per step at 512^3) for the same number of SpMVs -- u = M⁻¹p is a product with the epilogue 2p - Âp (mode
-// 4, no extra vector pass), v = Âu carries the dot as before -- so the vector passes, the reductions and, with several
-// ranks, the all-reduces per time step halve.  The residual is the true residual of Âx = b̂, the stopping test unchanged:
-//   u = 2p - Âp;  v = Âu, (r̂,v);  s = r - αv;  u_s = 2s - Âs;  t = Âu_s, (t,s), (t,t), (r̂,t);
-//   x += αu + ωu_s;  r = s - ωt;  p = r + β(p - ωv)
+// Polynomial right preconditioner (default where admissible, CsrMatrix::poly_ok; opts.precond = -1 or PG_POLY=0 turns it
+// off).  The equilibrated systems of the time loop have their spectrum inside [1 - g, 1 + g], g = the Gershgorin radius
+// pg_precond.hip computes (0.72 for the benchmark's Crank-Nicolson matrix).  With λ_1..λ_m the Chebyshev nodes of that
+// interval, R(Â) = Π_k (I - Â/λ_k) is the degree-m residual polynomial of smallest maximum on it (0.29, 0.11, 0.043,
+// 0.016 for m = 2, 3, 4, 5 at g = 0.72), M⁻¹ = q(Â) = Â⁻¹(I - R(Â)) a polynomial approximation of Â⁻¹, and BiCGStab runs on
+//     C y = b̂ - Â x0,   C = Â M⁻¹ = I - R(Â),   x = x0 + q(Â) y
+// whose spectrum lies within that maximum of 1: iterations fall like 1/m while the number of products with Â stays about
+// the same -- and all but the last product of an application of C are LEAN launches (mode 4: w <- w - Âw/λ_k, one vector
+// in, one out, no dots, no BLAS-1 pass), the last one closes the chain (v = p - w_m, t = s - w_m) and carries the dots.
+// The vector passes, the reductions and, with several ranks, the all-reduces of a time step fall with the iteration
+// count.  R is applied in product form (Richardson steps), roots taken alternately from both ends of the interval so
+// that no partial product grows; y is accumulated in place of x and x recovered once per solve with the same chain
+// (mode 7 accumulates Σ_k w_(k-1)/λ_k = q(Â) y on the way).  The residual BiCGStab sees is the true residual of Âx = b̂,
+// the stopping test is unchanged.  m = 2 with both roots at 1 is the Neumann preconditioner 2I - Â of round 1.
 #include "pg_krylov.h"
 #include "pg_spmv.h"
 
@@ -68,37 +74,57 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_init(i64 n, i64 nvec, const doub
 // summed together with the dots of the SpMV that follows (one scalar kernel instead of two)
 // NTV: stream hints on the vectors that are dead after this kernel (v here; x, t, v in k_bicg_xrp), so that they do not
 // push the SpMV's matrix data (records, packed irregular rows: ~90 MB) out of the 256 MB Infinity Cache between launches
+// slot 4 = (s,s)_W, the weighted norm of the half-step convergence test (PH_BICG_S; the second product overwrites the slot
+// afterwards)
 template <bool NTV>
 __global__ __launch_bounds__(BLOCK) void k_bicg_s(i64 n, const double* __restrict__ sc, const double* __restrict__ v,
                                                   const double* __restrict__ rhat, double* __restrict__ r,
-                                                  double* __restrict__ partials) {
+                                                  double* __restrict__ partials, const double* __restrict__ ds) {
   __shared__ double s_red[BLOCK / 64];
   if (sc[S_DONE] != 0.0) return;
   const double alpha = sc[S_ALPHA];
-  double a0 = 0.0, a1 = 0.0;
+  double a0 = 0.0, a1 = 0.0, aw = 0.0;
   for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) {
     const double si = r[i] - alpha * (NTV ? __builtin_nontemporal_load(v + i) : v[i]);
     r[i] = si;
     a0 += rhat[i] * si;
     a1 += si * si;
+    const double ws = ds[i] * si;
+    aw += ws * ws;
   }
   const double t0 = block_sum(a0, s_red);
   if (threadIdx.x == 0) partials[2 * (size_t)gridDim.x + blockIdx.x] = t0;
   const double t1 = block_sum(a1, s_red);
   if (threadIdx.x == 0) partials[3 * (size_t)gridDim.x + blockIdx.x] = t1;
+  const double tw = block_sum(aw, s_red);
+  if (threadIdx.x == 0) partials[4 * (size_t)gridDim.x + blockIdx.x] = tw;
+}
+
+// the half step accepted (PH_BICG_S): x += αp, r = s stands, the iteration counts, done
+__global__ __launch_bounds__(BLOCK) void k_bicg_half(i64 n, double* sc, const double* __restrict__ p, double* __restrict__ x) {
+  if (sc[S_DONE] != 0.0 || sc[S_HALF] == 0.0) return;
+  const double alpha = sc[S_ALPHA];
+  for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) x[i] += alpha * p[i];
+}
+// (separate launch: every block of k_bicg_half must have read the flags before they change)
+__global__ void k_bicg_half_done(double* sc) {
+  if (sc[S_DONE] != 0.0 || sc[S_HALF] == 0.0) return;
+  sc[S_RR] = sc[S_RED4];
+  sc[S_ITERS] += 1.0;
+  sc[S_PENDING3] = 0.0;
+  sc[S_DONE] = 1.0;
 }
 
 // x += αp + ωs;  r = s - ωt;  p = r + β(p - ωv)  (restart: p = r̂ = r);  partial slot 1 = (r,r)_W (convergence, weights
 // ds²: pg_spmv.h), slot 2 = (r,r) (restart bookkeeping).
 // β is known before r exists because ρ_new = (r̂,r) = (r̂,s) - ω(r̂,t) comes out of the dots of k_bicg_s and of the
 // second SpMV: the classical p-update kernel (4 vector passes) and one scalar kernel per iteration disappear.
-// POLY: the search directions of the preconditioned iteration are u = M⁻¹p and us = M⁻¹s (x += αu + ωus)
-template <bool NTV, bool POLY>
+// (with the polynomial preconditioner x is the accumulated solution y of the preconditioned system)
+template <bool NTV>
 __global__ __launch_bounds__(BLOCK) void k_bicg_xrp(i64 n, double* sc, const double* __restrict__ t,
                                                     const double* __restrict__ v, double* __restrict__ x,
                                                     double* __restrict__ r, double* __restrict__ p,
                                                     double* __restrict__ rhat, double* __restrict__ partials,
-                                                    const double* __restrict__ u, const double* __restrict__ us,
                                                     const double* __restrict__ ds) {
   __shared__ double s_red[BLOCK / 64];
   if (sc[S_DONE] != 0.0) return;
@@ -107,9 +133,7 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_xrp(i64 n, double* sc, const dou
   double a0 = 0.0, aw = 0.0;
   for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) {
     const double si = r[i], pi = p[i];
-    const double du = POLY ? (NTV ? __builtin_nontemporal_load(u + i) : u[i]) : pi;
-    const double dus = POLY ? (NTV ? __builtin_nontemporal_load(us + i) : us[i]) : si;
-    const double xi = (NTV ? __builtin_nontemporal_load(x + i) : x[i]) + alpha * du + omega * dus;
+    const double xi = (NTV ? __builtin_nontemporal_load(x + i) : x[i]) + alpha * pi + omega * si;
     if (NTV) __builtin_nontemporal_store(xi, x + i); else x[i] = xi;
     const double ri = si - omega * (NTV ? __builtin_nontemporal_load(t + i) : t[i]);
     r[i] = ri;
@@ -180,6 +204,11 @@ __global__ __launch_bounds__(BLOCK) void k_cg_p(i64 n, const double* __restrict_
   for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) p[i] = r[i] + beta * p[i];
 }
 
+// x += a w  (last term of x = x0 + q(Â) y)
+__global__ __launch_bounds__(BLOCK) void k_axpy(i64 n, double a, const double* __restrict__ w, double* __restrict__ x) {
+  for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) x[i] += a * w[i];
+}
+
 // ---- scalar phase: sum block partials (deterministic order), then derive the iteration scalars (pg_spmv.h) ----
 __global__ __launch_bounds__(BLOCK) void k_finalize(int phase, int slot0, int nslots, int grid,
                                                     const double* __restrict__ partials, double* __restrict__ sc,
@@ -233,7 +262,10 @@ struct SpmvTimer {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs;
   std::vector<int> iter_of;   // Krylov iteration each launch belongs to
+  std::vector<char> lean_of;  // 1: lean launch (no dots), 0: launch with fused dots
+  std::vector<char> second_of;   // 1: launch of the second half of its iteration (skipped when the half step was accepted)
   int cur = 0;
+  bool cur_lean = false, cur_second = false;
   bool armed = false;
   explicit SpmvTimer(bool on_) : on(on_) {}
   // events are recycled through a per-thread pool: nothing is created or destroyed inside the time loop after the
@@ -253,12 +285,14 @@ struct SpmvTimer {
     PG_HIP(hipEventCreate(&e));
     return e;
   }
-  void begin(hipStream_t st, int iteration) {
+  void begin(hipStream_t st, int iteration, bool lean = false, bool second = false) {
     cur = iteration;
-    // every `sample`-th launch is bracketed (PG_PROFILE_SAMPLE, default 3 -- odd, so the two fused-dot modes of a
-    // BiCGStab iteration are sampled alternately): two event records per launch cost the stream a few microseconds
-    // each, which at 21 launches per step is a measurable share (~3 %) of what is being measured
-    static const int sample = getenv("PG_PROFILE_SAMPLE") ? std::max(1, atoi(getenv("PG_PROFILE_SAMPLE"))) : 3;
+    cur_lean = lean;
+    cur_second = second;
+    // every `sample`-th launch is bracketed (PG_PROFILE_SAMPLE, default 7 -- coprime with the 2m launches of an
+    // iteration for every degree in use, so lean and closing launches of both halves are all sampled in turn): two event
+    // records per launch cost the stream a few microseconds each, a measurable share of what is being measured
+    static const int sample = getenv("PG_PROFILE_SAMPLE") ? std::max(1, atoi(getenv("PG_PROFILE_SAMPLE"))) : 7;
     static thread_local unsigned long long counter = 0;
     armed = on && (counter++ % sample == 0);
     if (!armed) return;
@@ -271,23 +305,28 @@ struct SpmvTimer {
     PG_HIP(hipEventRecord(e1, st));
     pairs.emplace_back(e0, e1);
     iter_of.push_back(cur);
+    lean_of.push_back(cur_lean ? 1 : 0);
+    second_of.push_back(cur_second ? 1 : 0);
   }
   // launches queued after convergence return at their first instruction (done flag): they are not SpMVs and are
   // left out of the launch count and of the average
-  void collect(SolveStats& s, int iters_done) {
+  void collect(SolveStats& s, int iters_done, bool half_exit) {
     for (size_t q = 0; q < pairs.size(); ++q) {
       auto& pr = pairs[q];
       float ms = 0.f;
       (void)hipEventSynchronize(pr.second);
-      if (iter_of[q] < iters_done && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
-        s.spmv_ms += ms;
-        s.spmv_launches += 1;
+      const bool ran = iter_of[q] < iters_done && !(half_exit && iter_of[q] == iters_done - 1 && second_of[q]);
+      if (ran && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+        if (lean_of[q]) { s.spmv_lean_ms += ms; s.spmv_lean_launches += 1; }
+        else { s.spmv_ms += ms; s.spmv_launches += 1; }
       }
       pool().push_back(pr.first);
       pool().push_back(pr.second);
     }
     pairs.clear();
     iter_of.clear();
+    lean_of.clear();
+    second_of.clear();
   }
 };
 
@@ -351,14 +390,33 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
   const bool cg = opts.method == PG_METHOD_CG;
   static const bool ntv = getenv("PG_KRYLOV_NT") ? atoi(getenv("PG_KRYLOV_NT")) != 0 : true;
   static const bool poly_env = getenv("PG_POLY") ? atoi(getenv("PG_POLY")) != 0 : true;
-  // Neumann preconditioner: BiCGStab on the slice kernel, where Gershgorin bounds the spectrum inside |λ - 1| < 0.95
-  const bool poly = poly_env && opts.precond >= 0 && !cg && A.poly_ok && spmv_supports_preconditioner_product() && n > 0;
-  if (poly && w.u.n < nvec) {
-    w.u.alloc(nvec);
-    w.us.alloc(nvec);
-    w.u.zero();
-    w.us.zero();
+  static const int degree_env = getenv("PG_POLY_DEGREE") ? atoi(getenv("PG_POLY_DEGREE")) : 6;
+  // polynomial right preconditioner: BiCGStab on the slice kernel, where Gershgorin bounds the spectrum inside
+  // |λ - 1| < 0.95; m products with Â per application of C = I - R(Â)  (m < 2: the plain iteration)
+  int m = 0;
+  if (poly_env && opts.precond >= 0 && !cg && A.poly_ok && spmv_supports_preconditioner_product() && n > 0)
+    m = std::min(opts.precond > 0 ? opts.precond : degree_env, 16);
+  if (m < 2) m = 0;
+  const bool poly = m > 0;
+  stats.poly_degree = m;
+  double tau[16];
+  if (poly) {
+    // 1 / Chebyshev nodes of [1 - g, 1 + g], the largest and the smallest remaining root in turn
+    const double g = std::min(std::max(A.gersh, 0.05), 0.95);
+    double lam[16];
+    for (int k = 0; k < m; ++k) lam[k] = 1.0 + g * std::cos(M_PI * (2.0 * k + 1.0) / (2.0 * m));   // descending
+    for (int k = 0, lo = 0, hi = m - 1; k < m; ++k) tau[k] = 1.0 / ((k & 1) ? lam[hi--] : lam[lo++]);
+    if (w.ya.n < nvec) {
+      w.ya.alloc(nvec); w.wa.alloc(nvec); w.wb.alloc(nvec);
+      w.ya.zero(); w.wa.zero(); w.wb.zero();
+    }
+    PG_HIP(hipMemsetAsync(w.ya.p, 0, sizeof(double) * (size_t)nvec, st));   // y0 = 0: x = x0 + q(Â) y
   }
+  double* const xit = poly ? w.ya.p : x;   // what the iteration updates
+  // convergence is also tested after the first half of an iteration when a half costs several products (the test itself
+  // costs two small launches); PG_HALF_TEST=0/1 forces it off / on
+  static const int half_env = getenv("PG_HALF_TEST") ? atoi(getenv("PG_HALF_TEST")) : -1;
+  const bool half_test = !cg && (half_env < 0 ? m >= 3 : half_env != 0);
   PG_REQUIRE(!preinit || !cg, "preinit is a BiCGStab path");
   if (!cg) {
     if (!preinit)
@@ -376,7 +434,8 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
   // next few polls come after every iteration: no iterations are queued past convergence (each would still cost
   // its launch overheads), at the price of two or three extra stream syncs per solve.
   int launched = 0, polls = 0;
-  bool done = false;
+  bool done = false, poly_failed = false;
+  const int poly_give_up = 40 + 400 / std::max(m, 1);   // iterations; an admitted system needs 2 .. 10
   while (!done) {
     int want = check_every;
     if (w.last_iters > 1) want = polls == 0 ? w.last_iters - 1 : (polls <= 4 ? 1 : check_every);
@@ -384,39 +443,49 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
     ++polls;
     for (int it = 0; it < batch; ++it) {
       if (!cg) {
-        double* dir_p = w.p.p;     // what Â is applied to: p, or u = M⁻¹p
-        if (poly) {
-          spmv_with_halo(4, A, nb, slab, w.p.p, w.u.p, nullptr, nullptr, w.sc.p, G, st);   // u = 2p - Âp
-          dir_p = w.u.p;
-        }
-        timer.begin(st, launched + it);
-        // the scalar phase that follows an SpMV is evaluated by the last block of that launch (stencil-slice kernel);
-        // with several ranks the halo exchange of p overlaps the rows that need no ghost value (spmv_with_halo)
+        // out = C in = in - R(Â) in with the dots of `mode_last` (5: (r̂,out); 6: (out,in), (out,out), (r̂,out)); the plain
+        // iteration applies Â itself (modes 1 / 3)
         const int derive_here = (cx.nranks == 1 && !cx.comm) ? 1 : 0;
-        const FinArgs f1{w.ticket.p, w.sc.p, PH_BICG_1, 3, derive_here, nullptr};
-        const bool folded1 = spmv_with_halo(1, A, nb, slab, dir_p, w.v.p, w.rhat.p, w.partials.p, w.sc.p, G, st, &f1);   // v = Â p, (r̂,v)
-        timer.end(st);
-        // previous iteration's (r,r): convergence / restart; then α
-        if (folded1) finalize_folded(PH_BICG_1, 3, w, st); else finalize(PH_BICG_1, 3, w, st, true);
-        if (ntv) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_s<true>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_s<false>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p);
-        double* dir_s = w.r.p;     // r holds s
-        if (poly) {
-          spmv_with_halo(4, A, nb, slab, w.r.p, w.us.p, nullptr, nullptr, w.sc.p, G, st);  // us = 2s - Âs
-          dir_s = w.us.p;
+        auto apply = [&](double* in, double* out, int phase, int nslots) {
+          const bool second = phase == PH_BICG_2;
+          double* src = in;
+          for (int k = 0; k + 1 < m; ++k) {
+            double* dst = (k & 1) ? w.wb.p : w.wa.p;
+            FinArgs f{nullptr, nullptr, PH_NONE, 0, 0, nullptr};
+            f.pc0 = 1.0; f.pc1 = -tau[k];
+            timer.begin(st, launched + it, true, second);
+            spmv_with_halo(4, A, nb, slab, src, dst, nullptr, nullptr, w.sc.p, G, st, &f);   // w <- w - τ_k Â w
+            timer.end(st);
+            src = dst;
+          }
+          // the scalar phase that follows is evaluated by the last block of the launch (stencil-slice kernel); with
+          // several ranks the halo exchange of the input overlaps the rows that need no ghost value (spmv_with_halo)
+          FinArgs f{w.ticket.p, w.sc.p, phase, nslots, derive_here, nullptr};
+          int mode = phase == PH_BICG_1 ? 1 : 3;
+          if (poly) {
+            mode = phase == PH_BICG_1 ? 5 : 6;
+            f.pc0 = 1.0; f.pc1 = -tau[m - 1];
+            f.base = in;      // mode 5: out = in - (w - τ_m Â w)
+            f.dotx = in;      // mode 6: the same, `in` is the operand of the (out, in) dot as well
+          }
+          timer.begin(st, launched + it, false, second);
+          const bool folded = spmv_with_halo(mode, A, nb, slab, src, out, w.rhat.p, w.partials.p, w.sc.p, G, st, &f);
+          timer.end(st);
+          if (folded) finalize_folded(phase, nslots, w, st); else finalize(phase, nslots, w, st, true);
+        };
+        apply(w.p.p, w.v.p, PH_BICG_1, 3);     // v = C p, (r̂,v); previous iteration's (r,r): convergence / restart; then α
+        if (ntv) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_s<true>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p, (const double*)A.ds.p);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_s<false>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p, (const double*)A.ds.p);
+        if (half_test) {   // does s already meet the tolerance?  then x += αp and stop: the second half is 1 + m launches
+          finalize(PH_BICG_S, 1, w, st, true, 4);
+          hipLaunchKernelGGL(k_bicg_half, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, (const double*)w.p.p, xit);
+          hipLaunchKernelGGL(k_bicg_half_done, dim3(1), dim3(1), 0, st, w.sc.p);
         }
-        timer.begin(st, launched + it);
-        // (t, s) keeps s as its operand when t = Â us
-        const FinArgs f2{w.ticket.p, w.sc.p, PH_BICG_2, 5, derive_here, poly ? w.r.p : nullptr};
-        const bool folded2 = spmv_with_halo(3, A, nb, slab, dir_s, w.t.p, w.rhat.p, w.partials.p, w.sc.p, G, st, &f2);   // t = Â s, (t,s), (t,t), (r̂,t)
-        timer.end(st);
-        if (folded2) finalize_folded(PH_BICG_2, 5, w, st); else finalize(PH_BICG_2, 5, w, st, true);   // ω, ρ, β / restart
-#define PG_LAUNCH_X(NTV_, POLY_)                                                                                        \
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_xrp<NTV_, POLY_>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.t.p, w.v.p, x, w.r.p, \
-                     w.p.p, w.rhat.p, w.partials.p, (const double*)w.u.p, (const double*)w.us.p, (const double*)A.ds.p)
-        if (ntv) { if (poly) PG_LAUNCH_X(true, true); else PG_LAUNCH_X(true, false); }
-        else { if (poly) PG_LAUNCH_X(false, true); else PG_LAUNCH_X(false, false); }
-#undef PG_LAUNCH_X
+        apply(w.r.p, w.t.p, PH_BICG_2, 5);     // t = C s (r holds s), (t,s), (t,t), (r̂,t); then ω, ρ, β / restart
+        if (ntv) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_xrp<true>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.t.p, w.v.p, xit, w.r.p,
+                                    w.p.p, w.rhat.p, w.partials.p, (const double*)A.ds.p);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_xrp<false>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.t.p, w.v.p, xit, w.r.p,
+                                w.p.p, w.rhat.p, w.partials.p, (const double*)A.ds.p);
       } else {
         timer.begin(st, launched + it);
         spmv_with_halo(2, A, nb, slab, w.p.p, w.v.p, nullptr, w.partials.p, w.sc.p, G, st);   // v = A p ; (v.p), (v.v)
@@ -433,6 +502,35 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
     PG_HIP(hipMemcpyAsync(w.h_sc, w.sc.p, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, st));
     PG_HIP(hipStreamSynchronize(st));
     if (w.h_sc[S_DONE] != 0.0 || launched >= maxiter) done = true;
+    // safety net of the polynomial preconditioner: its roots assume a (nearly) real spectrum inside the Gershgorin
+    // interval; a matrix that defeats that assumption shows as stagnation, and the solve falls back to the plain iteration
+    // from the iterate reached (the matrix keeps the verdict)
+    if (!done && poly && launched >= poly_give_up) { poly_failed = true; done = true; }
+  }
+  if (poly) {
+    // x = x0 + q(Â) y,  q(Â) y = Σ_k τ_k w_(k-1),  w_0 = y, w_k = w_(k-1) - τ_k Â w_(k-1): the chain once more, every launch
+    // adding its term to x (mode 7), the last term by a vector kernel.  (No done flag here: it is set.)
+    double* src = w.ya.p;
+    for (int k = 0; k + 1 < m; ++k) {
+      double* dst = (k & 1) ? w.wb.p : w.wa.p;
+      FinArgs f{nullptr, nullptr, PH_NONE, 0, 0, nullptr};
+      f.pc0 = 1.0; f.pc1 = -tau[k]; f.accv = x; f.pc2 = tau[k];
+      spmv_with_halo(7, A, nb, slab, src, dst, nullptr, nullptr, nullptr, G, st, &f);
+      src = dst;
+    }
+    hipLaunchKernelGGL(k_axpy, dim3(G), dim3(BLOCK), 0, st, n, tau[m - 1], (const double*)src, x);
+    PG_HIP(hipGetLastError());
+    if (poly_failed) {
+      if (getenv("PG_DEBUG")) fprintf(stderr, "[pg_krylov] polynomial preconditioner (m = %d) stagnated after %d iterations: plain iteration\n", m, launched);
+      const_cast<CsrMatrix&>(A).poly_ok = false;
+      spmv_with_halo(0, A, nb, slab, x, w.t.p, nullptr, nullptr, nullptr, G, st);   // Â x of the iterate reached
+      timer.collect(stats, launched, false);
+      SolveStats rest;
+      krylov_solve(A, nb, slab, b, x, w, opts, rest, x, w.t.p, false);
+      stats = rest;
+      stats.iters += launched;
+      return;
+    }
   }
   if (getenv("PG_DEBUG"))
     fprintf(stderr, "[pg_krylov] done=%g iters=%g rr=%g tol2=%g rho=%g rho_old=%g alpha=%g omega=%g beta=%g red0=%g red1=%g\n",
@@ -441,9 +539,10 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
   stats.iters = (int)w.h_sc[S_ITERS];
   w.last_iters = stats.iters;
   stats.converged = w.h_sc[S_DONE] == 1.0 ? 1 : 0;
+  stats.half_exit = w.h_sc[S_HALF] != 0.0 ? 1 : 0;
   stats.resnorm = std::sqrt(cg ? w.h_sc[S_RRW] : w.h_sc[S_RR]);   // the weighted norms of the convergence test
   stats.bnorm = std::sqrt(w.h_sc[S_BB]);
-  timer.collect(stats, stats.iters);
+  timer.collect(stats, stats.iters, w.h_sc[S_HALF] != 0.0);
 }
 
 }  // namespace pg

@@ -839,6 +839,9 @@ int32_t pg_solver_run(pg_solver* s, double Tend, int32_t scheme, const pg_krylov
   double worst = 0.0;
   auto account = [&](const SolveStats& st) {
     iters += st.iters; tot.spmv_ms += st.spmv_ms; tot.spmv_launches += st.spmv_launches;
+    tot.spmv_lean_ms += st.spmv_lean_ms; tot.spmv_lean_launches += st.spmv_lean_launches;
+    tot.poly_degree = st.poly_degree;
+    tot.half_exit += st.half_exit;
     if (!st.converged) ++unconverged;
     if (st.bnorm > 0.0) worst = std::max(worst, st.resnorm / st.bnorm);
   };
@@ -870,6 +873,10 @@ int32_t pg_solver_run(pg_solver* s, double Tend, int32_t scheme, const pg_krylov
     info->spmv_launches = tot.spmv_launches;
     info->unconverged_steps = unconverged;
     info->worst_relres = worst;
+    info->spmv_lean_ms_total = tot.spmv_lean_ms;
+    info->spmv_lean_launches = tot.spmv_lean_launches;
+    info->poly_degree = tot.poly_degree;
+    info->half_exits = tot.half_exit;
   }
   PG_API_END
 }

@@ -6,7 +6,7 @@ namespace pg {
 
 // device scalar block of one Krylov solve (KrylovWork::sc)
 enum { S_RHO = 0, S_RHO_OLD, S_ALPHA, S_OMEGA, S_BETA, S_RR, S_BB, S_TOL2, S_DONE, S_ITERS, S_RELTOL2, S_ABSTOL2,
-       S_RESTART, S_RHAT2, S_FORCE, S_PENDING3, S_RRW,
+       S_RESTART, S_RHAT2, S_FORCE, S_PENDING3, S_RRW, S_HALF,
        S_RED0, S_RED1, S_RED2, S_RED3, S_RED4, S_COUNT };
 
 constexpr int BLOCK = 256;
@@ -34,7 +34,7 @@ __device__ inline double block_sum(double v, double* sh /*BLOCK/64*/) {
 
 // ---- scalar phases of the Krylov drivers (shared: evaluated by k_finalize / k_derive or by the LAST block of the
 // producing SpMV launch, see last_block_arrives) ------------------------------------------------------------------
-enum { PH_NONE = -1, PH_INIT = 0, PH_BICG_1, PH_BICG_2, PH_BICG_3, PH_CG_INIT, PH_CG_1, PH_CG_2 };
+enum { PH_NONE = -1, PH_INIT = 0, PH_BICG_1, PH_BICG_2, PH_BICG_3, PH_CG_INIT, PH_CG_1, PH_CG_2, PH_BICG_S };
 
 // Convergence is tested in the units of x.  The loop iterates on the equilibrated system Â = B⁻¹ S A S, y = S⁻¹x, whose
 // residual r̂ = B⁻¹S(b − A x) weighs every row by |a_ii|^-½: at 512^3 that is 1 for the (decoupled) Dirichlet border rows
@@ -114,6 +114,12 @@ __device__ inline void derive(int phase, double* sc) {
     case PH_BICG_3:
       if (sc[S_PENDING3] != 0.0) end_of_iteration(sc);
       break;
+    case PH_BICG_S:
+      // half step: s = r - αv already meets the tolerance (S_RED4 = (s,s)_W): x += αp and stop (k_bicg_half) -- with a
+      // polynomial of degree m in every application of the operator a whole iteration is 2m products, worth testing in
+      // the middle
+      if (sc[S_DONE] == 0.0 && sc[S_RED4] <= sc[S_TOL2]) sc[S_HALF] = 1.0;
+      break;
     case PH_CG_1:
       if (r0 == 0.0) sc[S_DONE] = 2.0; else sc[S_ALPHA] = sc[S_RR] / r0;
       break;
@@ -173,7 +179,10 @@ struct FinArgs {
   int nslots;         // partial slots [0, nslots) to sum into S_RED0..
   int do_derive;      // 0: sums only (several ranks: an all-reduce follows)
   const double* dotx; // operand of the (y, .) dot of modes 2 / 3; nullptr: the input vector x itself
-  double pc0 = 2.0, pc1 = -1.0;   // mode 4: y = pc0 x + pc1 A x  (default: the Neumann product 2x - Âx)
+  double pc0 = 2.0, pc1 = -1.0;   // modes 4..7: pc0 x + pc1 A x  (default: the Neumann product 2x - Âx)
+  const double* base = nullptr;   // mode 5: y = base - (pc0 x + pc1 A x)
+  double* accv = nullptr;         // mode 7: accv += pc2 x
+  double pc2 = 0.0;
 };
 
 // executed by every block at the end of a producing launch (after its partials are stored); nparts = partial sums per

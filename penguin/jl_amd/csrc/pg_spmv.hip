@@ -279,14 +279,45 @@ __device__ inline d2_t load_pair(const double* p) {
 // residual polynomial, or 2x - Âx (pg_krylov.hip); the ONE expression every path of the kernel uses
 __device__ inline double mode4_out(double xown, double ax, double pc0, double pc1) { return pc0 * xown + pc1 * ax; }
 
+// Launch modes of the slice kernel (MODE): what the epilogue does with s = (A x)_row.  A, B = operand vectors read at the
+// row (pa, pb below); own = x_row.
+//   0  y = s
+//   1  y = s;                         acc0 += A y                                   A = aux
+//   2  y = s;                         acc0 += A y, acc1 += y y                      A = dotx (or x)
+//   3  y = s;                         acc0 += A y, acc1 += y y, acc2 += B y         A = dotx (or x), B = aux
+//   4  y = pc0 own + pc1 s                                                          (one factor of the polynomial)
+//   5  y = B - (pc0 own + pc1 s);     acc0 += A y                                   A = aux, B = base
+//   6  y = A - (pc0 own + pc1 s);     acc0 += A y, acc1 += y y, acc2 += B y         A = dotx, B = aux
+//   7  y = pc0 own + pc1 s;           A_row += pc2 own  (A = accv, read and written)
+// 5 / 6 close a chain of mode-4 launches: v = p - R(Â)p with (r̂,v), t = s - R(Â)s with (t,s), (t,t), (r̂,t); 7 is a step of
+// the same chain that also accumulates q(Â)y = Σ τ_k w_(k-1) (pg_krylov.hip).
+template <int MODE>
+struct ModeInfo {
+  static constexpr bool OWN = MODE >= 4;
+  static constexpr bool HAS_A = MODE == 1 || MODE == 2 || MODE == 3 || MODE == 5 || MODE == 6 || MODE == 7;
+  static constexpr bool HAS_B = MODE == 3 || MODE == 5 || MODE == 6;
+  static constexpr bool DOT0 = MODE == 1 || MODE == 2 || MODE == 3 || MODE == 5 || MODE == 6;
+  static constexpr bool DOT1 = MODE == 2 || MODE == 3 || MODE == 6;
+  static constexpr bool DOT2 = MODE == 3 || MODE == 6;
+};
+
+// y of one row from its product s; a, b = the operands A, B at the row
+template <int MODE>
+__device__ __forceinline__ double mode_out(double s, double own, double a, double b, double pc0, double pc1) {
+  if (MODE == 4 || MODE == 7) return mode4_out(own, s, pc0, pc1);
+  if (MODE == 5) return b - mode4_out(own, s, pc0, pc1);
+  if (MODE == 6) return a - mode4_out(own, s, pc0, pc1);
+  return s;
+}
+
 // rows of one U (PSL = false) or P (PSL = true) slice with CNT stencil slots; rec = the slice's record (lane & 31).
 // NB batches of 128 rows: every load of the slice is issued before the first FMA (one exposed latency per slice).
 template <int CNT, int NB, bool PSL, int MODE, bool NT>
 __device__ inline void slice_rows(const SDesc& d, int nrows, int rec, const double* __restrict__ pval,
-                                  const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ aux,
-                                  const double* __restrict__ dx, int lane, double& acc0, double& acc1, double& acc2, int dbg,
-                                  double pc0, double pc1) {
-  constexpr bool DOTS = MODE >= 1 && MODE <= 3;   // MODE 4: y = 2x - Ax (the Neumann preconditioner), no dots
+                                  const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ pa,
+                                  const double* __restrict__ pb, int lane, double& acc0, double& acc1, double& acc2, int dbg,
+                                  double pc0, double pc1, double pc2) {
+  using MI = ModeInfo<MODE>;
   int o[CNT];
 #pragma unroll
   for (int j = 0; j < CNT; ++j) o[j] = (dbg & 4) ? 0 : rlane(rec, 4 + j);
@@ -329,62 +360,68 @@ __device__ inline void slice_rows(const SDesc& d, int nrows, int rec, const doub
       }
     }
   }
-  d2_t ax[NB], ax2[NB];   // ax: the vector of the first dot (aux in mode 1, x in modes 2/3); ax2: aux in mode 3
+  d2_t own[NB], ax[NB], ax2[NB];   // the row's own x, operands A and B (ModeInfo)
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    if (MODE == 1) ax[b] = load_pair<false>(aux + d.r0 + l0[b]);
-    else if (MODE == 2 || MODE == 3) ax[b] = load_pair<false>(dx + d.r0 + l0[b]);
-    else if (MODE == 4) ax[b] = load_pair<false>(x + d.r0 + l0[b]);      // the row's own x: y = 2x - Ax
-    else { ax[b].x = 0.0; ax[b].y = 0.0; }
-    if (MODE == 3) ax2[b] = load_pair<false>(aux + d.r0 + l0[b]);
-    else { ax2[b].x = 0.0; ax2[b].y = 0.0; }
+    own[b].x = own[b].y = ax[b].x = ax[b].y = ax2[b].x = ax2[b].y = 0.0;
+    if (MI::OWN) own[b] = load_pair<false>(x + d.r0 + l0[b]);
+    if (MI::HAS_A) ax[b] = load_pair<false>(pa + d.r0 + l0[b]);
+    if (MI::HAS_B) ax2[b] = load_pair<false>(pb + d.r0 + l0[b]);
   }
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    if (MODE == 4) { sum[b].x = mode4_out(ax[b].x, sum[b].x, pc0, pc1); sum[b].y = mode4_out(ax[b].y, sum[b].y, pc0, pc1); }
+    sum[b].x = mode_out<MODE>(sum[b].x, own[b].x, ax[b].x, ax2[b].x, pc0, pc1);
+    sum[b].y = mode_out<MODE>(sum[b].y, own[b].y, ax[b].y, ax2[b].y, pc0, pc1);
     const bool st = !(dbg & 8) || sum[b].x == 1.2345e-300;
     double* yp = y + d.r0 + l0[b];
+    double* ap = const_cast<double*>(pa) + d.r0 + l0[b];   // mode 7: the accumulated vector
     if (live1[b]) {
       if (st) {
         d2u_t out;
         out.x = sum[b].x; out.y = sum[b].y;
         *reinterpret_cast<d2u_t*>(yp) = out;
       }
-      if (DOTS) acc0 += ax[b].x * sum[b].x + ax[b].y * sum[b].y;
-      if (DOTS && MODE >= 2) acc1 += sum[b].x * sum[b].x + sum[b].y * sum[b].y;
-      if (MODE == 3) acc2 += ax2[b].x * sum[b].x + ax2[b].y * sum[b].y;
+      if (MODE == 7) {
+        d2u_t out;
+        out.x = ax[b].x + pc2 * own[b].x; out.y = ax[b].y + pc2 * own[b].y;
+        *reinterpret_cast<d2u_t*>(ap) = out;
+      }
+      if (MI::DOT0) acc0 += ax[b].x * sum[b].x + ax[b].y * sum[b].y;
+      if (MI::DOT1) acc1 += sum[b].x * sum[b].x + sum[b].y * sum[b].y;
+      if (MI::DOT2) acc2 += ax2[b].x * sum[b].x + ax2[b].y * sum[b].y;
     } else if (live0[b]) {
       if (st) *yp = sum[b].x;
-      if (DOTS) acc0 += ax[b].x * sum[b].x;
-      if (DOTS && MODE >= 2) acc1 += sum[b].x * sum[b].x;
-      if (MODE == 3) acc2 += ax2[b].x * sum[b].x;
+      if (MODE == 7) *ap = ax[b].x + pc2 * own[b].x;
+      if (MI::DOT0) acc0 += ax[b].x * sum[b].x;
+      if (MI::DOT1) acc1 += sum[b].x * sum[b].x;
+      if (MI::DOT2) acc2 += ax2[b].x * sum[b].x;
     }
   }
 }
 
 template <int CNT, bool PSL, int MODE, bool NT>
 __device__ inline void slice_nb(const SDesc& d, int nrows, int rec, const double* __restrict__ pval,
-                                const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ aux,
-                                const double* __restrict__ dx, int lane, double& acc0, double& acc1, double& acc2, int dbg,
-                                  double pc0, double pc1) {
-  if (!PSL && nrows > 128) slice_rows<CNT, 2, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg, pc0, pc1);
-  else slice_rows<CNT, 1, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg, pc0, pc1);
+                                const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ pa,
+                                const double* __restrict__ pb, int lane, double& acc0, double& acc1, double& acc2, int dbg,
+                                double pc0, double pc1, double pc2) {
+  if (!PSL && nrows > 128) slice_rows<CNT, 2, PSL, MODE, NT>(d, nrows, rec, pval, x, y, pa, pb, lane, acc0, acc1, acc2, dbg, pc0, pc1, pc2);
+  else slice_rows<CNT, 1, PSL, MODE, NT>(d, nrows, rec, pval, x, y, pa, pb, lane, acc0, acc1, acc2, dbg, pc0, pc1, pc2);
 }
 
 template <bool PSL, int MODE, bool NT>
 __device__ inline void slice_dispatch(int cnt, const SDesc& d, int nrows, int rec, const double* __restrict__ pval,
                                       const double* __restrict__ x, double* __restrict__ y,
-                                      const double* __restrict__ aux, const double* __restrict__ dx, int lane, double& acc0,
-                                      double& acc1, double& acc2, int dbg, double pc0, double pc1) {
+                                      const double* __restrict__ pa, const double* __restrict__ pb, int lane, double& acc0,
+                                      double& acc1, double& acc2, int dbg, double pc0, double pc1, double pc2) {
   switch (cnt) {   // wave-uniform
-    case 1: slice_nb<1, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg, pc0, pc1); break;
-    case 3: slice_nb<3, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg, pc0, pc1); break;
-    case 5: slice_nb<5, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg, pc0, pc1); break;
-    case 7: slice_nb<7, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg, pc0, pc1); break;
-    case 2: slice_nb<2, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg, pc0, pc1); break;
-    case 4: slice_nb<4, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg, pc0, pc1); break;
-    case 6: slice_nb<6, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg, pc0, pc1); break;
-    default: slice_nb<8, PSL, MODE, NT>(d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg, pc0, pc1); break;
+    case 1: slice_nb<1, PSL, MODE, NT>(d, nrows, rec, pval, x, y, pa, pb, lane, acc0, acc1, acc2, dbg, pc0, pc1, pc2); break;
+    case 3: slice_nb<3, PSL, MODE, NT>(d, nrows, rec, pval, x, y, pa, pb, lane, acc0, acc1, acc2, dbg, pc0, pc1, pc2); break;
+    case 5: slice_nb<5, PSL, MODE, NT>(d, nrows, rec, pval, x, y, pa, pb, lane, acc0, acc1, acc2, dbg, pc0, pc1, pc2); break;
+    case 7: slice_nb<7, PSL, MODE, NT>(d, nrows, rec, pval, x, y, pa, pb, lane, acc0, acc1, acc2, dbg, pc0, pc1, pc2); break;
+    case 2: slice_nb<2, PSL, MODE, NT>(d, nrows, rec, pval, x, y, pa, pb, lane, acc0, acc1, acc2, dbg, pc0, pc1, pc2); break;
+    case 4: slice_nb<4, PSL, MODE, NT>(d, nrows, rec, pval, x, y, pa, pb, lane, acc0, acc1, acc2, dbg, pc0, pc1, pc2); break;
+    case 6: slice_nb<6, PSL, MODE, NT>(d, nrows, rec, pval, x, y, pa, pb, lane, acc0, acc1, acc2, dbg, pc0, pc1, pc2); break;
+    default: slice_nb<8, PSL, MODE, NT>(d, nrows, rec, pval, x, y, pa, pb, lane, acc0, acc1, acc2, dbg, pc0, pc1, pc2); break;
   }
 }
 
@@ -430,8 +467,9 @@ struct MarchSide {   // per-plane operands besides the chain's own lines: latera
 template <int CNT, int MODE>
 __device__ __forceinline__ double march_plane(const double (&c)[CNT], int rng, int l2, double* __restrict__ yrow, const d2_t& xm,
                                               double xm_n, const d2_t& xc, const d2_t& xp, const MarchSide& sd, double pc0,
-                                              double pc1, double& acc0, double& acc1, double& acc2, int dbg) {
-  constexpr bool DOTS = MODE >= 1 && MODE <= 3;
+                                              double pc1, double pc2, double* __restrict__ arow, double& acc0, double& acc1,
+                                              double& acc2, int dbg) {
+  using MI = ModeInfo<MODE>;
   constexpr bool Y = CNT == 7;
   const double xc_nx = lane_up(xc.x), xc_ny = lane_up(xc.y), xp_n = lane_up(xp.x);
   // entry order of the assembled rows (eval_row, pg_stencil.h): +1, -1, [+lateral, -lateral,] +plane, -plane, diagonal
@@ -446,10 +484,9 @@ __device__ __forceinline__ double march_plane(const double (&c)[CNT], int rng, i
   s1 += c[j] * xp.y;  s2 += c[j] * xp_n;  ++j;
   s1 += c[j] * xm.y;  s2 += c[j] * xm_n;  ++j;
   s1 += c[j] * xc.y;  s2 += c[j] * xc_nx;
-  if (MODE == 4) {   // the row's own x: elements 2l+1, 2l+2 of the centre line
-    s1 = mode4_out(xc.y, s1, pc0, pc1);
-    s2 = mode4_out(xc_nx, s2, pc0, pc1);
-  }
+  // (the row's own x: elements 2l+1, 2l+2 of the centre line)
+  s1 = mode_out<MODE>(s1, xc.y, sd.ax.x, sd.ax2.x, pc0, pc1);
+  s2 = mode_out<MODE>(s2, xc_nx, sd.ax.y, sd.ax2.y, pc0, pc1);
   const int lo = rng & 255, hi = rng >> 8;
   const bool nost = (dbg & 32) && s1 != 1.2345e-300;   // diagnostics: no stores
   const bool allst = (dbg & 512) != 0;                  // diagnostics: every lane stores its pair (whole windows)
@@ -464,11 +501,23 @@ __device__ __forceinline__ double march_plane(const double (&c)[CNT], int rng, i
   } else if (v2) {
     yrow[1] = s2;
   }
-  if (DOTS) {
+  if (MODE == 7) {   // the accumulated vector of the chain: A_row += pc2 own
+    const double a1 = sd.ax.x + pc2 * xc.y, a2 = sd.ax.y + pc2 * xc_nx;
+    if (v1 && v2) {
+      d2u_t out;
+      out.x = a1; out.y = a2;
+      *reinterpret_cast<d2u_t*>(arow) = out;
+    } else if (v1) {
+      arow[0] = a1;
+    } else if (v2) {
+      arow[1] = a2;
+    }
+  }
+  if (MI::DOT0) {
     const double w1 = v1 ? s1 : 0.0, w2 = v2 ? s2 : 0.0;
     acc0 += (v1 ? sd.ax.x : 0.0) * w1 + (v2 ? sd.ax.y : 0.0) * w2;
-    if (MODE >= 2) acc1 += w1 * w1 + w2 * w2;
-    if (MODE == 3) acc2 += (v1 ? sd.ax2.x : 0.0) * w1 + (v2 ? sd.ax2.y : 0.0) * w2;
+    if (MI::DOT1) acc1 += w1 * w1 + w2 * w2;
+    if (MI::DOT2) acc2 += (v1 ? sd.ax2.x : 0.0) * w1 + (v2 ? sd.ax2.y : 0.0) * w2;
   }
   return xc_nx;
 }
@@ -480,8 +529,9 @@ __device__ __forceinline__ double march_plane(const double (&c)[CNT], int rng, i
 // and a copy waits for the load that fills it (2.2 us per plane, measured).
 template <int CNT, int MODE, int KK>
 __device__ __forceinline__ void march_unit(int rec, int lane, const double* __restrict__ x, double* __restrict__ y,
-                                  const double* __restrict__ aux, const double* __restrict__ dx, double pc0, double pc1,
-                                  double& acc0, double& acc1, double& acc2, int dbg) {
+                                  const double* __restrict__ pa, const double* __restrict__ pb, double pc0, double pc1,
+                                  double pc2, double& acc0, double& acc1, double& acc2, int dbg) {
+  using MI = ModeInfo<MODE>;
   constexpr bool Y = CNT == 7;
   const int amask = (dbg & 128) ? ~1 : ~0;          // diagnostics: every access 16-byte aligned (wrong results)
   const int one = (dbg & 128) ? 0 : 1;
@@ -516,24 +566,23 @@ __device__ __forceinline__ void march_unit(int rec, int lane, const double* __re
         sd[q].ym = load_pair<false>(x + rb[q] + (rlane(rec, 19 + 4 * q) & amask) + l2 + one);
         sd[q].yp = load_pair<false>(x + rb[q] + (rlane(rec, 20 + 4 * q) & amask) + l2 + one);
       }
-      if (MODE == 1) sd[q].ax = load_pair<false>(aux + rb[q] + l2 + one);
-      if (MODE == 2 || MODE == 3) sd[q].ax = load_pair<false>(dx + rb[q] + l2 + one);
-      if (MODE == 3) sd[q].ax2 = load_pair<false>(aux + rb[q] + l2 + one);
+      if (MI::HAS_A) sd[q].ax = load_pair<false>(pa + rb[q] + l2 + one);
+      if (MI::HAS_B) sd[q].ax2 = load_pair<false>(pb + rb[q] + l2 + one);
     }
   }
   double xm_n = lane_up(ln[0].x);
 #pragma unroll
   for (int q = 0; q < KK; ++q)
     xm_n = march_plane<CNT, MODE>(c, rlane(rec, 21 + 4 * q), l2, y + rb[q] + l2 + one, ln[q], xm_n, ln[q + 1], ln[q + 2], sd[q], pc0,
-                                  pc1, acc0, acc1, acc2, dbg);
+                                  pc1, pc2, const_cast<double*>(pa) + rb[q] + l2 + one, acc0, acc1, acc2, dbg);
 }
 
 template <int CNT, int MODE>
 __device__ __forceinline__ void march_dispatch(int rec, int lane, const double* __restrict__ x, double* __restrict__ y,
-                                      const double* __restrict__ aux, const double* __restrict__ dx, double pc0, double pc1,
-                                      double& acc0, double& acc1, double& acc2, int dbg) {
-  if ((rlane(rec, 0) & 255) == MARCH_K) march_unit<CNT, MODE, MARCH_K>(rec, lane, x, y, aux, dx, pc0, pc1, acc0, acc1, acc2, dbg);
-  else march_unit<CNT, MODE, MARCH_KS>(rec, lane, x, y, aux, dx, pc0, pc1, acc0, acc1, acc2, dbg);
+                                      const double* __restrict__ pa, const double* __restrict__ pb, double pc0, double pc1,
+                                      double pc2, double& acc0, double& acc1, double& acc2, int dbg) {
+  if ((rlane(rec, 0) & 255) == MARCH_K) march_unit<CNT, MODE, MARCH_K>(rec, lane, x, y, pa, pb, pc0, pc1, pc2, acc0, acc1, acc2, dbg);
+  else march_unit<CNT, MODE, MARCH_KS>(rec, lane, x, y, pa, pb, pc0, pc1, pc2, acc0, acc1, acc2, dbg);
 }
 
 template <int MODE, bool NT>
@@ -549,8 +598,12 @@ __global__ __launch_bounds__(BLOCK, 4) void k_spmv_s(i64 nslices, const int* __r
   __shared__ __attribute__((aligned(16))) double s_x[BLOCK / 64][512];   // G chunks: x[col] of every entry of the chunk
   __shared__ double s_red[BLOCK / 64];
   if (sc && sc[S_DONE] != 0.0) return;
-  constexpr bool DOTS = MODE >= 1 && MODE <= 3;
-  const double* __restrict__ dx = fin.dotx ? fin.dotx : x;   // operand of the (y, .) dot of modes 2 / 3
+  using MI = ModeInfo<MODE>;
+  constexpr bool DOTS = MI::DOT0;
+  const double* __restrict__ dx = fin.dotx ? fin.dotx : x;   // operand of the (y, .) dot of modes 2 / 3 / 6
+  // operand vectors A and B of the epilogue (ModeInfo)
+  const double* __restrict__ pa = (MODE == 1 || MODE == 5) ? aux : ((MODE == 2 || MODE == 3 || MODE == 6) ? dx : (MODE == 7 ? fin.accv : nullptr));
+  const double* __restrict__ pb = (MODE == 3 || MODE == 6) ? aux : (MODE == 5 ? fin.base : nullptr);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   double* __restrict__ sv = s_val[wave];
@@ -587,9 +640,9 @@ __global__ __launch_bounds__(BLOCK, 4) void k_spmv_s(i64 nslices, const int* __r
       const int urec_n = mrec[MARCH_REC * (un < uhi ? un : ucur) + lane];   // the next unit's record is in flight meanwhile
       if (!(dbg & 16)) {
         if (((rlane(urec, 0) >> 8) & 255) == 7)
-          march_dispatch<7, MODE>(urec, lane, x, y, aux, dx, fin.pc0, fin.pc1, acc0, acc1, acc2, dbg);
+          march_dispatch<7, MODE>(urec, lane, x, y, pa, pb, fin.pc0, fin.pc1, fin.pc2, acc0, acc1, acc2, dbg);
         else
-          march_dispatch<5, MODE>(urec, lane, x, y, aux, dx, fin.pc0, fin.pc1, acc0, acc1, acc2, dbg);
+          march_dispatch<5, MODE>(urec, lane, x, y, pa, pb, fin.pc0, fin.pc1, fin.pc2, acc0, acc1, acc2, dbg);
       }
       urec = urec_n;
     }
@@ -622,9 +675,9 @@ __global__ __launch_bounds__(BLOCK, 4) void k_spmv_s(i64 nslices, const int* __r
     const bool skip = ((dbg & 1) && type == SL_G) || ((dbg & 2) && type != SL_G);
     if (skip) {
     } else if (type == SL_U) {
-      slice_dispatch<false, MODE, NT>(cnt, d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg, fin.pc0, fin.pc1);
+      slice_dispatch<false, MODE, NT>(cnt, d, nrows, rec, pval, x, y, pa, pb, lane, acc0, acc1, acc2, dbg, fin.pc0, fin.pc1, fin.pc2);
     } else if (type == SL_P) {
-      slice_dispatch<true, MODE, NT>(cnt, d, nrows, rec, pval, x, y, aux, dx, lane, acc0, acc1, acc2, dbg, fin.pc0, fin.pc1);
+      slice_dispatch<true, MODE, NT>(cnt, d, nrows, rec, pval, x, y, pa, pb, lane, acc0, acc1, acc2, dbg, fin.pc0, fin.pc1, fin.pc2);
     } else {
       // packed irregular rows: same data flow as k_spmv_cw on the compact CSR, plus the row-id indirection
       Desc dd;
@@ -638,8 +691,8 @@ __global__ __launch_bounds__(BLOCK, 4) void k_spmv_s(i64 nslices, const int* __r
 #pragma unroll
       for (int j = 0; j < XV_IT; ++j) sv2[lane + 64 * j] = q.v[j];
       // the dot operands of the row ride with the gathers (issued before the LDS phase, not after it)
-      const double auxr = (MODE == 1 || MODE == 3) ? aux[rid] : 0.0;
-      const double xr = (MODE == 2 || MODE == 3) ? dx[rid] : (MODE == 4 ? x[rid] : 0.0);
+      const double opa = MI::HAS_A ? pa[rid] : 0.0, opb = MI::HAS_B ? pb[rid] : 0.0;
+      const double xown = MI::OWN ? x[rid] : 0.0;
       // ENTRY-parallel x gathers: lane l holds the columns of entries 4l..4l+3 (and 256 + 4l..), so neighbouring lanes
       // gather for the same or the next row and one gather instruction touches ~20 cache lines -- a row per lane (the CSR
       // kernel's way) touches 64, and the vector-memory unit serves a line per cycle.  The x values go to LDS next to the
@@ -679,14 +732,12 @@ __global__ __launch_bounds__(BLOCK, 4) void k_spmv_s(i64 nslices, const int* __r
       }
       __builtin_amdgcn_wave_barrier();
       if (live) {
-        if (MODE == 4) sum = mode4_out(xr, sum, fin.pc0, fin.pc1);
+        sum = mode_out<MODE>(sum, xown, opa, opb, fin.pc0, fin.pc1);
         y[rid] = sum;
-        if (MODE == 1) acc0 += auxr * sum;
-        if (DOTS && MODE >= 2) {
-          acc0 += sum * xr;
-          acc1 += sum * sum;
-        }
-        if (MODE == 3) acc2 += auxr * sum;
+        if (MODE == 7) const_cast<double*>(pa)[rid] = opa + fin.pc2 * xown;
+        if (MI::DOT0) acc0 += opa * sum;
+        if (MI::DOT1) acc1 += sum * sum;
+        if (MI::DOT2) acc2 += opb * sum;
       }
     }
     rec = rec_n;
@@ -700,11 +751,11 @@ __global__ __launch_bounds__(BLOCK, 4) void k_spmv_s(i64 nslices, const int* __r
     const double t0 = block_sum(acc0, s_red);
     if (threadIdx.x == 0) put_partial(partials + blockIdx.x, t0, accum);
   }
-  if (DOTS && MODE >= 2) {
+  if (MI::DOT1) {
     const double t1 = block_sum(acc1, s_red);
     if (threadIdx.x == 0) put_partial(partials + pstride + blockIdx.x, t1, accum);
   }
-  if (MODE == 3) {
+  if (MI::DOT2) {
     const double t2 = block_sum(acc2, s_red);
     if (threadIdx.x == 0) put_partial(partials + 4 * (size_t)pstride + blockIdx.x, t2, accum);
   }
@@ -820,7 +871,7 @@ template <int MODE>
 bool launch_mode(int v, const CsrMatrix& A, const double* x, double* y, const double* aux, double* partials,
                  const double* sc, int grid, hipStream_t st, const FinArgs* fin) {
   if (v & 64) return launch_slices<MODE>(v, A, 0, A.nslices, x, y, aux, partials, sc, grid, grid, 0, st, fin);
-  PG_REQUIRE(MODE != 4 && !(fin && fin->dotx), "the preconditioner product and separate dot operands need the slice kernel");
+  PG_REQUIRE(MODE < 4 && !(fin && fin->dotx), "the preconditioner products and separate dot operands need the slice kernel");
   if (v != 1) ensure_csr_chunks(A);
   if (v == 1) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv<MODE>), dim3(grid), dim3(BLOCK), 0, st, A.n, A.rowptr.p, A.col.p, A.val.p, x, y,
@@ -1385,6 +1436,10 @@ bool launch_spmv(int mode, const CsrMatrix& A, const double* x, double* y, const
   if (mode == 1) return launch_mode<1>(v, A, x, y, aux, partials, sc, grid, st, fin);
   if (mode == 2) return launch_mode<2>(v, A, x, y, aux, partials, sc, grid, st, fin);
   if (mode == 4) return launch_mode<4>(v, A, x, y, aux, partials, sc, grid, st, fin);
+  if (mode == 5) return launch_mode<5>(v, A, x, y, aux, partials, sc, grid, st, fin);
+  if (mode == 6) return launch_mode<6>(v, A, x, y, aux, partials, sc, grid, st, fin);
+  if (mode == 7) return launch_mode<7>(v, A, x, y, aux, partials, sc, grid, st, fin);
+  PG_REQUIRE(mode == 3, "unknown SpMV launch mode");
   return launch_mode<3>(v, A, x, y, aux, partials, sc, grid, st, fin);
 }
 
@@ -1407,7 +1462,7 @@ bool spmv_with_halo(int mode, const CsrMatrix& A, const Numbering& nb, const Sla
   halo_begin(nb, slab, x, st);                      // x's owned part is final on `st`; ghosts arrive on the comm stream
   bool folded;
   FinArgs fin_nofold{nullptr, nullptr, PH_NONE, 0, 0, fin ? fin->dotx : nullptr};   // first launch: dot operand, no scalar phase
-  if (fin) { fin_nofold.pc0 = fin->pc0; fin_nofold.pc1 = fin->pc1; }
+  if (fin) { fin_nofold.pc0 = fin->pc0; fin_nofold.pc1 = fin->pc1; fin_nofold.pc2 = fin->pc2; fin_nofold.base = fin->base; fin_nofold.accv = fin->accv; }
 #define PG_SPLIT(MODE_)                                                                                              \
   launch_slices<MODE_>(v, A, 0, ni, x, y, aux, partials, sc, grid, grid, 0, st, fin ? &fin_nofold : nullptr);      \
   halo_end(st);                                                                                                      \
@@ -1416,6 +1471,9 @@ bool spmv_with_halo(int mode, const CsrMatrix& A, const Numbering& nb, const Sla
   else if (mode == 1) { PG_SPLIT(1); }
   else if (mode == 2) { PG_SPLIT(2); }
   else if (mode == 4) { PG_SPLIT(4); }
+  else if (mode == 5) { PG_SPLIT(5); }
+  else if (mode == 6) { PG_SPLIT(6); }
+  else if (mode == 7) { PG_SPLIT(7); }
   else { PG_SPLIT(3); }
 #undef PG_SPLIT
   return folded;

@@ -16,6 +16,7 @@ from penguin.jl_amd import _lib as L
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 modes = [int(c) for c in sys.argv[3]] if len(sys.argv) > 3 else [0, 1, 3, 4]
+modes = [m for m in modes if m <= 4]
 pj.init(0)
 mesh = pj.Mesh((n, n, n), (4.0, 4.0, 4.0))
 cap = pj.Capacity(pj.Sphere((2.01, 2.01, 2.01), 1.0), mesh)
@@ -49,5 +50,6 @@ for mode in modes:
 if not broken:
     L.check(lib.pg_set_profiling(1))
     L.check(lib.pg_solver_run(s._h, C.c_double(1e9), C.c_int32(1), C.byref(opts), 0, C.c_int64(10), 0, C.byref(run)))
-    out.append(f"| loop: {run.steps / run.solve_ms * 1e3:6.1f} steps/s, {run.total_iters / run.steps:.2f} it/step, spmv {run.spmv_ms_total / max(run.spmv_launches, 1) * 1e3:6.1f} us")
+    out.append(f"| loop: {run.steps / run.solve_ms * 1e3:6.1f} steps/s, {run.total_iters / run.steps:.2f} it/step, m={run.poly_degree}, spmv dots "
+               f"{run.spmv_ms_total / max(run.spmv_launches, 1) * 1e3:6.1f} us lean {run.spmv_lean_ms_total / max(run.spmv_lean_launches, 1) * 1e3:6.1f} us")
 print(" ".join(out), flush=True)

@@ -10,6 +10,7 @@ import pytest
 
 from oracle import penguin_oracle as po
 from oracle.geometry import Ball, MultiBall
+from penguin.jl_amd import _lib as L
 from tests.common import oracle_capacity_from_product, rel_l2
 
 pytestmark = pytest.mark.gpu
@@ -967,30 +968,46 @@ def test_advection_diffusion_diphasic_unsteady_matches_oracle(pj):
         pj.AdvectionDiffusionUnsteadyDiph(p1, p2, bcb, ic, dt, u0, "RK4")
 
 
-def test_neumann_preconditioner_is_admitted_and_halves_the_iterations(pj):
-    """benchmark/Heat3D.jl shape at 24^3: the Gershgorin test admits the Neumann right preconditioner (radius < 0.95),
-    the first solve then takes about half the iterations the oracle's plain BiCGStab needs on the same preconditioned
-    system, and the states still match the direct solve; a steady Poisson system is not admitted (no mass term)."""
+def test_polynomial_preconditioner_is_admitted_and_follows_the_host_restatement(pj):
+    """benchmark/Heat3D.jl shape at 24^3: the Gershgorin test admits the polynomial right preconditioner (radius < 0.95).
+    For every degree the first solve takes the iterations the oracle's C restatement of the same algorithm (Chebyshev
+    residual polynomial in product form, weighted test after both halves) takes on the same preconditioned system --
+    about 1/m of the plain iteration's -- and the states still match the direct solve; a steady Poisson system is not
+    admitted (no mass term)."""
+    import os
+
+    from oracle import krylov_c
+
     n = 24
     M = (n + 1) ** 3
     keys = ("left", "right", "top", "bottom")
     dt = 0.75 * (4.0 / n) ** 2
-    (s, ph, bcb, bci), (so, oph, obcb, obci) = _mono_pair(
-        pj, 3, n, 4.0, (2.01, 2.01, 2.01), 1.0, pj.Dirichlet(1.0), po.Dirichlet(1.0),
-        {k: pj.Dirichlet(1.0) for k in keys}, {k: po.Dirichlet(1.0) for k in keys}, dt, np.zeros(2 * M), "BE")
-    info = s.system_info(2)
-    assert info.neumann_ok == 1 and 0.0 < info.gershgorin < 0.95
-    Ah, bh, _ = s.system(2)
-    Ah = Ah[:, : Ah.shape[0]].tocsr()
-    _, it_plain, _ = po.bicgstab_ref(Ah, bh, reltol=1e-12)
-    pj.solve_DiffusionUnsteadyMono_b(s, ph, dt, 3 * dt, bcb, bci, "CN", reltol=1e-12, log=True, warm_start=False)
-    po.solve_DiffusionUnsteadyMono(so, oph, dt, 3 * dt, obcb, obci, "CN", method="\\")
-    import os
-    slices = int(os.environ.get("PG_SPMV_VARIANT", "70")) & 64          # the preconditioner product lives in the slice kernel
-    if os.environ.get("PG_POLY", "1") != "0" and slices:
-        assert s.ch[0]["iters"] <= it_plain // 2 + 1, (s.ch[0]["iters"], it_plain)
-    for a, b in zip(s.states, so.states):
-        assert rel_l2(a, b) <= TOL_T
+    slices = int(os.environ.get("PG_SPMV_VARIANT", "70")) & 64          # the preconditioner products live in the slice kernel
+    on = os.environ.get("PG_POLY", "1") != "0" and bool(slices)
+    it_of = {}
+    for degree in (-1, 2, 3, 4, 6, 8):
+        (s, ph, bcb, bci), (so, oph, obcb, obci) = _mono_pair(
+            pj, 3, n, 4.0, (2.01, 2.01, 2.01), 1.0, pj.Dirichlet(1.0), po.Dirichlet(1.0),
+            {k: pj.Dirichlet(1.0) for k in keys}, {k: po.Dirichlet(1.0) for k in keys}, dt, np.zeros(2 * M), "BE")
+        info = s.system_info(2)
+        assert info.neumann_ok == 1 and 0.0 < info.gershgorin < 0.95
+        Ah, bh, _ = s.system(2)
+        Ah = Ah[:, : Ah.shape[0]].tocsr()
+        wts = np.empty(Ah.shape[0])
+        L.check(L.lib().pg_solver_get_row_scaling(s._h, 0, L.dptr(wts)))
+        _, it_ref, _, _ = krylov_c.solve_poly(Ah, bh, max(degree, 0), info.gershgorin, weights=wts, reltol=1e-12)
+        pj.solve_DiffusionUnsteadyMono_b(s, ph, dt, 3 * dt, bcb, bci, "CN", reltol=1e-12, log=True, warm_start=False,
+                                         precond=degree)
+        po.solve_DiffusionUnsteadyMono(so, oph, dt, 3 * dt, obcb, obci, "CN", method="\\")
+        it_of[degree] = s.ch[0]["iters"]
+        if on or degree < 0:
+            assert abs(s.ch[0]["iters"] - it_ref) <= 1, (degree, s.ch[0]["iters"], it_ref)
+        assert s.unconverged == 0
+        for a, b in zip(s.states, so.states):
+            assert rel_l2(a, b) <= TOL_T
+    if on:
+        for degree in (2, 3, 4, 6, 8):
+            assert it_of[degree] <= it_of[-1] // degree + 2, it_of
     # steady: spectrum reaches down to ~0, Gershgorin radius ~1: the plain iteration runs
     cap = ph.capacity
     ph2 = pj.Phase(cap, ph.operator, lambda x, y, z, t=0.0: 1.0, lambda x, y, z: 1.0)

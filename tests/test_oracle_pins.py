@@ -348,11 +348,13 @@ def test_unsteady_diphasic_advection_diffusion_reduces_to_diffusion_at_zero_velo
         po.A_diph_unstead_advdiff(q[0].operator, q[1].operator, c1, c2, D, D, ic, dt, "RK4")
 
 
-def test_neumann_right_preconditioner_halves_bicgstab_iterations():
+def test_polynomial_right_preconditioner_divides_bicgstab_iterations():
     """What pg_krylov.hip relies on, checked on the oracle's system of a 3-D CN step (benchmark/Heat3D.jl shape at 20^3):
-    with the point-equilibrated Â = I - K, BiCGStab on Â(2I - Â) = I - K² reaches the same solution in about half the
-    iterations (same number of products with Â), and the Gershgorin radius that admits it -- columns of identity rows
-    left out, rows taken in the D⁻¹A scaling -- is below 0.95 although the plain row sums are not."""
+    with the point-equilibrated Â and the Chebyshev residual polynomial R of degree m on the Gershgorin interval,
+    BiCGStab on C = I - R(Â) reaches the same solution in about 1/m of the iterations (about the same number of products
+    with Â) -- m = 2 with both roots at 1 is round 1's Neumann preconditioner 2I - Â -- and the Gershgorin radius that
+    admits it (columns of identity rows left out, rows taken in the D⁻¹A scaling) is below 0.95 although the plain row
+    sums are not."""
     import scipy.sparse as sp
 
     n = 20
@@ -370,30 +372,53 @@ def test_neumann_right_preconditioner_halves_bicgstab_iterations():
     d = 1.0 / np.sqrt(np.abs(Ar.diagonal()))
     Ah = (sp.diags(d) @ Ar @ sp.diags(d)).tocsr()
     bh = d * br
-
-    class Pre:                                   # v -> Â (2v - Âv): only `@` is asked of it by bicgstab_ref
-        shape = Ah.shape
-
-        def __matmul__(self, v):
-            return Ah @ (2.0 * v - Ah @ v)
-
-    x_plain, it_plain, _ = po.bicgstab_ref(Ah, bh, reltol=1e-12)
-    y, it_pre, _ = po.bicgstab_ref(Pre(), bh, reltol=1e-12)
-    x_pre = 2.0 * y - Ah @ y                     # x = M⁻¹ y
-    assert np.linalg.norm(x_pre - x_plain) <= 1e-10 * np.linalg.norm(x_plain)
-    assert it_pre <= it_plain // 2 + 1, (it_pre, it_plain)
-    # the admissibility test of pg_precond.hip (k_gershgorin)
     rl = np.diff(Ar.indptr)
     ident = rl == 1
     DA = (sp.diags(1.0 / np.abs(Ar.diagonal())) @ Ar).tocsr()
-    off_all = np.asarray(abs(DA).sum(axis=1)).ravel() - np.abs(DA.diagonal())
     off = np.asarray(abs(DA @ sp.diags((~ident).astype(float))).sum(axis=1)).ravel() - np.abs(DA.diagonal())
-    assert off[~ident].max() < 0.95 <= off_all.max()
+    g = off[~ident].max()
+
+    def chain(taus):
+        class Pre:                               # v -> v - Π_k (I - τ_k Â) v: only `@` is asked of it by bicgstab_ref
+            shape = Ah.shape
+
+            def __matmul__(self, v):
+                w = v
+                for tk in taus:
+                    w = w - tk * (Ah @ w)
+                return v - w
+
+        def recover(y):                          # x = q(Â) y = Σ_k τ_k w_(k-1)
+            u, w = np.zeros_like(y), y
+            for k, tk in enumerate(taus):
+                u = u + tk * w
+                if k + 1 < len(taus):
+                    w = w - tk * (Ah @ w)
+            return u
+
+        return Pre(), recover
+
+    x_plain, it_plain, _ = po.bicgstab_ref(Ah, bh, reltol=1e-12)
+    pre, recover = chain([1.0, 1.0])             # Neumann: C = Â(2I - Â) = I - (I - Â)²
+    y, it_pre, _ = po.bicgstab_ref(pre, bh, reltol=1e-12)
+    assert np.linalg.norm(recover(y) - x_plain) <= 1e-10 * np.linalg.norm(x_plain)
+    assert np.allclose(recover(y), 2.0 * y - Ah @ y, rtol=1e-13, atol=1e-15)
+    assert it_pre <= it_plain // 2 + 1, (it_pre, it_plain)
+    for m in (3, 4, 6):
+        lam = sorted(1.0 + g * math.cos(math.pi * (2 * k + 1) / (2 * m)) for k in range(m))
+        pre, recover = chain([1.0 / l for l in lam])
+        y, it_m, _ = po.bicgstab_ref(pre, bh, reltol=1e-12)
+        assert np.linalg.norm(recover(y) - x_plain) <= 1e-10 * np.linalg.norm(x_plain)
+        assert it_m <= it_plain // m + 2, (m, it_m, it_plain)
+    # the admissibility test of pg_precond.hip (k_gershgorin)
+    off_all = np.asarray(abs(DA).sum(axis=1)).ravel() - np.abs(DA.diagonal())
+    assert g < 0.95 <= off_all.max()
 
 
 def test_c_krylov_port_matches_the_numpy_restatement():
     """oracle/krylov_ref.c (what bench.py times on the host cores) against oracle/penguin_oracle.py on a cut-cell system:
-    plain BiCGStab takes the same number of iterations as bicgstab_ref, the Neumann-preconditioned variant about half and
+    plain BiCGStab takes the same number of iterations as bicgstab_ref, the polynomially preconditioned variant (the
+    iteration of pg_krylov.hip: product form, weighted test after both halves, optional warm start) about 1/m of them and
     the same solution; OpenMP threads do not change the iteration count."""
     import scipy.sparse as sp
 
@@ -414,10 +439,19 @@ def test_c_krylov_port_matches_the_numpy_restatement():
     x_ref, it_ref, _ = po.bicgstab_ref(Ah, bh, reltol=1e-12)
     x_c, it_c, res_c = krylov_c.solve(Ah, bh, "bicgstab", reltol=1e-12)
     assert it_c == it_ref and np.linalg.norm(x_c - x_ref) <= 1e-10 * np.linalg.norm(x_ref)
-    x_n, it_n, res_n = krylov_c.solve(Ah, bh, "bicgstab_neumann", reltol=1e-12)
-    assert it_n <= it_ref // 2 + 1 and res_n <= 1e-12 * np.linalg.norm(bh)
-    assert np.linalg.norm(x_n - x_ref) <= 1e-10 * np.linalg.norm(x_ref)
-    _, it_n4, _ = krylov_c.solve(Ah, bh, "bicgstab_neumann", reltol=1e-12, nthreads=4)
-    assert abs(it_n4 - it_n) <= 1
+    x_0, it_0, _, nmv_0 = krylov_c.solve_poly(Ah, bh, 0, 0.0, reltol=1e-12)          # plain, through the same routine
+    assert abs(it_0 - it_ref) <= 1 and nmv_0 <= 2 * it_0 and np.linalg.norm(x_0 - x_ref) <= 1e-10 * np.linalg.norm(x_ref)
+    for m in (2, 4, 6):
+        x_n, it_n, res_n, nmv = krylov_c.solve_poly(Ah, bh, m, 0.72, reltol=1e-12)
+        assert it_n <= it_ref // m + 2 and res_n <= 1e-12 * np.linalg.norm(bh), (m, it_n, it_ref)
+        assert nmv <= 2 * m * it_n + (m - 1)
+        assert np.linalg.norm(x_n - x_ref) <= 1e-10 * np.linalg.norm(x_ref)
+        _, it_n4, _, _ = krylov_c.solve_poly(Ah, bh, m, 0.72, reltol=1e-12, nthreads=4)
+        assert abs(it_n4 - it_n) <= 1
+    # weighted test and warm start: a tighter criterion in the units of x, fewer iterations from a good guess
+    x_w, it_w, _, _ = krylov_c.solve_poly(Ah, bh, 4, 0.72, weights=d, reltol=1e-12)
+    assert np.linalg.norm(d * (x_w - x_ref)) <= 1e-11 * np.linalg.norm(d * x_ref)
+    x_s, it_s, _, _ = krylov_c.solve_poly(Ah, bh, 4, 0.72, x0=x_ref * (1.0 + 1e-6), weights=d, reltol=1e-12)
+    assert it_s < it_w and np.linalg.norm(d * (x_s - x_ref)) <= 1e-11 * np.linalg.norm(d * x_ref)
     y = krylov_c.spmv(Ah, bh, nthreads=2)
     assert np.allclose(y, Ah @ bh, rtol=1e-14, atol=1e-14 * np.abs(bh).max())
