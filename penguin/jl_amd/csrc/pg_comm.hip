@@ -1,8 +1,9 @@
 // pg_comm.hip -- the only place that talks to RCCL (C1/C2/C3 of SURVEY.md section 2.3).
 //
 // Two backends behind the same four calls:
-//   * RCCL over xGMI (production): one process per GPU; collectives and nearest-neighbour send/recv are
-//     enqueued on the compute stream, no host synchronisation.
+//   * RCCL over xGMI (production): one process per GPU, two communicators each driven from one stream: `comm` for the
+//     reductions (compute stream) and `comm_halo` for the nearest-neighbour send/recv (communication stream, forked off
+//     and joined back to the compute stream with events); no host synchronisation.
 //   * LocalComm (diagnostics): N "virtual ranks" = N host threads of ONE process sharing one GPU, exchanging
 //     through device-to-device copies and pthread barriers.  It exists so that the slab partition, the ghost
 //     numbering and every send/recv offset of the multi-GPU path can be verified bit for bit on a 1-GPU box
@@ -105,7 +106,9 @@ void halo_exchange(const Numbering& nb, const Slab& slab, double* vec, hipStream
     lc->barrier();                      // nobody overwrites a source before it has been copied
     return;
   }
-  rccl_halo(nb, slab, vec, st);
+  // RCCL: always on the communication stream (the halo communicator is never driven from the compute stream)
+  halo_begin(nb, slab, vec, st);
+  halo_end(st);
 }
 
 void halo_begin(const Numbering& nb, const Slab& slab, double* vec, hipStream_t st) {
@@ -133,12 +136,12 @@ static void rccl_halo(const Numbering& nb, const Slab& slab, double* vec, hipStr
   PG_NCCL(ncclGroupStart());
   for (int k = 0; k < nb.K; ++k) {
     if (has_lo) {
-      if (nb.sendL_cnt[k] > 0) PG_NCCL(ncclSend(vec + nb.sendL_off[k], nb.sendL_cnt[k], ncclDouble, cx.rank - 1, cx.comm, st));
-      if (nb.cntL[k] > 0) PG_NCCL(ncclRecv(vec + nb.offL[k], nb.cntL[k], ncclDouble, cx.rank - 1, cx.comm, st));
+      if (nb.sendL_cnt[k] > 0) PG_NCCL(ncclSend(vec + nb.sendL_off[k], nb.sendL_cnt[k], ncclDouble, cx.rank - 1, cx.comm_halo, st));
+      if (nb.cntL[k] > 0) PG_NCCL(ncclRecv(vec + nb.offL[k], nb.cntL[k], ncclDouble, cx.rank - 1, cx.comm_halo, st));
     }
     if (has_hi) {
-      if (nb.sendU_cnt[k] > 0) PG_NCCL(ncclSend(vec + nb.sendU_off[k], nb.sendU_cnt[k], ncclDouble, cx.rank + 1, cx.comm, st));
-      if (nb.cntU[k] > 0) PG_NCCL(ncclRecv(vec + nb.offU[k], nb.cntU[k], ncclDouble, cx.rank + 1, cx.comm, st));
+      if (nb.sendU_cnt[k] > 0) PG_NCCL(ncclSend(vec + nb.sendU_off[k], nb.sendU_cnt[k], ncclDouble, cx.rank + 1, cx.comm_halo, st));
+      if (nb.cntU[k] > 0) PG_NCCL(ncclRecv(vec + nb.offU[k], nb.cntU[k], ncclDouble, cx.rank + 1, cx.comm_halo, st));
     }
   }
   PG_NCCL(ncclGroupEnd());

@@ -69,7 +69,8 @@ struct Context {
   hipStream_t comm_stream = nullptr; // halo exchange stream (overlaps interior SpMV rows)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // compute stream -> comm stream -> compute stream (halo_begin / halo_end)
   int rank = 0, nranks = 1;
-  ncclComm_t comm = nullptr;
+  ncclComm_t comm = nullptr;         // reductions of the Krylov scalars and set-up collectives: compute stream ONLY
+  ncclComm_t comm_halo = nullptr;    // ghost-plane send / recv: communication stream ONLY (ncclCommSplit of comm)
   bool profiling = false;
   std::string device_name;
 };

@@ -83,6 +83,12 @@ int32_t pg_init_distributed(int32_t device_id, int32_t rank, int32_t nranks, con
     ncclUniqueId id;
     std::memcpy(&id, unique_id128, sizeof(id));
     PG_NCCL(ncclCommInitRank(&c.comm, nranks, id, rank));
+    // A communicator of its own for the halos: each communicator is then driven from exactly ONE stream (comm: compute
+    // stream, comm_halo: communication stream), so nothing rests on how RCCL orders operations that one communicator
+    // receives from two streams.  Both are used by every rank in the same program order, and a halo exchange is never in
+    // flight together with a reduction (halo_end joins the compute stream before the launch whose dots are reduced; the
+    // next exchange forks off the compute stream after that reduction): no two RCCL kernels can wait for each other.
+    PG_NCCL(ncclCommSplit(c.comm, 0, rank, &c.comm_halo, nullptr));
   }
   PG_API_END
 }
@@ -92,6 +98,7 @@ int32_t pg_finalize(void) {
   Context& c = ctx();
   if (c.inited) {
     (void)hipDeviceSynchronize();
+    if (c.comm_halo) { (void)ncclCommDestroy(c.comm_halo); c.comm_halo = nullptr; }
     if (c.comm) { (void)ncclCommDestroy(c.comm); c.comm = nullptr; }
     if (c.stream) { (void)hipStreamDestroy(c.stream); c.stream = nullptr; }
     if (c.comm_stream) { (void)hipStreamDestroy(c.comm_stream); c.comm_stream = nullptr; }
