@@ -355,3 +355,70 @@ class MultiBall:
         plo[d] = s
         phi[d] = s
         return self._pick(plo, phi).section(d, s, lo, hi)
+
+
+class HalfSpace:
+    """Level set f(x) = sign * (x[axis] - pos); fluid where f < 0 (f > 0 if complement) -- the reference's 1-D diphasic
+    bodies `(x, _=0) -> (x - xint)` (/root/reference/test/convergence_test.jl:111-112,230-231) and their extrusions.
+    Capacities are exact: a cut cell is the box cut by one axis-aligned plane."""
+
+    def __init__(self, axis: int, pos: float, sign: float = 1.0, complement: bool = False, N: int = 1):
+        self.axis, self.pos = int(axis), float(pos)
+        self.sign = -1.0 if sign < 0 else 1.0
+        self.complement = bool(complement)
+        self.N = N
+
+    def __call__(self, *x):
+        f = self.sign * (x[self.axis] - self.pos)
+        return -f if self.complement else f
+
+    def _interval(self, lo: float, hi: float):
+        below = (self.sign > 0.0) != self.complement          # fluid = {x < pos}
+        if below:
+            if hi <= self.pos:
+                return FULL, lo, hi
+            if lo >= self.pos:
+                return EMPTY, lo, hi
+            return CUT, lo, self.pos
+        if lo >= self.pos:
+            return FULL, lo, hi
+        if hi <= self.pos:
+            return EMPTY, lo, hi
+        return CUT, self.pos, hi
+
+    def box(self, lo, hi, want_surface=True) -> BoxMeasure:
+        n = len(lo)
+        ext = [hi[d] - lo[d] for d in range(n)]
+        ctr = tuple(0.5 * (lo[d] + hi[d]) for d in range(n))
+        zero = tuple(0.0 for _ in range(n))
+        t, flo, fhi = self._interval(lo[self.axis], hi[self.axis])
+        if any(e <= 0.0 for e in ext):
+            return BoxMeasure(t, 0.0, ctr, 0.0, zero)
+        if t != CUT:
+            return BoxMeasure(t, _prod(ext) if t == FULL else 0.0, ctr, 0.0, zero)
+        others = [ext[d] for d in range(n) if d != self.axis]
+        cross = _prod(others) if others else 1.0
+        cen = list(ctr)
+        cen[self.axis] = 0.5 * (flo + fhi)
+        cg = list(ctr)
+        cg[self.axis] = self.pos
+        return BoxMeasure(CUT, (fhi - flo) * cross, tuple(cen), cross, tuple(cg))
+
+    def section(self, d: int, s: float, lo, hi) -> float:
+        n = len(lo)
+        others = [k for k in range(n) if k != d]
+        full = _prod([hi[k] - lo[k] for k in others]) if others else 1.0
+        if d == self.axis:
+            f = self.sign * (s - self.pos)
+            f = -f if self.complement else f
+            return full if f <= 0.0 else 0.0
+        t, flo, fhi = self._interval(lo[self.axis], hi[self.axis])
+        if t == FULL:
+            return full
+        if t == EMPTY:
+            return 0.0
+        m = fhi - flo
+        for k in others:
+            if k != self.axis:
+                m = m * (hi[k] - lo[k])
+        return m

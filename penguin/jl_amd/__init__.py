@@ -12,8 +12,8 @@ from .api import (  # noqa: F401
     solve_AdvectionDiffusionSteadyDiph_b, solve_AdvectionDiffusionSteadyMono_b, solve_AdvectionDiffusionUnsteadyMono_b,
     BorderConditions, Capacity, Circle, DarcyFlow, DarcyFlowUnsteady, DiffusionOps, DiffusionSteadyDiph, DiffusionSteadyMono, DiffusionUnsteadyDiph,
     DiffusionUnsteadyMono, Dirichlet,
-    FluxJump, InterfaceConditions, Mesh, MultiSphere, Neumann, Periodic, Phase, Robin, ScalarJump, Solver, Sphere,
-    check_convergence, div, grad, lp_norm, nC, solve_DarcyFlow_b, solve_DarcyFlowUnsteady_b, solve_darcy_velocity, solve_DiffusionSteadyDiph_b, solve_DiffusionSteadyMono_b,
+    FluxJump, HalfSpace, InterfaceConditions, Mesh, MultiSphere, Neumann, Periodic, Phase, Robin, ScalarJump, Solver, Sphere,
+    check_convergence, check_convergence_diph, div, grad, lp_norm, nC, solve_DarcyFlow_b, solve_DarcyFlowUnsteady_b, solve_darcy_velocity, solve_DiffusionSteadyDiph_b, solve_DiffusionSteadyMono_b,
     solve_DiffusionUnsteadyDiph_b, solve_DiffusionUnsteadyMono_b,
 )
 from .utils import (  # noqa: F401,E402

@@ -144,6 +144,27 @@ class MultiSphere:
         return L.PG_BODY_MULTIBALL, np.array(flat), 0
 
 
+class HalfSpace:
+    """Tagged level set f(x) = sign * (x[axis] - position) (fluid where f < 0), evaluated in-kernel: the reference's 1-D
+    diphasic bodies `(x, _=0) -> (x - xint)` / `-(x - xint)` (test/convergence_test.jl:111-112,230-231) and their
+    extrusions to 2-D / 3-D.  `axis` is 0-based; `complement=True` gives -f."""
+
+    def __init__(self, axis: int, position: float, sign: float = 1.0, complement: bool = False):
+        self.axis, self.position = int(axis), float(position)
+        self.sign = -1.0 if sign < 0 else 1.0
+        self.complement = bool(complement)
+
+    def __call__(self, *x):
+        f = self.sign * (np.asarray(x[self.axis]) - self.position)
+        return -f if self.complement else f
+
+    def _abi(self, N: int):
+        if not 0 <= self.axis < N:
+            raise ValueError("body axis does not exist on this mesh")
+        return (L.PG_BODY_HALFSPACE, np.array([float(self.axis), self.position, self.sign]),
+                (L.PG_FLAG_COMPLEMENT if self.complement else 0))
+
+
 # =============================================================================== Capacity
 
 
@@ -1185,3 +1206,23 @@ def check_convergence(u_analytical: Callable, solver: Solver, capacity: Capacity
     sel = lambda m: np.flatnonzero(m)
     return (u_ana, u_num, lp_norm(err, sel((ct == 1) | (ct == -1)), p, capacity), lp_norm(err, sel(ct == 1), p, capacity),
             lp_norm(err, sel(ct == -1), p, capacity), lp_norm(err, sel(ct == 0), p, capacity))
+
+
+def check_convergence_diph(u1_analytical: Callable, u2_analytical: Callable, solver: Solver, capacity1: Capacity,
+                           capacity2: Capacity, p=2):
+    """src/convergence.jl:114-234 (absolute norms): ((u1_ana, u2_ana), (u1_num, u2_num), global, full, cut, empty), each error
+    entry a triple (phase 1, phase 2, max of both)."""
+    M = len(capacity1.V)
+    x = solver.states[-1] if solver.states else solver.x
+    u_num = (x[:M], x[2 * M:3 * M])
+    out_ana, errs = [], []
+    for cap, ua, un in ((capacity1, u1_analytical, u_num[0]), (capacity2, u2_analytical, u_num[1])):
+        ana = np.array([ua(*c) for c in cap.C_ω], dtype=np.float64)
+        err = ana - un
+        ct = cap.cell_types
+        sel = lambda m: np.flatnonzero(m)
+        out_ana.append(ana)
+        errs.append((lp_norm(err, sel((ct == 1) | (ct == -1)), p, cap), lp_norm(err, sel(ct == 1), p, cap),
+                     lp_norm(err, sel(ct == -1), p, cap), lp_norm(err, sel(ct == 0), p, cap)))
+    trip = lambda k: (errs[0][k], errs[1][k], max(errs[0][k], errs[1][k]))
+    return tuple(out_ana), u_num, trip(0), trip(1), trip(2), trip(3)

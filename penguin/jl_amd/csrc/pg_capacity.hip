@@ -394,6 +394,15 @@ int32_t pg_capacity_create_levelset(pg_mesh* m, int32_t body_kind, const double*
     PG_REQUIRE(!bs.complement, "PG_BODY_MULTIBALL: complement not supported");
     for (int s = 0; s < bs.nballs; ++s)
       for (int d = 0; d < N; ++d) bs.c[s][d] = params[2 + s * N + d];
+  } else if (body_kind == PG_BODY_HALFSPACE) {
+    PG_REQUIRE(nparams == 3, "PG_BODY_HALFSPACE expects params = {axis (0-based), position, sign}");
+    bs.kind = BODY_HALFSPACE;
+    bs.axis = (int)params[0];
+    bs.pos = params[1];
+    bs.sgn = params[2] < 0.0 ? -1.0 : 1.0;
+    bs.nballs = 1;
+    bs.r = 1.0;
+    PG_REQUIRE(bs.axis >= 0 && bs.axis < N && (double)bs.axis == params[0], "PG_BODY_HALFSPACE: axis must be 0 .. N-1");
   } else {
     throw Error("pg_capacity_create_levelset: unknown body kind (arbitrary bodies: use pg_capacity_create_from_arrays)");
   }

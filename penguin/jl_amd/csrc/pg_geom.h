@@ -34,12 +34,19 @@ struct GLTable {
   double w[NGL];
 };
 
+constexpr int BODY_BALLS = 0, BODY_HALFSPACE = 1;
+
 struct BallSet {
   int N;          // spatial dimension 1..3
   int nballs;
-  int complement; // fluid outside the ball(s)
+  int complement; // fluid outside the ball(s) / on the other side of the plane
   double r;
   double c[MAX_BALLS][3];
+  // axis-aligned half space (kind == BODY_HALFSPACE): level set f(x) = sgn (x_axis - pos), fluid where f < 0 -- the
+  // reference's 1-D diphasic bodies `(x, _=0) -> x - xint` (test/convergence_test.jl:111,230) and their N-D extrusions
+  int kind;
+  int axis;
+  double pos, sgn;
 };
 
 struct BoxMeasure {
@@ -300,8 +307,32 @@ PG_HD double prod_ext(const double* lo, const double* hi, int N, int skip) {
   return first ? 1.0 : p;
 }
 
+// ---- axis-aligned half space ---------------------------------------------------------------------------------
+// fluid part [flo, fhi] of the interval [lo, hi] along the axis (compare-only: the oracle reproduces it bit for bit)
+// with_complement = false: the type with respect to the body as given (what pick_ball returns: its callers apply the
+// complement themselves, as for balls)
+PG_HD int hs_interval(const BallSet& bs, double lo, double hi, double& flo, double& fhi, bool with_complement = true) {
+  const bool below = (bs.sgn > 0.0) != (with_complement && bs.complement != 0);   // fluid = {x < pos} (true) or {x > pos}
+  flo = lo; fhi = hi;
+  if (below) {
+    if (hi <= bs.pos) return PG_FULL;
+    if (lo >= bs.pos) return PG_EMPTY;
+    fhi = bs.pos;
+  } else {
+    if (lo >= bs.pos) return PG_FULL;
+    if (hi <= bs.pos) return PG_EMPTY;
+    flo = bs.pos;
+  }
+  return PG_CUT;
+}
+
 // pick the ball a box can meet (balls are pairwise disjoint): first non-EMPTY, else the last one
 PG_HD int pick_ball(const BallSet& bs, const double* lo, const double* hi, int& type) {
+  if (bs.kind == BODY_HALFSPACE) {
+    double flo, fhi;
+    type = hs_interval(bs, lo[bs.axis], hi[bs.axis], flo, fhi, false);
+    return 0;
+  }
   int t = PG_EMPTY;
   for (int s = 0; s < bs.nballs; ++s) {
     t = ball_box_type(bs.c[s], bs.r, lo, hi, bs.N);
@@ -330,6 +361,28 @@ PG_HD BoxMeasure box_measure(const BallSet& bs, const double* lo, const double* 
   }
   int t;
   const int s = pick_ball(bs, lo, hi, t);
+  if (bs.kind == BODY_HALFSPACE) {
+    if (bs.complement && t != PG_CUT) t = 1 - t;
+    o.type = t;
+    if (degenerate || t != PG_CUT) {
+      o.vol = (!degenerate && t == PG_FULL) ? prod_ext(lo, hi, N, -1) : 0.0;
+      return o;
+    }
+    double flo, fhi;   // closed form: lane 0 of a cooperating group contributes all of it
+    hs_interval(bs, lo[bs.axis], hi[bs.axis], flo, fhi);
+    const double cross = prod_ext(lo, hi, N, bs.axis);
+    Mom m;
+    m.vol = qlane == 0 ? (fhi - flo) * cross : 0.0;
+    m.gamma = qlane == 0 ? cross : 0.0;
+    for (int d = 0; d < 3; ++d) m.m[d] = m.gm[d] = 0.0;
+    group(m);
+    o.vol = m.vol;
+    o.gamma = m.gamma;
+    o.cen[bs.axis] = 0.5 * (flo + fhi);
+    for (int d = 0; d < N; ++d) o.cg[d] = o.cen[d];
+    o.cg[bs.axis] = bs.pos;
+    return o;
+  }
   if (degenerate || t != PG_CUT) {
     if (bs.complement && t != PG_CUT) t = 1 - t;
     o.type = t;
@@ -366,6 +419,26 @@ PG_HD double section_measure(const BallSet& bs, int d, double s, const double* l
   plo[d] = s; phi[d] = s;
   int t;
   const int sb = pick_ball(bs, plo, phi, t);
+  if (bs.kind == BODY_HALFSPACE) {
+    // the section is a point (N = 1), or a box of N - 1 dimensions cut by the same plane (d != axis), or lies in a
+    // plane x_axis = s that is fluid or not as a whole (a section IN the interface plane counts as fluid, f <= 0, as
+    // the ball's 1-D rule does)
+    if (d == bs.axis) {
+      double f = bs.sgn * (s - bs.pos);
+      if (bs.complement) f = -f;
+      if (N == 1) return f <= 0.0 ? 1.0 : 0.0;
+      return f <= 0.0 ? (full_measure >= 0.0 ? full_measure : prod_ext(lo, hi, N, d)) : 0.0;
+    }
+    if (bs.complement && t != PG_CUT) t = 1 - t;
+    if (t == PG_FULL) return full_measure >= 0.0 ? full_measure : prod_ext(lo, hi, N, d);
+    if (t == PG_EMPTY) return 0.0;
+    double flo, fhi;
+    hs_interval(bs, lo[bs.axis], hi[bs.axis], flo, fhi);
+    double m = fhi - flo;
+    for (int k = 0; k < N; ++k)
+      if (k != d && k != bs.axis) m = m * (hi[k] - lo[k]);
+    return m;
+  }
   const double* c = bs.c[sb];
   if (N == 1) {
     double f = fabs(s - c[0]) - bs.r;

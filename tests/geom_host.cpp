@@ -10,7 +10,7 @@ extern "C" {
 void geom_box(int N, int nballs, int complement, double r, const double* centers, const double* lo,
               const double* hi, int want_surface, double* out) {
   init();
-  BallSet bs; bs.N = N; bs.nballs = nballs; bs.complement = complement; bs.r = r;
+  BallSet bs; bs.kind = BODY_BALLS; bs.axis = 0; bs.pos = 0.0; bs.sgn = 1.0; bs.N = N; bs.nballs = nballs; bs.complement = complement; bs.r = r;
   for (int s = 0; s < nballs; ++s) for (int d = 0; d < N; ++d) bs.c[s][d] = centers[s * N + d];
   BoxMeasure m = box_measure(bs, lo, hi, want_surface != 0, g_gl);
   out[0] = m.type; out[1] = m.vol; out[2] = m.cen[0]; out[3] = m.cen[1]; out[4] = m.cen[2];
@@ -19,7 +19,7 @@ void geom_box(int N, int nballs, int complement, double r, const double* centers
 double geom_section(int N, int nballs, int complement, double r, const double* centers, int d, double s,
                     const double* lo, const double* hi) {
   init();
-  BallSet bs; bs.N = N; bs.nballs = nballs; bs.complement = complement; bs.r = r;
+  BallSet bs; bs.kind = BODY_BALLS; bs.axis = 0; bs.pos = 0.0; bs.sgn = 1.0; bs.N = N; bs.nballs = nballs; bs.complement = complement; bs.r = r;
   for (int k = 0; k < nballs; ++k) for (int q = 0; q < N; ++q) bs.c[k][q] = centers[k * N + q];
   return section_measure(bs, d, s, lo, hi);
 }
