@@ -1,25 +1,32 @@
 # PenguinHIP.jl -- drop-in replacement of Penguin.jl's hot path
-#     Mesh -> Capacity -> DiffusionOps -> Phase -> DiffusionUnsteadyMono -> solve_DiffusionUnsteadyMono!
-# on AMD MI355X: same exported names, positional/keyword signatures and field names as Penguin.jl
-# (src/Penguin.jl:25-75), every numeric operation done by libpenguin_hip.so through `ccall`
+#     Mesh -> Capacity -> DiffusionOps -> Phase -> DiffusionUnsteadyMono / Diph -> solve_DiffusionUnsteady*!
+# (and the steady twins) on AMD MI355X: same exported names, positional / keyword signatures and field names as
+# Penguin.jl (src/Penguin.jl:25-75); every numeric operation is done by libpenguin_hip.so through `ccall`
 # (C ABI: include/penguin_hip.h).
 #
-# NOTE: there is no Julia in the authoring container, so this file has never been executed; it is the
-# reference-side binding a maintainer would add (INTEGRATION.md).  The Python mirror
-# penguin/jl_amd/api.py binds the SAME symbols with ctypes and is what the test-suite drives.
+# STATUS: there is no Julia in the authoring container (`which julia` is empty), so this file has never been parsed or
+# executed.  It is the reference-side binding a maintainer would add (INTEGRATION.md); the Python mirror
+# penguin/jl_amd/api.py binds the SAME symbols with ctypes, follows the same steps in the same order and is what the
+# test-suite drives on the GPU.  Everything a caller can reach below is bound to the ABI -- nothing is stubbed; inputs
+# the GPU path cannot take (arbitrary level-set closures) raise instead of being replaced by something else.
 module PenguinHIP
 
-using SparseArrays, StaticArrays
+using SparseArrays, StaticArrays, LinearAlgebra
 
-export Mesh, nC, Capacity, Sphere, MultiSphere, DiffusionOps, Phase, Dirichlet, Neumann, Robin, Periodic,
-       ScalarJump, FluxJump, BorderConditions, InterfaceConditions, Solver, DiffusionUnsteadyMono,
-       solve_DiffusionUnsteadyMono!, ∇, ∇₋
+export Mesh, nC, Capacity, capacity_from_arrays, Sphere, MultiSphere, HalfSpace, DiffusionOps, Phase,
+       Dirichlet, Neumann, Robin, Periodic, ScalarJump, FluxJump, BorderConditions, InterfaceConditions, Solver,
+       DiffusionUnsteadyMono, solve_DiffusionUnsteadyMono!, DiffusionUnsteadyDiph, solve_DiffusionUnsteadyDiph!,
+       DiffusionSteadyMono, solve_DiffusionSteadyMono!, DiffusionSteadyDiph, solve_DiffusionSteadyDiph!,
+       ConvectionOps, AdvectionDiffusionSteadyMono, solve_AdvectionDiffusionSteadyMono!, AdvectionDiffusionSteadyDiph,
+       solve_AdvectionDiffusionSteadyDiph!, AdvectionDiffusionUnsteadyMono, solve_AdvectionDiffusionUnsteadyMono!,
+       AdvectionDiffusionUnsteadyDiph, solve_AdvectionDiffusionUnsteadyDiph!,
+       ∇, ∇₋, gmres, bicgstabl, cg
 
 const libpg = get(ENV, "PENGUIN_HIP_LIB", joinpath(@__DIR__, "..", "penguin", "jl_amd", "lib", "libpenguin_hip.so"))
 
 function check(status::Int32)
     if status != 0
-        buf = Vector{UInt8}(undef, 4096)
+        buf = zeros(UInt8, 4096)
         ccall((:pg_last_error, libpg), Int32, (Ptr{UInt8}, Csize_t), buf, length(buf))
         error(unsafe_string(pointer(buf)))          # Penguin.jl raises with error(...) too
     end
@@ -31,6 +38,48 @@ function init(device::Integer=0)
     _initialised[] && return
     check(ccall((:pg_init, libpg), Int32, (Int32,), device))
     _initialised[] = true
+    nothing
+end
+
+# Markers with IterativeSolvers' names: `method = gmres` (the default of solve_system!, src/solver.jl:158), `bicgstabl`, `cg`.
+# Passing the real IterativeSolvers functions works too: only the NAME of the function is looked at.
+function gmres end
+function bicgstabl end
+function cg end
+# method -> PG_METHOD_*: cg -> 1, gmres -> 2 (restarted GMRES on the device), everything else (`\`, bicgstabl) -> 0 = BiCGStab
+function _method_id(m)
+    n = m isa Symbol ? String(m) : (m isa Function ? String(nameof(m)) : "")
+    n == "cg" ? Int32(1) : (n == "gmres" ? Int32(2) : Int32(0))
+end
+
+# ---------------------------------------------------------------------------------- plain structs of the ABI
+struct pg_bc_desc; kind::Int32; alpha::Float64; beta::Float64; value::Float64; value_array::Ptr{Float64}; end
+struct pg_border_desc; key::Int32; kind::Int32; value::Float64; end
+struct pg_jump_desc
+    alpha1::Float64; alpha2::Float64; g::Float64; beta1::Float64; beta2::Float64; h::Float64
+    g_array::Ptr{Float64}; h_array::Ptr{Float64}
+end
+struct pg_krylov_opts
+    method::Int32; reltol::Float64; abstol::Float64; maxiter::Int32; check_every::Int32; warm_start::Int32
+    restart::Int32; precond::Int32
+end
+mutable struct pg_step_info
+    iters::Int32; converged::Int32; resnorm::Float64; bnorm::Float64; extremum::Float64; time::Float64
+    pg_step_info() = new(0, 0, 0.0, 0.0, 0.0, 0.0)
+end
+mutable struct pg_run_info
+    steps::Int64; total_iters::Int64; t_final::Float64; extremum::Float64; solve_ms::Float64
+    spmv_ms_total::Float64; spmv_launches::Int64; unconverged_steps::Int64; worst_relres::Float64
+    spmv_lean_ms_total::Float64; spmv_lean_launches::Int64; poly_degree::Int64; half_exits::Int64
+    pg_run_info() = new(0, 0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0.0, 0.0, 0, 0, 0)
+end
+# kwargs... of solve_system! (src/solver.jl:158-188) -> the options of the device Krylov solve.  reltol defaults to 1e-12,
+# not IterativeSolvers' sqrt(eps): the parity target is the direct-solve path; warm_start and precond are not in the
+# reference (warm_start=false, precond=-1 give IterativeSolvers' plain iteration from a zero initial guess)
+function _opts(method, kw; warm_default::Bool=true)
+    pg_krylov_opts(_method_id(method), Float64(get(kw, :reltol, 1e-12)), Float64(get(kw, :abstol, 0.0)),
+                   Int32(get(kw, :maxiter, 0)), Int32(4), Int32(get(kw, :warm_start, warm_default) ? 1 : 0),
+                   Int32(get(kw, :restart, 0)), Int32(get(kw, :precond, 0)))
 end
 
 # ---------------------------------------------------------------------------------- Mesh  (src/mesh.jl:41-79)
@@ -41,39 +90,79 @@ abstract type AbstractMesh end
 mutable struct Mesh{N} <: AbstractMesh
     centers::NTuple{N, Vector{Float64}}
     nodes::NTuple{N, Vector{Float64}}
-    tag::MeshTag
+    tag::MeshTag{N}
     dims::NTuple{N, Int}
+    border_keys::Vector{Int32}        # PG_KEY_* of every border cell, in tag.border_cells order (not a Penguin.jl field)
     handle::Ptr{Cvoid}
 end
 function Mesh(n::NTuple{N, Int}, domain_size::NTuple{N, Float64}, x0::NTuple{N, Float64}=ntuple(_ -> 0.0, N)) where N
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    nv, Lv, xv = collect(Int64, n), collect(domain_size), collect(x0)
+    nv, Lv, xv = collect(Int64, n), collect(Float64, domain_size), collect(Float64, x0)
     check(ccall((:pg_mesh_create, libpg), Int32, (Int32, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Ptr{Ptr{Cvoid}}),
                 N, nv, Lv, xv, h))
-    centers = ntuple(d -> begin v = Vector{Float64}(undef, n[d])
-        check(ccall((:pg_mesh_get_centers, libpg), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Int64), h[], d - 1, v, n[d])); v end, N)
-    nodes = ntuple(d -> begin v = Vector{Float64}(undef, n[d] + 1)
-        check(ccall((:pg_mesh_get_nodes, libpg), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Int64), h[], d - 1, v, n[d] + 1)); v end, N)
+    centers = ntuple(N) do d
+        v = Vector{Float64}(undef, n[d])
+        check(ccall((:pg_mesh_get_centers, libpg), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Int64), h[], d - 1, v, n[d]))
+        v
+    end
+    nodes = ntuple(N) do d
+        v = Vector{Float64}(undef, n[d] + 1)
+        check(ccall((:pg_mesh_get_nodes, libpg), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Int64), h[], d - 1, v, n[d] + 1))
+        v
+    end
     nb = Ref{Int64}(0)
     check(ccall((:pg_mesh_num_border_cells, libpg), Int32, (Ptr{Cvoid}, Ptr{Int64}), h[], nb))
     idx = Matrix{Int64}(undef, N, nb[]); pos = Matrix{Float64}(undef, N, nb[]); key = Vector{Int32}(undef, nb[])
     check(ccall((:pg_mesh_get_border_cells, libpg), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Float64}, Ptr{Int32}), h[], idx, pos, key))
     border = [(CartesianIndex(ntuple(d -> Int(idx[d, q]), N)), ntuple(d -> pos[d, q], N)) for q in 1:nb[]]
-    m = Mesh{N}(centers, nodes, MeshTag{N}(border), n, h[])
+    m = Mesh{N}(centers, nodes, MeshTag{N}(border), n, key, h[])
     finalizer(x -> ccall((:pg_mesh_destroy, libpg), Int32, (Ptr{Cvoid},), x.handle), m)
     m
 end
 nC(mesh::AbstractMesh) = prod(mesh.dims)
 
 # ---------------------------------------------------------------------------------- bodies
-# A tagged level set the GPU can evaluate; calling it gives the same signed distance a Penguin.jl closure would.
-struct Sphere{N} <: Function
+# Tagged level sets the GPU can evaluate; calling one gives the signed function a Penguin.jl closure would.
+abstract type TaggedBody <: Function end
+struct Sphere{N} <: TaggedBody
     center::NTuple{N, Float64}
     radius::Float64
     complement::Bool
 end
 Sphere(center::NTuple{N, Float64}, radius::Float64; complement::Bool=false) where N = Sphere{N}(center, radius, complement)
-(s::Sphere{N})(x...) where N = (f = sqrt(sum((x[d] - s.center[d])^2 for d in 1:N)) - s.radius; s.complement ? -f : f)
+function (s::Sphere{N})(x...) where N
+    f = sqrt(sum((x[d] - s.center[d])^2 for d in 1:N)) - s.radius
+    s.complement ? -f : f
+end
+_abi(s::Sphere{N}, ::Val{N}) where N = (Int32(1), vcat(collect(s.center), s.radius), s.complement)
+
+# union of pairwise disjoint spheres of one radius, f = min_s f_s (the weak-scaling body of the benchmark)
+struct MultiSphere{N} <: TaggedBody
+    centers::Vector{NTuple{N, Float64}}
+    radius::Float64
+end
+(s::MultiSphere{N})(x...) where N = minimum(sqrt(sum((x[d] - c[d])^2 for d in 1:N)) - s.radius for c in s.centers)
+_abi(s::MultiSphere{N}, ::Val{N}) where N =
+    (Int32(2), vcat(s.radius, Float64(length(s.centers)), [c[d] for c in s.centers for d in 1:N]), false)
+
+# f(x) = sign * (x[axis] - position): the 1-D diphasic bodies `(x,_=0) -> x - xint` (test/convergence_test.jl:111) and their
+# extrusions.  `axis` is 1-based here (Julia), 0-based in the ABI.
+struct HalfSpace <: TaggedBody
+    axis::Int
+    position::Float64
+    sign::Float64
+    complement::Bool
+end
+HalfSpace(axis::Int, position::Float64, sign::Real=1.0; complement::Bool=false) =
+    HalfSpace(axis, position, sign < 0 ? -1.0 : 1.0, complement)
+function (s::HalfSpace)(x...)
+    f = s.sign * (x[s.axis] - s.position)
+    s.complement ? -f : f
+end
+function _abi(s::HalfSpace, ::Val{N}) where N
+    1 <= s.axis <= N || error("HalfSpace: axis $(s.axis) does not exist on a $(N)-D mesh")
+    (Int32(3), [Float64(s.axis - 1), s.position, s.sign], s.complement)
+end
 
 # ---------------------------------------------------------------------------------- Capacity (src/capacity.jl:25-36)
 abstract type AbstractCapacity end
@@ -93,37 +182,71 @@ end
 const PG_CAP_V, PG_CAP_GAMMA, PG_CAP_CELL_TYPES, PG_CAP_A, PG_CAP_B, PG_CAP_W, PG_CAP_C_OMEGA, PG_CAP_C_GAMMA = 0:7
 function _field(h, field, d, M)
     v = zeros(M)
-    check(ccall((:pg_capacity_get, libpg), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{Float64}, Int64), h, field, d, v, M)); v
+    check(ccall((:pg_capacity_get, libpg), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{Float64}, Int64), h, field, d, v, M))
+    v
 end
-function Capacity(body::Sphere{N}, mesh::Mesh{N}; method::String="VOFI", compute_centroids::Bool=true) where N
-    init()
-    params = vcat(collect(body.center), body.radius)
-    flags = Int32((body.complement ? 1 : 0) | (compute_centroids ? 0 : 2))
-    h = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:pg_capacity_create_levelset, libpg), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Int32, Int32, Ptr{Ptr{Cvoid}}),
-                mesh.handle, 1, params, length(params), flags, h))
+_diag(v) = spdiagm(0 => v)          # diagonal matrices store explicit zeros, as `spdiagm` does in the reference
+function _wrap_capacity(h::Ptr{Cvoid}, mesh::Mesh{N}, body, compute_centroids::Bool) where N
     M = prod(mesh.dims .+ 1)
-    diagm(v) = spdiagm(0 => v)
-    A = ntuple(d -> diagm(_field(h[], PG_CAP_A, d - 1, M)), N)
-    B = ntuple(d -> diagm(_field(h[], PG_CAP_B, d - 1, M)), N)
-    W = ntuple(d -> diagm(_field(h[], PG_CAP_W, d - 1, M)), N)
-    cw = [_field(h[], PG_CAP_C_OMEGA, d - 1, M) for d in 1:N]
+    A = ntuple(d -> _diag(_field(h, PG_CAP_A, d - 1, M)), N)
+    B = ntuple(d -> _diag(_field(h, PG_CAP_B, d - 1, M)), N)
+    W = ntuple(d -> _diag(_field(h, PG_CAP_W, d - 1, M)), N)
+    cw = [_field(h, PG_CAP_C_OMEGA, d - 1, M) for d in 1:N]
     C_ω = [SVector{N, Float64}(ntuple(d -> cw[d][i], N)) for i in 1:M]
     C_γ = if compute_centroids
-        cg = [_field(h[], PG_CAP_C_GAMMA, d - 1, M) for d in 1:N]
+        cg = [_field(h, PG_CAP_C_GAMMA, d - 1, M) for d in 1:N]
         [SVector{N, Float64}(ntuple(d -> cg[d][i], N)) for i in 1:M]
     else
         Vector{SVector{N, Float64}}(undef, 0)
     end
-    c = Capacity{N}(A, B, diagm(_field(h[], PG_CAP_V, 0, M)), W, C_ω, C_γ, diagm(_field(h[], PG_CAP_GAMMA, 0, M)),
-                    _field(h[], PG_CAP_CELL_TYPES, 0, M), mesh, body, h[])
+    c = Capacity{N}(A, B, _diag(_field(h, PG_CAP_V, 0, M)), W, C_ω, C_γ, _diag(_field(h, PG_CAP_GAMMA, 0, M)),
+                    _field(h, PG_CAP_CELL_TYPES, 0, M), mesh, body, h)
     finalizer(x -> ccall((:pg_capacity_destroy, libpg), Int32, (Ptr{Cvoid},), x.handle), c)
     c
 end
-# arbitrary Julia closures: compute the capacities with Penguin.jl's own VOFI path and hand the arrays over
+function Capacity(body::TaggedBody, mesh::Mesh{N}; method::String="VOFI", compute_centroids::Bool=true) where N
+    init()
+    kind, params, complement = _abi(body, Val(N))
+    flags = Int32((complement ? 1 : 0) | (compute_centroids ? 0 : 2))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:pg_capacity_create_levelset, libpg), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Int32, Int32, Ptr{Ptr{Cvoid}}),
+                mesh.handle, kind, params, length(params), flags, h))
+    _wrap_capacity(h[], mesh, body, compute_centroids)
+end
+# Arbitrary Julia closures cannot run on the GPU.  Nothing is substituted: build the capacity with Penguin.jl itself
+# (`Penguin.Capacity(body, penguin_mesh)`, the libvofi path) and hand its arrays over with capacity_from_arrays.
 function Capacity(body::Function, mesh::Mesh{N}; kwargs...) where N
-    error("PenguinHIP.Capacity: arbitrary level-set closures cannot run on the GPU; pass a Sphere, or build the " *
-          "capacity with Penguin.Capacity and call PenguinHIP.capacity_from_arrays(penguin_capacity, mesh)")
+    error("PenguinHIP.Capacity: arbitrary level-set closures cannot run on the GPU; pass a Sphere / MultiSphere / " *
+          "HalfSpace, or build the capacity with Penguin.Capacity and call PenguinHIP.capacity_from_arrays(cap, mesh)")
+end
+"""
+    capacity_from_arrays(cap, mesh::Mesh{N})
+
+`cap`: anything with Penguin.jl's Capacity fields (`A, B, W::NTuple{N}` of diagonal matrices, `V, Γ` diagonal matrices,
+`C_ω, C_γ::Vector{SVector{N}}`, `cell_types`, `body`) -- typically a `Penguin.Capacity` computed by libvofi on a mesh with
+the same `n, L, x0`.  The arrays are copied to the device (pg_capacity_create_from_arrays); single rank only.
+"""
+function capacity_from_arrays(cap, mesh::Mesh{N}) where N
+    init()
+    M = prod(mesh.dims .+ 1)
+    dv(m) = Vector{Float64}(diag(m))
+    V, Γ = dv(cap.V), dv(cap.Γ)
+    A, B, W = [dv(cap.A[d]) for d in 1:N], [dv(cap.B[d]) for d in 1:N], [dv(cap.W[d]) for d in 1:N]
+    Cω = [Float64[c[d] for c in cap.C_ω] for d in 1:N]
+    has_cg = length(cap.C_γ) == M
+    Cγ = has_cg ? [Float64[c[d] for c in cap.C_γ] for d in 1:N] : Vector{Float64}[]
+    ct = Vector{Float64}(cap.cell_types)
+    all(length(v) == M for v in (V, Γ, ct)) || error("capacity_from_arrays: the capacity does not live on this mesh")
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve V Γ A B W Cω Cγ ct begin
+        pa, pb, pw, pcw = pointer.(A), pointer.(B), pointer.(W), pointer.(Cω)
+        pcg = has_cg ? pointer.(Cγ) : Ptr{Float64}[]
+        check(ccall((:pg_capacity_create_from_arrays, libpg), Int32,
+                    (Ptr{Cvoid}, Ptr{Float64}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}, Ptr{Float64},
+                     Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}, Ptr{Float64}, Ptr{Ptr{Cvoid}}),
+                    mesh.handle, V, pa, pb, pw, Γ, pcw, has_cg ? pcg : C_NULL, ct, h))
+    end
+    _wrap_capacity(h[], mesh, cap.body, has_cg)
 end
 
 # ---------------------------------------------------------------------------------- DiffusionOps (src/operators.jl:49-55)
@@ -150,17 +273,20 @@ function DiffusionOps(cap::Capacity{N}) where N
     check(ccall((:pg_diffops_create, libpg), Int32, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), cap.handle, h))
     sz = cap.mesh.dims .+ 1
     M = prod(sz)
-    op = DiffusionOps{N}(_export_csc(h[], 0, N * M, M), _export_csc(h[], 1, N * M, M), _export_csc(h[], 2, N * M, N * M), cap.V, sz, h[])
+    op = DiffusionOps{N}(_export_csc(h[], 0, N * M, M), _export_csc(h[], 1, N * M, M), _export_csc(h[], 2, N * M, N * M),
+                         cap.V, sz, h[])
     finalizer(x -> ccall((:pg_diffops_destroy, libpg), Int32, (Ptr{Cvoid},), x.handle), op)
     op
 end
 function ∇(op::AbstractOperators, p::Vector{Float64})
     out = Vector{Float64}(undef, length(op.size) * prod(op.size))
-    check(ccall((:pg_diffops_grad, libpg), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), op.handle, p, out)); out
+    check(ccall((:pg_diffops_grad, libpg), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), op.handle, p, out))
+    out
 end
 function ∇₋(op::AbstractOperators, qω::Vector{Float64}, qγ::Vector{Float64})
     out = Vector{Float64}(undef, prod(op.size))
-    check(ccall((:pg_diffops_div, libpg), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), op.handle, qω, qγ, out)); out
+    check(ccall((:pg_diffops_div, libpg), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), op.handle, qω, qγ, out))
+    out
 end
 
 # ---------------------------------------------------------------------------------- boundary / phase (src/boundary.jl, src/phase.jl)
@@ -170,10 +296,10 @@ struct Neumann <: AbstractBoundary; value::Union{Function, Float64}; end
 struct Robin <: AbstractBoundary; α::Union{Function, Float64}; β::Union{Function, Float64}; value::Union{Function, Float64}; end
 struct Periodic <: AbstractBoundary end
 abstract type AbstractInterfaceBC end
-struct ScalarJump <: AbstractInterfaceBC; α₁; α₂; value; end
-struct FluxJump <: AbstractInterfaceBC; β₁; β₂; value; end
+struct ScalarJump <: AbstractInterfaceBC; α₁::Float64; α₂::Float64; value::Union{Function, Float64}; end
+struct FluxJump <: AbstractInterfaceBC; β₁::Float64; β₂::Float64; value::Union{Function, Float64}; end
 struct BorderConditions; borders::Dict{Symbol, AbstractBoundary}; end
-struct InterfaceConditions; scalar; flux; end
+struct InterfaceConditions; scalar::ScalarJump; flux::FluxJump; end
 struct Phase
     capacity::AbstractCapacity
     operator::AbstractOperators
@@ -182,18 +308,7 @@ struct Phase
 end
 
 # ---------------------------------------------------------------------------------- Solver (src/solver.jl:33-42)
-struct pg_bc_desc; kind::Int32; alpha::Float64; beta::Float64; value::Float64; value_array::Ptr{Float64}; end
-struct pg_border_desc; key::Int32; kind::Int32; value::Float64; end
-struct pg_krylov_opts; method::Int32; reltol::Float64; abstol::Float64; maxiter::Int32; check_every::Int32; warm_start::Int32; restart::Int32; end
-# method kwarg -> PG_METHOD_*: :cg / IterativeSolvers.cg -> 1, :gmres / IterativeSolvers.gmres -> 2 (restarted GMRES on the device),
-# everything else (`\`, bicgstabl, nothing) -> 0 = BiCGStab run to reltol
-function _method_id(m)
-    n = m isa Symbol ? String(m) : (m isa Function ? String(nameof(m)) : "")
-    n == "cg" ? Int32(1) : (n == "gmres" ? Int32(2) : Int32(0))
-end
-mutable struct pg_step_info; iters::Int32; converged::Int32; resnorm::Float64; bnorm::Float64; extremum::Float64; time::Float64
-    pg_step_info() = new(0, 0, 0.0, 0.0, 0.0, 0.0); end
-const KEYS = Dict(:left => 0, :right => 1, :bottom => 2, :top => 3, :backward => 4, :forward => 5)
+const KEYS = Dict(:left => 0, :right => 1, :bottom => 2, :top => 3, :backward => 4, :forward => 5)   # src/solver.jl:379-409
 
 mutable struct Solver
     time_type; phase_type; equation_type
@@ -204,114 +319,311 @@ mutable struct Solver
     handle::Ptr{Cvoid}
     nunk::Int
 end
-
-coords3(c) = length(c) == 1 ? (c[1], 0.0, 0.0) : length(c) == 2 ? (c[1], c[2], 0.0) : (c[1], c[2], c[3])   # src/solver.jl:230-248
-evalf(f, C, t) = [try f(coords3(c)..., t) catch e; e isa MethodError ? f(coords3(c)...) : rethrow() end for c in C]
-
-function DiffusionUnsteadyMono(phase::Phase, bc_b::BorderConditions, bc_i::AbstractBoundary, Δt::Float64, Tᵢ::Vector{Float64}, scheme::String)
-    println("Solver creation:"); println("- Monophasic problem"); println("- Unsteady problem"); println("- Diffusion problem")
-    cap = phase.capacity
-    kind = bc_i isa Dirichlet ? 1 : bc_i isa Neumann ? 2 : 3
-    α, β = bc_i isa Robin ? (Float64(bc_i.α), Float64(bc_i.β)) : (0.0, 0.0)
-    g = bc_i.value isa Function ? evalf(bc_i.value, cap.C_γ, Δt) : Float64[]
-    D = [phase.Diffusion_coeff(coords3(c)...) for c in cap.C_ω]
-    f = evalf(phase.source, cap.C_ω, Δt)
-    borders = [pg_border_desc(KEYS[k], v isa Dirichlet ? 1 : v isa Periodic ? 4 : v isa Neumann ? 2 : 3,
-                              v isa Periodic || v.value isa Function ? 0.0 : Float64(v.value)) for (k, v) in bc_b.borders if haskey(KEYS, k)]
-    h = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve g D f Tᵢ borders begin
-        desc = Ref(pg_bc_desc(kind, α, β, bc_i.value isa Function ? 0.0 : Float64(bc_i.value), isempty(g) ? C_NULL : pointer(g)))
-        check(ccall((:pg_solver_create_unsteady_mono, libpg), Int32,
-                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{pg_bc_desc}, Ptr{pg_border_desc}, Int32, Ptr{Float64}, Ptr{Float64}, Float64, Ptr{Float64}, Int32, Ptr{Ptr{Cvoid}}),
-                    cap.handle, phase.operator.handle, desc, borders, length(borders), D, f, Δt, Tᵢ, scheme == "CN" ? 1 : 0, h))
-    end
-    s = Solver(:Unsteady, :Monophasic, :Diffusion, nothing, nothing, nothing, [], [], h[], length(Tᵢ))
+function _new_solver(tt, pt, et, h::Ptr{Cvoid}, nunk::Int)
+    s = Solver(tt, pt, et, nothing, nothing, nothing, [], [], h, nunk)
     finalizer(x -> ccall((:pg_solver_destroy, libpg), Int32, (Ptr{Cvoid},), x.handle), s)
     s
 end
 
+# closures are evaluated on the host at the reference's points and times, exactly as it does:
+# interface / source functions receive 3 padded coordinates (src/solver.jl:230-248), `try f(x..., t) catch f(x...)`
+coords3(c) = length(c) == 1 ? (c[1], 0.0, 0.0) : length(c) == 2 ? (c[1], c[2], 0.0) : (c[1], c[2], c[3])
+function _call_t(f, x, t)
+    try
+        return Float64(f(x..., t))
+    catch e
+        e isa MethodError || rethrow()
+        return Float64(f(x...))
+    end
+end
+evalf(f, C, t) = Float64[_call_t(f, coords3(c), t) for c in C]
+evalf0(f, C) = Float64[Float64(f(coords3(c)...)) for c in C]                 # build_source / build_g_g without t
+
+_bkind(v::AbstractBoundary) = v isa Dirichlet ? Int32(1) : v isa Neumann ? Int32(2) : v isa Robin ? Int32(3) : Int32(4)
+_bvalue(v::AbstractBoundary) = (v isa Periodic || v.value isa Function) ? 0.0 : Float64(v.value)
+# unknown keys (:front / :back of examples/3D/Diffusion/Heat.jl:26) are silently ignored, as the reference does
+_border_descs(bc_b::BorderConditions) =
+    pg_border_desc[pg_border_desc(Int32(KEYS[k]), _bkind(v), _bvalue(v)) for (k, v) in bc_b.borders if haskey(KEYS, k)]
+_has_border_functions(bc_b::BorderConditions) =
+    any(!(v isa Periodic) && v.value isa Function for (k, v) in bc_b.borders if haskey(KEYS, k))
+# eval_bc_value at every border cell (src/solver.jl:441-448): value(pos..., t) with the N UNPADDED coordinates of
+# mesh.centers, falling back to value(pos...); t === nothing: the diphasic drivers call BC_border_diph! without t
+function _border_values(bc_b::BorderConditions, mesh::Mesh, t)
+    inv = Dict(v => k for (k, v) in KEYS)
+    vals = zeros(length(mesh.border_keys))
+    for (q, (_, pos)) in enumerate(mesh.tag.border_cells)
+        cond = get(bc_b.borders, inv[Int(mesh.border_keys[q])], nothing)
+        (cond === nothing || cond isa Periodic) && continue
+        v = cond.value
+        vals[q] = v isa Function ? (t === nothing ? Float64(v(pos...)) : _call_t(v, pos, t)) : Float64(v)
+    end
+    vals
+end
+function _set_border_values!(s::Solver, bc_b::BorderConditions, mesh::Mesh, t)
+    vals = _border_values(bc_b, mesh, t)
+    check(ccall((:pg_solver_set_border_values, libpg), Int32, (Ptr{Cvoid}, Ptr{Float64}), s.handle, vals))
+end
+function _interface_desc(bc_i::AbstractBoundary, g::Vector{Float64})
+    kind = bc_i isa Dirichlet ? Int32(1) : bc_i isa Neumann ? Int32(2) : bc_i isa Robin ? Int32(3) :
+           error("unsupported interface condition $(typeof(bc_i))")
+    if bc_i isa Robin && (bc_i.α isa Function || bc_i.β isa Function)
+        error("PenguinHIP: function-valued Robin coefficients are not supported on the GPU path")
+    end
+    α, β = bc_i isa Robin ? (Float64(bc_i.α), Float64(bc_i.β)) : (0.0, 0.0)
+    pg_bc_desc(kind, α, β, bc_i.value isa Function ? 0.0 : Float64(bc_i.value), isempty(g) ? Ptr{Float64}(C_NULL) : pointer(g))
+end
 function _state(s::Solver)
     x = zeros(s.nunk)
-    check(ccall((:pg_solver_get_state, libpg), Int32, (Ptr{Cvoid}, Int64, Ptr{Float64}, Int64), s.handle, -1, x, s.nunk)); x
+    check(ccall((:pg_solver_get_state, libpg), Int32, (Ptr{Cvoid}, Int64, Ptr{Float64}, Int64), s.handle, -1, x, s.nunk))
+    x
+end
+function _record!(s::Solver, info::pg_step_info, log::Bool)
+    info.converged == 0 && @warn "PenguinHIP: a solve did not converge" iters = info.iters relres = info.resnorm / max(info.bnorm, floatmin())
+    log && push!(s.ch, (iters = info.iters, resnorm = info.resnorm, isconverged = info.converged != 0))
+    s.x = _state(s)
+    push!(s.states, s.x)
+    nothing
+end
+_scheme(s::String) = s == "CN" ? Int32(1) : Int32(0)          # diffusion.jl:200-206: anything but "CN" is BE
+
+# ---------------------------------------------------------------------------------- DiffusionUnsteadyMono (diffusion.jl:192-210)
+function DiffusionUnsteadyMono(phase::Phase, bc_b::BorderConditions, bc_i::AbstractBoundary, Δt::Float64, Tᵢ::Vector{Float64}, scheme::String)
+    println("Solver creation:"); println("- Monophasic problem"); println("- Unsteady problem"); println("- Diffusion problem")
+    cap = phase.capacity
+    g = bc_i.value isa Function ? evalf(bc_i.value, cap.C_γ, Δt) : Float64[]      # b(t=0) uses g(0+Δt)   diffusion.jl:249
+    D = evalf0(phase.Diffusion_coeff, cap.C_ω)
+    f = evalf(phase.source, cap.C_ω, Δt)                                          # f(0+Δt)
+    borders = _border_descs(bc_b)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve g D f Tᵢ borders begin
+        desc = Ref(_interface_desc(bc_i, g))
+        check(ccall((:pg_solver_create_unsteady_mono, libpg), Int32,
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{pg_bc_desc}, Ptr{pg_border_desc}, Int32, Ptr{Float64}, Ptr{Float64}, Float64,
+                     Ptr{Float64}, Int32, Ptr{Ptr{Cvoid}}),
+                    cap.handle, phase.operator.handle, desc, borders, length(borders), D, f, Δt, Tᵢ, _scheme(scheme), h))
+    end
+    s = _new_solver(:Unsteady, :Monophasic, :Diffusion, h[], length(Tᵢ))
+    if scheme == "CN"                                   # the CN right-hand side also needs f(0) and g(0)
+        f0 = evalf(phase.source, cap.C_ω, 0.0)
+        check(ccall((:pg_solver_set_source, libpg), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}), s.handle, 0, f0, C_NULL))
+        if bc_i.value isa Function
+            g0 = evalf(bc_i.value, cap.C_γ, 0.0)
+            check(ccall((:pg_solver_set_interface_value, libpg), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), s.handle, g0, C_NULL))
+        end
+    end
+    _has_border_functions(bc_b) && _set_border_values!(s, bc_b, cap.mesh, 0.0)    # ctor applies borders with t = 0  (:207)
+    s
 end
 
+# solve_DiffusionUnsteadyMono!(s, phase, Δt, Tₑ, bc_b, bc, scheme; method=gmres, algorithm=nothing, kwargs...)  diffusion.jl:268-301
+# Extra keywords (not in the reference): `save_states=true`; with `save_states=false` and no function-valued data the
+# whole loop runs on the device (pg_solver_run) and only the last state is fetched.
 function solve_DiffusionUnsteadyMono!(s::Solver, phase::Phase, Δt::Float64, Tₑ, bc_b::BorderConditions, bc::AbstractBoundary, scheme::String;
-                                      method=nothing, algorithm=nothing, kwargs...)
-    s.handle == C_NULL && error("Solver is not initialized. Call a solver constructor first.")
-    kw = (; kwargs...)
-    opts = Ref(pg_krylov_opts(_method_id(method), get(kw, :reltol, 1e-12), get(kw, :abstol, 0.0), get(kw, :maxiter, 0), 4, get(kw, :warm_start, true) ? 1 : 0, get(kw, :restart, 0)))
+                                      method::Function=gmres, algorithm=nothing, save_states::Bool=true, kwargs...)
+    (s.handle == C_NULL) && error("Solver is not initialized. Call a solver constructor first.")
+    kw = Dict{Symbol, Any}(kwargs)
+    log = get(kw, :log, false)
+    opts = Ref(_opts(method, kw))
     info = pg_step_info()
+    cap, mesh = phase.capacity, phase.capacity.mesh
     t = 0.0
     check(ccall((:pg_solver_initial_solve, libpg), Int32, (Ptr{Cvoid}, Ptr{pg_krylov_opts}, Ref{pg_step_info}), s.handle, opts, info))
-    s.x = _state(s); push!(s.states, s.x)
+    _record!(s, info, log)                                                        # states[1]   (:275-277)
     println("Time: ", t); println("Solver Extremum: ", info.extremum)
-    cap = phase.capacity
+    if !save_states && !(bc.value isa Function) && !_has_border_functions(bc_b) && get(kw, :constant_source, false)
+        run = pg_run_info()
+        check(ccall((:pg_solver_run, libpg), Int32, (Ptr{Cvoid}, Float64, Int32, Ptr{pg_krylov_opts}, Int32, Int64, Int32, Ref{pg_run_info}),
+                    s.handle, Float64(Tₑ), _scheme(scheme), opts, 0, -1, 0, run))
+        run.unconverged_steps == 0 || @warn "PenguinHIP: $(run.unconverged_steps) of $(run.steps) time-step solves did not converge"
+        s.x = _state(s); s.states[end] = s.x
+        return s
+    end
     while t < Tₑ
-        t += Δt
+        t += Δt                                                                    # :287
         println("Time: ", t)
-        fn, fn1 = evalf(phase.source, cap.C_ω, t), evalf(phase.source, cap.C_ω, t + Δt)
+        fn, fn1 = evalf(phase.source, cap.C_ω, t), evalf(phase.source, cap.C_ω, t + Δt)    # f(t+Δt), t already advanced (:248)
         check(ccall((:pg_solver_set_source, libpg), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}), s.handle, 0, fn, fn1))
         if bc.value isa Function
             gn, gn1 = evalf(bc.value, cap.C_γ, t), evalf(bc.value, cap.C_γ, t + Δt)
             check(ccall((:pg_solver_set_interface_value, libpg), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), s.handle, gn, gn1))
         end
-        check(ccall((:pg_solver_step, libpg), Int32, (Ptr{Cvoid}, Int32, Ptr{pg_krylov_opts}, Ref{pg_step_info}), s.handle, scheme == "CN" ? 1 : 0, opts, info))
-        s.x = _state(s); push!(s.states, s.x)
+        _has_border_functions(bc_b) && _set_border_values!(s, bc_b, mesh, t)      # BC_border_mono!(...; t=t)   (:292)
+        check(ccall((:pg_solver_step, libpg), Int32, (Ptr{Cvoid}, Int32, Ptr{pg_krylov_opts}, Ref{pg_step_info}), s.handle, _scheme(scheme), opts, info))
+        _record!(s, info, log)
         println("Solver Extremum: ", info.extremum)
     end
+    s
 end
 
-# ---- steady diffusion (src/solver/diffusion.jl:14-71): same blocks without V and Δt ---------------------------------
-evalf0(f, C) = [f(coords3(c)...) for c in C]                                  # build_source / build_g_g without t
+# ---------------------------------------------------------------------------------- DiffusionUnsteadyDiph (diffusion.jl:319-454)
+function _jump_desc(ic::InterfaceConditions, cap1, cap2, g::Vector{Float64}, hh::Vector{Float64})
+    pg_jump_desc(ic.scalar.α₁, ic.scalar.α₂, ic.scalar.value isa Function ? 0.0 : Float64(ic.scalar.value),
+                 ic.flux.β₁, ic.flux.β₂, ic.flux.value isa Function ? 0.0 : Float64(ic.flux.value),
+                 isempty(g) ? Ptr{Float64}(C_NULL) : pointer(g), isempty(hh) ? Ptr{Float64}(C_NULL) : pointer(hh))
+end
+function DiffusionUnsteadyDiph(phase1::Phase, phase2::Phase, bc_b::BorderConditions, ic::InterfaceConditions, Δt::Float64, Tᵢ::Vector{Float64}, scheme::String)
+    println("Solver creation:"); println("- Diphasic problem"); println("- Unsteady problem"); println("- Diffusion problem")
+    c1, c2 = phase1.capacity, phase2.capacity
+    g = ic.scalar.value isa Function ? evalf0(ic.scalar.value, c1.C_γ) : Float64[]       # g, h are built WITHOUT t (:397)
+    hh = ic.flux.value isa Function ? evalf0(ic.flux.value, c2.C_γ) : Float64[]
+    D1, D2 = evalf0(phase1.Diffusion_coeff, c1.C_ω), evalf0(phase2.Diffusion_coeff, c2.C_ω)
+    f1, f2 = evalf(phase1.source, c1.C_ω, Δt), evalf(phase2.source, c2.C_ω, Δt)
+    borders = _border_descs(bc_b)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve g hh D1 D2 f1 f2 Tᵢ borders begin
+        desc = Ref(_jump_desc(ic, c1, c2, g, hh))
+        check(ccall((:pg_solver_create_unsteady_diph, libpg), Int32,
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{pg_jump_desc}, Ptr{pg_border_desc}, Int32,
+                     Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Float64, Ptr{Float64}, Int32, Ptr{Ptr{Cvoid}}),
+                    c1.handle, phase1.operator.handle, c2.handle, phase2.operator.handle, desc, borders, length(borders),
+                    D1, D2, f1, f2, Δt, Tᵢ, _scheme(scheme), h))
+    end
+    s = _new_solver(:Unsteady, :Diphasic, :Diffusion, h[], length(Tᵢ))
+    if scheme == "CN"
+        for (q, ph) in enumerate((phase1, phase2))
+            f0 = evalf(ph.source, ph.capacity.C_ω, 0.0)
+            check(ccall((:pg_solver_set_source, libpg), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}), s.handle, q - 1, f0, C_NULL))
+        end
+    end
+    _has_border_functions(bc_b) && _set_border_values!(s, bc_b, c1.mesh, nothing)   # BC_border_diph! is called without t (:330)
+    s
+end
 
+function solve_DiffusionUnsteadyDiph!(s::Solver, phase1::Phase, phase2::Phase, Δt::Float64, Tₑ, bc_b::BorderConditions, ic::InterfaceConditions, scheme::String;
+                                      method::Function=gmres, algorithm=nothing, kwargs...)
+    (s.handle == C_NULL) && error("Solver is not initialized. Call a solver constructor first.")
+    kw = Dict{Symbol, Any}(kwargs)
+    log = get(kw, :log, false)
+    opts = Ref(_opts(method, kw))
+    info = pg_step_info()
+    t = 0.0
+    println("Time: ", t)
+    check(ccall((:pg_solver_initial_solve, libpg), Int32, (Ptr{Cvoid}, Ptr{pg_krylov_opts}, Ref{pg_step_info}), s.handle, opts, info))
+    _record!(s, info, log)
+    println("Solver Extremum: ", info.extremum)
+    while t < Tₑ
+        t += Δt
+        println("Time: ", t)
+        for (q, ph) in enumerate((phase1, phase2))                                 # f(t+Δt) and, for CN, f(t)   (:401-421)
+            fn, fn1 = evalf(ph.source, ph.capacity.C_ω, t), evalf(ph.source, ph.capacity.C_ω, t + Δt)
+            check(ccall((:pg_solver_set_source, libpg), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}), s.handle, q - 1, fn, fn1))
+        end
+        check(ccall((:pg_solver_step, libpg), Int32, (Ptr{Cvoid}, Int32, Ptr{pg_krylov_opts}, Ref{pg_step_info}), s.handle, _scheme(scheme), opts, info))
+        _record!(s, info, log)
+        println("Solver Extremum: ", info.extremum)
+    end
+    s
+end
+
+# ---------------------------------------------------------------------------------- steady diffusion (diffusion.jl:14-175)
 function DiffusionSteadyMono(phase::Phase, bc_b::BorderConditions, bc_i::AbstractBoundary)
     println("Solver creation:"); println("- Monophasic problem"); println("- Steady problem"); println("- Diffusion problem")
     cap = phase.capacity
-    kind = bc_i isa Dirichlet ? 1 : bc_i isa Neumann ? 2 : 3
-    α, β = bc_i isa Robin ? (Float64(bc_i.α), Float64(bc_i.β)) : (0.0, 0.0)
     g = bc_i.value isa Function ? evalf0(bc_i.value, cap.C_γ) : Float64[]
-    D = [phase.Diffusion_coeff(coords3(c)...) for c in cap.C_ω]
+    D = evalf0(phase.Diffusion_coeff, cap.C_ω)
     f = evalf0(phase.source, cap.C_ω)
-    borders = [pg_border_desc(KEYS[k], v isa Dirichlet ? 1 : v isa Periodic ? 4 : v isa Neumann ? 2 : 3,
-                              v isa Periodic || v.value isa Function ? 0.0 : Float64(v.value)) for (k, v) in bc_b.borders if haskey(KEYS, k)]
+    borders = _border_descs(bc_b)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve g D f borders begin
-        desc = Ref(pg_bc_desc(kind, α, β, bc_i.value isa Function ? 0.0 : Float64(bc_i.value), isempty(g) ? C_NULL : pointer(g)))
+        desc = Ref(_interface_desc(bc_i, g))
         check(ccall((:pg_solver_create_steady_mono, libpg), Int32,
                     (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{pg_bc_desc}, Ptr{pg_border_desc}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Ptr{Cvoid}}),
                     cap.handle, phase.operator.handle, desc, borders, length(borders), D, f, h))
     end
-    s = Solver(:Steady, :Monophasic, :Diffusion, nothing, nothing, nothing, [], [], h[], 2 * length(cap.C_ω))
-    finalizer(x -> ccall((:pg_solver_destroy, libpg), Int32, (Ptr{Cvoid},), x.handle), s)
+    s = _new_solver(:Steady, :Monophasic, :Diffusion, h[], 2 * length(cap.C_ω))
+    _has_border_functions(bc_b) && _set_border_values!(s, bc_b, cap.mesh, nothing)
     s
 end
-
-function solve_DiffusionSteadyMono!(s::Solver; method=nothing, algorithm=nothing, kwargs...)
-    s.handle == C_NULL && error("Solver is not initialized. Call a solver constructor first.")
-    println("Solving the system:"); println("- Monophasic problem"); println("- Steady problem"); println("- Diffusion problem")
-    kw = (; kwargs...)
-    opts = Ref(pg_krylov_opts(_method_id(method), get(kw, :reltol, 1e-12), get(kw, :abstol, 0.0), get(kw, :maxiter, 0), 4, 0, get(kw, :restart, 0)))
+function DiffusionSteadyDiph(phase1::Phase, phase2::Phase, bc_b::BorderConditions, ic::InterfaceConditions)
+    println("Solver creation:"); println("- Diphasic problem"); println("- Steady problem"); println("- Diffusion problem")
+    c1, c2 = phase1.capacity, phase2.capacity
+    g = ic.scalar.value isa Function ? evalf0(ic.scalar.value, c1.C_γ) : Float64[]
+    hh = ic.flux.value isa Function ? evalf0(ic.flux.value, c2.C_γ) : Float64[]
+    D1, D2 = evalf0(phase1.Diffusion_coeff, c1.C_ω), evalf0(phase2.Diffusion_coeff, c2.C_ω)
+    f1, f2 = evalf0(phase1.source, c1.C_ω), evalf0(phase2.source, c2.C_ω)
+    borders = _border_descs(bc_b)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve g hh D1 D2 f1 f2 borders begin
+        desc = Ref(_jump_desc(ic, c1, c2, g, hh))
+        check(ccall((:pg_solver_create_steady_diph, libpg), Int32,
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{pg_jump_desc}, Ptr{pg_border_desc}, Int32,
+                     Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Ptr{Cvoid}}),
+                    c1.handle, phase1.operator.handle, c2.handle, phase2.operator.handle, desc, borders, length(borders),
+                    D1, D2, f1, f2, h))
+    end
+    s = _new_solver(:Steady, :Diphasic, :Diffusion, h[], 4 * length(c1.C_ω))
+    _has_border_functions(bc_b) && _set_border_values!(s, bc_b, c1.mesh, nothing)
+    s
+end
+function _solve_steady!(s::Solver, method, kwargs, banner)
+    (s.handle == C_NULL) && error("Solver is not initialized. Call a solver constructor first.")
+    println("Solving the system:"); println(banner); println("- Steady problem"); println("- Diffusion problem")
+    kw = Dict{Symbol, Any}(kwargs)
+    opts = Ref(_opts(method, kw; warm_default=false))
     info = pg_step_info()
     check(ccall((:pg_solver_initial_solve, libpg), Int32, (Ptr{Cvoid}, Ptr{pg_krylov_opts}, Ref{pg_step_info}), s.handle, opts, info))
+    info.converged == 0 && @warn "PenguinHIP: the steady solve did not converge" iters = info.iters
+    get(kw, :log, false) && push!(s.ch, (iters = info.iters, resnorm = info.resnorm, isconverged = info.converged != 0))
     s.x = _state(s)
+    s
 end
-# DiffusionSteadyDiph / solve_DiffusionSteadyDiph! (:88-175) bind pg_solver_create_steady_diph the same way (two
-# capacities / operators, pg_jump_desc as in DiffusionUnsteadyDiph).
+solve_DiffusionSteadyMono!(s::Solver; method::Function=gmres, algorithm=nothing, kwargs...) =
+    _solve_steady!(s, method, kwargs, "- Monophasic problem")
+solve_DiffusionSteadyDiph!(s::Solver; method::Function=gmres, algorithm=nothing, kwargs...) =
+    _solve_steady!(s, method, kwargs, "- Diphasic problem")
 
-# ---- ConvectionOps (src/operators.jl:194-210) and the advection-diffusion drivers ---------------------------------------
-# struct ConvectionOps{N}: same handle type as DiffusionOps plus the velocity; C[d] / K[d] are exported on demand with
-# pg_diffops_export_csc(handle, 3 + (d-1) | 6 + (d-1), ...).  A solver constructor that receives such an operator
-# assembles the advection-diffusion blocks (advectiondiffusion.jl:29-44, 95-126, 180-213).
-function ConvectionOps(capacity::Capacity{N}, uₒ::NTuple{N,Vector{Float64}}, uᵧ::Vector{Float64}) where N
-    op = DiffusionOps(capacity)
+# ---------------------------------------------------------------------------------- ConvectionOps + advection-diffusion
+# src/operators.jl:194-210: C_d = δ_p[d] diag(Σ_m[d] A_d uₒ_d) Σ_m[d], K_d = diag(Σ_p[d] Hᵀuᵧ).  A solver built from such an
+# operator assembles the advection-diffusion blocks (src/solver/advectiondiffusion.jl:29-44,95-126,180-213): the diffusion
+# constructors and loops above, called with this operator.
+mutable struct ConvectionOps{N} <: AbstractOperators
+    C::NTuple{N, SparseMatrixCSC{Float64, Int}}
+    K::NTuple{N, SparseMatrixCSC{Float64, Int}}
+    G::SparseMatrixCSC{Float64, Int}
+    H::SparseMatrixCSC{Float64, Int}
+    Wꜝ::SparseMatrixCSC{Float64, Int}
+    V::SparseMatrixCSC{Float64, Int}
+    size::NTuple{N, Int}
+    handle::Ptr{Cvoid}
+end
+function ConvectionOps(capacity::Capacity{N}, uₒ::NTuple{N, Vector{Float64}}, uᵧ::Vector{Float64}) where N
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:pg_diffops_create, libpg), Int32, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), capacity.handle, h))
+    sz = capacity.mesh.dims .+ 1
+    M = prod(sz)
     GC.@preserve uₒ uᵧ begin
         ptrs = [pointer(u) for u in uₒ]
-        check(ccall((:pg_diffops_set_velocity, libpg), Int32, (Ptr{Cvoid}, Ptr{Ptr{Float64}}, Ptr{Float64}), op.handle, ptrs, uᵧ))
+        check(ccall((:pg_diffops_set_velocity, libpg), Int32, (Ptr{Cvoid}, Ptr{Ptr{Float64}}, Ptr{Float64}), h[], ptrs, uᵧ))
     end
+    op = ConvectionOps{N}(ntuple(d -> _export_csc(h[], 3 + d - 1, M, M), N), ntuple(d -> _export_csc(h[], 6 + d - 1, M, M), N),
+                          _export_csc(h[], 0, N * M, M), _export_csc(h[], 1, N * M, M), _export_csc(h[], 2, N * M, N * M),
+                          capacity.V, sz, h[])
+    finalizer(x -> ccall((:pg_diffops_destroy, libpg), Int32, (Ptr{Cvoid},), x.handle), op)
     op
 end
-# AdvectionDiffusionSteadyMono / SteadyDiph / UnsteadyMono / UnsteadyDiph ("BE" only: the reference's "CN" right-hand
-# side for the diphasic driver omits the diffusion term, advectiondiffusion.jl:375-377) and their solve_...! functions are
-# the diffusion constructors and loops above called with such an operator (DarcyFlow / DarcyFlowUnsteady likewise alias the diffusion drivers).
+_adv(s::Solver) = (s.equation_type = :DiffusionAdvection; s)
+_need_conv(ph::Phase) = ph.operator isa ConvectionOps || error("the advection-diffusion drivers need a Phase built on ConvectionOps")
+AdvectionDiffusionSteadyMono(phase::Phase, bc_b, bc_i) = (_need_conv(phase); _adv(DiffusionSteadyMono(phase, bc_b, bc_i)))
+solve_AdvectionDiffusionSteadyMono!(s::Solver; kwargs...) = solve_DiffusionSteadyMono!(s; kwargs...)
+AdvectionDiffusionSteadyDiph(p1::Phase, p2::Phase, bc_b, ic) = (_need_conv(p1); _need_conv(p2); _adv(DiffusionSteadyDiph(p1, p2, bc_b, ic)))
+solve_AdvectionDiffusionSteadyDiph!(s::Solver; kwargs...) = solve_DiffusionSteadyDiph!(s; kwargs...)
+function AdvectionDiffusionUnsteadyMono(phase::Phase, bc_b, bc_i, Δt::Float64, Tᵢ::Vector{Float64}, scheme::String)
+    _need_conv(phase)
+    scheme in ("BE", "CN") || error("Unknown scheme.")                              # advectiondiffusion.jl:203-205
+    _adv(DiffusionUnsteadyMono(phase, bc_b, bc_i, Δt, Tᵢ, scheme))
+end
+solve_AdvectionDiffusionUnsteadyMono!(s::Solver, phase::Phase, Δt::Float64, Tₑ, bc_b, bc, scheme::String; kwargs...) =
+    solve_DiffusionUnsteadyMono!(s, phase, Δt, Tₑ, bc_b, bc, scheme; kwargs...)
+# Backward Euler only: the reference's Crank-Nicolson right-hand side for the diphasic driver keeps the convection terms but
+# drops the diffusion part of the explicit half step (advectiondiffusion.jl:375-377); it is refused, not approximated.
+function AdvectionDiffusionUnsteadyDiph(p1::Phase, p2::Phase, bc_b, ic, Δt::Float64, Tᵢ::Vector{Float64}, scheme::String)
+    _need_conv(p1); _need_conv(p2)
+    scheme == "BE" || error("AdvectionDiffusionUnsteadyDiph: only scheme \"BE\" is available on the HIP path")
+    _adv(DiffusionUnsteadyDiph(p1, p2, bc_b, ic, Δt, Tᵢ, "BE"))
+end
+function solve_AdvectionDiffusionUnsteadyDiph!(s::Solver, p1::Phase, p2::Phase, Δt::Float64, Tₑ, bc_b, ic, scheme::String; kwargs...)
+    scheme == "BE" || error("solve_AdvectionDiffusionUnsteadyDiph!: only scheme \"BE\" is available on the HIP path")
+    solve_DiffusionUnsteadyDiph!(s, p1, p2, Δt, Tₑ, bc_b, ic, "BE"; kwargs...)
+end
 
 end # module
