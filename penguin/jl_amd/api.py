@@ -1196,10 +1196,22 @@ def lp_norm(errors, indices, pval, capacity: Capacity):
     return float((np.sum(np.abs(errors[indices]) ** pval * V[indices]) / np.sum(V)) ** (1.0 / pval))
 
 
+def _eval_points(u: Callable, C: np.ndarray) -> np.ndarray:
+    """u at the rows of C: one call with coordinate arrays when the callable takes them (a few million centroids in 3-D),
+    else point by point as `map(c -> u(c...), C)` does."""
+    try:
+        out = np.asarray(u(*[C[:, d] for d in range(C.shape[1])]), dtype=np.float64)
+        if out.shape == (C.shape[0],):
+            return out
+    except Exception:
+        pass
+    return np.array([u(*c) for c in C], dtype=np.float64)
+
+
 def check_convergence(u_analytical: Callable, solver: Solver, capacity: Capacity, p=2):
     """src/convergence.jl:45-93 (absolute norms)."""
     Cw = capacity.C_ω
-    u_ana = np.array([u_analytical(*c) for c in Cw], dtype=np.float64)
+    u_ana = _eval_points(u_analytical, Cw)
     u_num = solver.x[: len(solver.x) // 2]
     err = u_ana - u_num
     ct = capacity.cell_types
@@ -1217,7 +1229,7 @@ def check_convergence_diph(u1_analytical: Callable, u2_analytical: Callable, sol
     u_num = (x[:M], x[2 * M:3 * M])
     out_ana, errs = [], []
     for cap, ua, un in ((capacity1, u1_analytical, u_num[0]), (capacity2, u2_analytical, u_num[1])):
-        ana = np.array([ua(*c) for c in cap.C_ω], dtype=np.float64)
+        ana = _eval_points(ua, cap.C_ω)
         err = ana - un
         ct = cap.cell_types
         sel = lambda m: np.flatnonzero(m)
