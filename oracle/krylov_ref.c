@@ -14,6 +14,9 @@
 #ifdef _OPENMP
 #include <omp.h>
 #endif
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
 
 static void spmv(int64_t n, const int64_t* rp, const int32_t* ci, const double* v, const double* x, double* y) {
 #pragma omp parallel for schedule(static)

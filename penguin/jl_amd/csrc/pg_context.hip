@@ -1,5 +1,6 @@
 // pg_context.hip -- device / stream / RCCL communicator lifetime, error channel, Mesh.
 #include "pg_common.h"
+#include "pg_host_algos.h"
 
 #include <algorithm>
 #include <array>
@@ -213,21 +214,7 @@ int32_t pg_partition_planes(const int64_t* weight, int64_t nplanes, int32_t nran
   PG_API_BEGIN
   PG_REQUIRE(weight && bounds && nplanes >= 1 && nranks >= 1, "pg_partition_planes: bad arguments");
   PG_REQUIRE(nplanes >= nranks, "pg_partition_planes: fewer planes than ranks");
-  // contiguous ranges whose cumulated weight is closest to r/nranks of the total; every rank gets
-  // at least one plane.  (+1 per plane so that empty regions are still spread.)
-  std::vector<double> cum(nplanes + 1, 0.0);
-  for (i64 k = 0; k < nplanes; ++k) cum[k + 1] = cum[k] + static_cast<double>(weight[k]) + 1.0;
-  const double total = cum[nplanes];
-  bounds[0] = 0;
-  for (int r = 1; r < nranks; ++r) {
-    const double target = total * r / nranks;
-    i64 k = std::lower_bound(cum.begin(), cum.end(), target) - cum.begin();
-    if (k > 0 && (target - cum[k - 1]) < (cum[k] - target)) --k;
-    const i64 lo = bounds[r - 1] + 1;
-    const i64 hi = nplanes - (nranks - r);
-    bounds[r] = std::min(std::max(k, lo), hi);
-  }
-  bounds[nranks] = nplanes;
+  pghost::partition_planes(weight, nplanes, nranks, bounds);   // pg_host_algos.h (also built with ASan / UBSan for the CPU suite)
   PG_API_END
 }
 

@@ -1,0 +1,187 @@
+// pg_host_algos.h -- the pure HOST algorithms of the library, free of HIP so that the CPU test-suite can compile them with
+// AddressSanitizer + UndefinedBehaviorSanitizer (tests/host_asan.cpp): the slab partition of the
+// planes and the planning of the SpMV's marching units (index arithmetic over run descriptors: the place where an
+// off-by-one reads outside a vector on the GPU).  Included by pg_context.hip and pg_spmv.hip.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <vector>
+
+namespace pghost {
+
+// contiguous plane ranges whose cumulated weight is closest to r / nranks of the total; every rank gets at least one
+// plane (+1 per plane so that empty regions are still spread).  bounds: nranks + 1 entries.  nplanes >= nranks >= 1.
+inline void partition_planes(const int64_t* weight, int64_t nplanes, int nranks, int64_t* bounds) {
+  std::vector<double> cum(nplanes + 1, 0.0);
+  for (int64_t k = 0; k < nplanes; ++k) cum[k + 1] = cum[k] + static_cast<double>(weight[k]) + 1.0;
+  const double total = cum[nplanes];
+  bounds[0] = 0;
+  for (int r = 1; r < nranks; ++r) {
+    const double target = total * r / nranks;
+    int64_t k = std::lower_bound(cum.begin(), cum.end(), target) - cum.begin();
+    if (k > 0 && (target - cum[k - 1]) < (cum[k] - target)) --k;
+    const int64_t lo = bounds[r - 1] + 1;
+    const int64_t hi = nplanes - (nranks - r);
+    bounds[r] = std::min(std::max(k, lo), hi);
+  }
+  bounds[nranks] = nplanes;
+}
+
+struct MRun {
+  int r0, len, cnt;   // rows [r0, r0 + len) with one stencil (offsets and values), cnt = 5 / 7 entries
+};
+struct RowRange {
+  int64_t a, b;       // rows [a, b) that cannot march: they go back to the U slices
+  int cnt;
+};
+struct MarchGeometry {
+  int K, KS;          // planes per full / short unit (shorter units are closed with empty planes)
+  int REC;            // dwords per unit record
+  int W;              // rows computed per window (the window holds W + 2 elements of every line)
+  int INFO;           // dwords per run descriptor: 8 offsets, 8 values (lo, hi)
+  int kmax;           // planes per unit actually used (<= K)
+};
+
+// Chains of runs that face each other across the slowest stencil direction (entry cnt-3 / cnt-2 of a row lead to the row of
+// the same lateral position one plane up / down), cut into windows of W computed rows and units of <= kmax planes
+// (pg_spmv.hip "marching units" has the record layout).  info: INFO dwords per run -- the col - row offsets (8) and the
+// values (8 doubles as lo / hi dwords) of the run's first row, in the entry order of the assembled rows:
+// +1, -1, [+Y, -Y,] +Z, -Z, 0.  n = rows of the matrix (= guaranteed length of every vector the kernel reads).
+// mrec: the unit records, sorted by first row; fallback: rows that cannot march (another entry order, windows that would read
+// outside the vector); rows_m: rows covered by units.
+inline void plan_march_units(int64_t n, const std::vector<MRun>& runs, const std::vector<int>& info, const MarchGeometry& geo,
+                             std::vector<int>& mrec, std::vector<RowRange>& fallback, int64_t& rows_m) {
+  typedef int64_t i64;
+  rows_m = 0;
+  const i64 nr = (i64)runs.size();
+  const int RI = geo.INFO;
+  auto off = [&](i64 i, int k) { return info[RI * i + k]; };
+  auto same_values = [&](i64 i, i64 j, int cnt) {
+    for (int k = 0; k < 2 * cnt; ++k)
+      if (info[RI * i + 8 + k] != info[RI * j + 8 + k]) return false;
+    return true;
+  };
+  // entries of a marching row, in the order eval_row emits them: +1, -1, [+Y, -Y,] +Z, -Z, 0 with 1 < Y < Z
+  std::vector<char> ok(nr, 0);
+  for (i64 i = 0; i < nr; ++i) {
+    const int cnt = runs[i].cnt;
+    bool good = (cnt == 5 || cnt == 7) && off(i, 0) == 1 && off(i, 1) == -1 && off(i, cnt - 1) == 0;
+    if (good) {
+      const int up_e = cnt - 3, dn_e = cnt - 2;
+      good = off(i, up_e) > 1 && off(i, dn_e) < -1;
+      if (good && cnt == 7) good = off(i, 2) > 1 && off(i, 2) < off(i, up_e) && off(i, 3) < -1 && off(i, 3) > off(i, dn_e);
+    }
+    ok[i] = good;
+    if (!ok[i]) fallback.push_back(RowRange{runs[i].r0, (i64)runs[i].r0 + runs[i].len, cnt});
+  }
+  // successor of run i: the run that holds most of the rows r + o[up], r in run i, if it mirrors the offset and carries
+  // the same values; every run has at most one predecessor
+  std::vector<int> succ(nr, -1), pred(nr, -1);
+  for (i64 i = 0; i < nr; ++i) {
+    if (!ok[i]) continue;
+    const int cnt = runs[i].cnt, up_off = off(i, cnt - 3);
+    const i64 lo = (i64)runs[i].r0 + up_off, hi = lo + runs[i].len;
+    i64 j = std::upper_bound(runs.begin(), runs.end(), lo, [](i64 v, const MRun& r) { return v < (i64)r.r0; }) - runs.begin();
+    if (j > 0) --j;
+    i64 best = -1, best_ov = 0;
+    for (; j < nr && (i64)runs[j].r0 < hi; ++j) {
+      const i64 a = runs[j].r0, b = a + runs[j].len;
+      if (b <= lo || j == i || !ok[j] || pred[j] >= 0 || runs[j].cnt != cnt || off(j, cnt - 2) != -up_off || !same_values(i, j, cnt)) continue;
+      const i64 ov = std::min(hi, b) - std::max(lo, a);
+      if (ov > best_ov) { best_ov = ov; best = j; }
+    }
+    if (best >= 0) { succ[i] = (int)best; pred[best] = (int)i; }
+  }
+  struct Unit { int key; std::vector<int> rec; };
+  std::vector<Unit> units;
+  // every load of a unit reads elements idx0 .. idx0 + 129 of a vector of >= n elements (+ 8 of slack, DevBuf)
+  auto safe = [&](i64 idx0) { return idx0 >= 0 && idx0 + 130 <= n + 8; };
+  std::vector<i64> chain, B;
+  for (i64 h = 0; h < nr; ++h) {
+    if (!ok[h] || pred[h] >= 0) continue;
+    chain.clear(); B.clear();
+    const int cnt = runs[h].cnt;
+    const bool Y = cnt == 7;
+    const int up_e = cnt - 3, dn_e = cnt - 2;   // entries of the +plane / -plane taps
+    i64 base = runs[h].r0;
+    for (i64 i = h; i >= 0; i = succ[i]) {
+      chain.push_back(i);
+      B.push_back(base);
+      base += off(i, up_e);
+    }
+    const i64 L = (i64)chain.size();
+    i64 cmin = 0, cmax = 0;
+    for (i64 k = 0; k < L; ++k) {
+      const i64 a = runs[chain[k]].r0 - B[k], b = a + runs[chain[k]].len;
+      cmin = k == 0 ? a : std::min(cmin, a);
+      cmax = k == 0 ? b : std::max(cmax, b);
+    }
+    for (i64 W = cmin - 1; W + 1 < cmax; W += geo.W) {
+      auto range = [&](i64 k, i64& lo, i64& hi) {
+        const i64 a = runs[chain[k]].r0 - B[k], b = a + runs[chain[k]].len;
+        lo = std::max(a, W + 1);
+        hi = std::min(b, W + 1 + geo.W);
+        return lo < hi;
+      };
+      i64 k = 0;
+      while (k < L) {
+        i64 lo, hi;
+        if (!range(k, lo, hi)) { ++k; continue; }
+        i64 k1 = k;
+        while (k1 < L && k1 - k < geo.kmax && range(k1, lo, hi)) ++k1;
+        const int K = (int)(k1 - k);
+        bool fits = safe(B[k] + off(chain[k], dn_e) + W) && safe(B[k1 - 1] + off(chain[k1 - 1], up_e) + W);
+        for (i64 q = k; q < k1 && fits; ++q) {
+          fits = safe(B[q] + W);
+          if (Y) fits = fits && safe(B[q] + W + off(chain[q], 2)) && safe(B[q] + W + off(chain[q], 3));
+        }
+        if (!fits) {
+          for (i64 q = k; q < k1; ++q) {
+            range(q, lo, hi);
+            fallback.push_back(RowRange{B[q] + lo, B[q] + hi, cnt});
+          }
+          k = k1;
+          continue;
+        }
+        Unit u;
+        u.rec.assign(geo.REC, 0);
+        range(k, lo, hi);
+        u.key = (int)(B[k] + lo);
+        const int Kp = K <= geo.KS ? geo.KS : geo.K;   // the kernel's two unit sizes: shorter units end with empty planes
+        u.rec[0] = Kp | (cnt << 8);   // | active lanes << 16, below
+        u.rec[1] = u.key;
+        for (int q = 0; q < 2 * cnt; ++q) u.rec[2 + q] = info[RI * chain[k] + 8 + q];
+        u.rec[16] = (int)(B[k] + off(chain[k], dn_e) + W);
+        u.rec[17] = (int)(B[k1 - 1] + off(chain[k1 - 1], up_e) + W);
+        int hi_max = 0;
+        for (int i = 0; i < K; ++i) {
+          const i64 q = k + i;
+          range(q, lo, hi);
+          hi_max = std::max(hi_max, (int)(hi - W));
+          u.rec[18 + 4 * i] = (int)(B[q] + W);
+          u.rec[19 + 4 * i] = Y ? off(chain[q], 3) : 0;   // -lateral
+          u.rec[20 + 4 * i] = Y ? off(chain[q], 2) : 0;   // +lateral
+          u.rec[21 + 4 * i] = (int)(lo - W) | ((int)(hi - W) << 8);
+          rows_m += hi - lo;
+        }
+        // rows < hi_max need elements <= hi_max of the lines: lanes 0 .. hi_max / 2
+        u.rec[0] |= std::min(64, hi_max / 2 + 1) << 16;
+        for (int i = K; i < Kp; ++i) {
+          // closing planes compute nothing (lo = hi); their line is the one ABOVE the last real plane -- the line that
+          // plane's +plane tap reads, and a valid address for every load of the closing plane
+          u.rec[18 + 4 * i] = u.rec[17];
+          u.rec[19 + 4 * i] = 0;
+          u.rec[20 + 4 * i] = 0;
+          u.rec[21 + 4 * i] = 1 | (1 << 8);
+        }
+        units.push_back(std::move(u));
+        k = k1;
+      }
+    }
+  }
+  std::sort(units.begin(), units.end(), [](const Unit& a, const Unit& b) { return a.key < b.key; });
+  mrec.reserve(units.size() * geo.REC);
+  for (auto& u : units) mrec.insert(mrec.end(), u.rec.begin(), u.rec.end());
+}
+
+}  // namespace pghost

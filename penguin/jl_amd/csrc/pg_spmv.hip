@@ -26,6 +26,7 @@
 #include <thread>
 #include <vector>
 
+#include "pg_host_algos.h"
 #include "pg_krylov.h"
 #include "pg_spmv.h"
 
@@ -895,9 +896,7 @@ struct Slice {
   int bnd;   // 1: some row references a ghost column (the slice waits for the halo exchange)
 };
 
-struct MRun {
-  int r0, len, cnt;   // rows [r0, r0 + len) with one stencil (offsets and values), cnt = 5 / 7 entries
-};
+using pghost::MRun;   // rows [r0, r0 + len) with one stencil (offsets and values), cnt = 5 / 7 entries
 
 constexpr int RUN_INFO = 24;   // dwords per run: 8 offsets, 8 values (lo, hi)
 
@@ -963,9 +962,9 @@ void emit_u_rows(std::vector<Slice>& up, i64 a, i64 b, int cnt) {
   }
 }
 
-// Chains of runs that face each other across the slowest stencil direction, cut into windows of MARCH_W computed rows
-// and units of <= MARCH_K planes (see "marching units").  mrec: the unit records, sorted by first row; rows that cannot
-// march (no -1 / 0 / +1 middle, windows that would read outside the vector) are appended to `up` as U slices.
+// Chains of runs -> unit records: the planning itself is plain host code (pg_host_algos.h: also compiled, with
+// AddressSanitizer / UBSan, into the CPU test-suite); here: the run descriptors come from the device and the result goes
+// back.  Rows that cannot march are appended to `up` as U slices.
 void build_march_units(CsrMatrix& A, const std::vector<MRun>& runs, std::vector<int>& mrec, std::vector<Slice>& up) {
   A.rows_m = 0;
   const i64 nr = (i64)runs.size();
@@ -981,132 +980,13 @@ void build_march_units(CsrMatrix& A, const std::vector<MRun>& runs, std::vector<
     PG_HIP(hipGetLastError());
     d_info.download(info.data(), RUN_INFO * nr);
   }
-  auto off = [&](i64 i, int k) { return info[RUN_INFO * i + k]; };
-  auto same_values = [&](i64 i, i64 j, int cnt) {
-    for (int k = 0; k < 2 * cnt; ++k)
-      if (info[RUN_INFO * i + 8 + k] != info[RUN_INFO * j + 8 + k]) return false;
-    return true;
-  };
-  // entries of a marching row, in the order eval_row emits them: +1, -1, [+Y, -Y,] +Z, -Z, 0 with 1 < Y < Z
-  std::vector<char> ok(nr, 0);
-  for (i64 i = 0; i < nr; ++i) {
-    const int cnt = runs[i].cnt;
-    bool good = off(i, 0) == 1 && off(i, 1) == -1 && off(i, cnt - 1) == 0;
-    const int up_e = cnt - 3, dn_e = cnt - 2;
-    good = good && off(i, up_e) > 1 && off(i, dn_e) < -1;
-    if (cnt == 7) good = good && off(i, 2) > 1 && off(i, 2) < off(i, up_e) && off(i, 3) < -1 && off(i, 3) > off(i, dn_e);
-    ok[i] = good;
-    if (!ok[i]) emit_u_rows(up, runs[i].r0, (i64)runs[i].r0 + runs[i].len, cnt);
-  }
-  // successor of run i: the run that holds most of the rows r + o[cnt - 1], r in run i, if it mirrors the offset and
-  // carries the same values; every run has at most one predecessor
-  std::vector<int> succ(nr, -1), pred(nr, -1);
-  for (i64 i = 0; i < nr; ++i) {
-    if (!ok[i]) continue;
-    const int cnt = runs[i].cnt, up_off = off(i, cnt - 3);
-    const i64 lo = (i64)runs[i].r0 + up_off, hi = lo + runs[i].len;
-    i64 j = std::upper_bound(runs.begin(), runs.end(), lo, [](i64 v, const MRun& r) { return v < (i64)r.r0; }) - runs.begin();
-    if (j > 0) --j;
-    i64 best = -1, best_ov = 0;
-    for (; j < nr && (i64)runs[j].r0 < hi; ++j) {
-      const i64 a = runs[j].r0, b = a + runs[j].len;
-      if (b <= lo || j == i || !ok[j] || pred[j] >= 0 || runs[j].cnt != cnt || off(j, cnt - 2) != -up_off || !same_values(i, j, cnt)) continue;
-      const i64 ov = std::min(hi, b) - std::max(lo, a);
-      if (ov > best_ov) { best_ov = ov; best = j; }
-    }
-    if (best >= 0) { succ[i] = (int)best; pred[best] = (int)i; }
-  }
-  struct Unit { int key; std::vector<int> rec; };
-  std::vector<Unit> units;
-  const i64 n = A.n;
   static const int kmax = getenv("PG_SPMV_MARCH_K") ? std::max(1, std::min(MARCH_K, atoi(getenv("PG_SPMV_MARCH_K")))) : MARCH_K;
-  auto safe = [&](i64 idx0) { return idx0 >= 0 && idx0 + 130 <= n + 8; };
-  std::vector<i64> chain, B;
-  for (i64 h = 0; h < nr; ++h) {
-    if (!ok[h] || pred[h] >= 0) continue;
-    chain.clear(); B.clear();
-    const int cnt = runs[h].cnt;
-    const bool Y = cnt == 7;
-    i64 base = runs[h].r0;
-    const int up_e = cnt - 3, dn_e = cnt - 2;   // entries of the +plane / -plane taps
-    for (i64 i = h; i >= 0; i = succ[i]) {
-      chain.push_back(i);
-      B.push_back(base);
-      base += off(i, up_e);
-    }
-    const i64 L = (i64)chain.size();
-    i64 cmin = 0, cmax = 0;
-    for (i64 k = 0; k < L; ++k) {
-      const i64 a = runs[chain[k]].r0 - B[k], b = a + runs[chain[k]].len;
-      cmin = k == 0 ? a : std::min(cmin, a);
-      cmax = k == 0 ? b : std::max(cmax, b);
-    }
-    for (i64 W = cmin - 1; W + 1 < cmax; W += MARCH_W) {
-      auto range = [&](i64 k, i64& lo, i64& hi) {
-        const i64 a = runs[chain[k]].r0 - B[k], b = a + runs[chain[k]].len;
-        lo = std::max(a, W + 1);
-        hi = std::min(b, W + 1 + MARCH_W);
-        return lo < hi;
-      };
-      i64 k = 0;
-      while (k < L) {
-        i64 lo, hi;
-        if (!range(k, lo, hi)) { ++k; continue; }
-        i64 k1 = k;
-        while (k1 < L && k1 - k < kmax && range(k1, lo, hi)) ++k1;
-        const int K = (int)(k1 - k);
-        bool fits = safe(B[k] + off(chain[k], dn_e) + W) && safe(B[k1 - 1] + off(chain[k1 - 1], up_e) + W);
-        for (i64 q = k; q < k1 && fits; ++q) {
-          fits = safe(B[q] + W);
-          if (Y) fits = fits && safe(B[q] + W + off(chain[q], 2)) && safe(B[q] + W + off(chain[q], 3));
-        }
-        if (!fits) {
-          for (i64 q = k; q < k1; ++q) {
-            range(q, lo, hi);
-            emit_u_rows(up, B[q] + lo, B[q] + hi, cnt);
-          }
-          k = k1;
-          continue;
-        }
-        Unit u;
-        u.rec.assign(MARCH_REC, 0);
-        range(k, lo, hi);
-        u.key = (int)(B[k] + lo);
-        const int Kp = K <= MARCH_KS ? MARCH_KS : MARCH_K;   // the kernel's two unit sizes: shorter units end with empty planes
-        u.rec[0] = Kp | (cnt << 8);   // | active lanes << 16, below
-        u.rec[1] = u.key;
-        for (int q = 0; q < 2 * cnt; ++q) u.rec[2 + q] = info[RUN_INFO * chain[k] + 8 + q];
-        u.rec[16] = (int)(B[k] + off(chain[k], dn_e) + W);
-        u.rec[17] = (int)(B[k1 - 1] + off(chain[k1 - 1], up_e) + W);
-        int hi_max = 0;
-        for (int i = 0; i < K; ++i) {
-          const i64 q = k + i;
-          range(q, lo, hi);
-          hi_max = std::max(hi_max, (int)(hi - W));
-          u.rec[18 + 4 * i] = (int)(B[q] + W);
-          u.rec[19 + 4 * i] = Y ? off(chain[q], 3) : 0;   // -lateral
-          u.rec[20 + 4 * i] = Y ? off(chain[q], 2) : 0;   // +lateral
-          u.rec[21 + 4 * i] = (int)(lo - W) | ((int)(hi - W) << 8);
-          A.rows_m += hi - lo;
-        }
-        // rows < hi_max need elements <= hi_max of the lines: lanes 0 .. hi_max / 2
-        u.rec[0] |= std::min(64, hi_max / 2 + 1) << 16;
-        for (int i = K; i < Kp; ++i) {
-          // closing planes compute nothing (lo = hi); their line is the one ABOVE the last real plane -- the line that
-          // plane's +plane tap reads, and a valid address for every load of the closing plane
-          u.rec[18 + 4 * i] = u.rec[17];
-          u.rec[19 + 4 * i] = 0;
-          u.rec[20 + 4 * i] = 0;
-          u.rec[21 + 4 * i] = 1 | (1 << 8);
-        }
-        units.push_back(std::move(u));
-        k = k1;
-      }
-    }
-  }
-  std::sort(units.begin(), units.end(), [](const Unit& a, const Unit& b) { return a.key < b.key; });
-  mrec.reserve(units.size() * MARCH_REC);
-  for (auto& u : units) mrec.insert(mrec.end(), u.rec.begin(), u.rec.end());
+  pghost::MarchGeometry geo{MARCH_K, MARCH_KS, MARCH_REC, MARCH_W, RUN_INFO, kmax};
+  std::vector<pghost::RowRange> fallback;
+  i64 rows_m = 0;
+  pghost::plan_march_units(A.n, runs, info, geo, mrec, fallback, rows_m);
+  A.rows_m = rows_m;
+  for (const auto& f : fallback) emit_u_rows(up, f.a, f.b, f.cnt);
 }
 
 // stencil-slice image of A (see "stencil slices" above); rp = host copy of A.rowptr
