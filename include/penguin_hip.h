@@ -40,7 +40,9 @@ enum { PG_BODY_BALL = 1, PG_BODY_MULTIBALL = 2, PG_BODY_HALFSPACE = 3 }; /* clos
 enum { PG_FLAG_COMPLEMENT = 1, PG_FLAG_NO_CENTROIDS = 2 };
 /* capacity fields for pg_capacity_get (d = dimension for A,B,W,C_omega,C_gamma) */
 enum { PG_CAP_V = 0, PG_CAP_GAMMA = 1, PG_CAP_CELL_TYPES = 2, PG_CAP_A = 3, PG_CAP_B = 4,
-       PG_CAP_W = 5, PG_CAP_C_OMEGA = 6, PG_CAP_C_GAMMA = 7 };
+       PG_CAP_W = 5, PG_CAP_C_OMEGA = 6, PG_CAP_C_GAMMA = 7,
+       /* space-time capacities only: A_(N+1) at the lower / upper time face ("Vn_1", "Vn"), time component of C_ω / C_γ */
+       PG_CAP_ST_V0 = 8, PG_CAP_ST_V1 = 9, PG_CAP_ST_CT_OMEGA = 10, PG_CAP_ST_CT_GAMMA = 11 };
 enum { PG_OP_G = 0, PG_OP_H = 1, PG_OP_WINV = 2,
        PG_OP_C0 = 3 /* C_d: PG_OP_C0 + d */, PG_OP_K0 = 6 /* K_d: PG_OP_K0 + d */ };   /* ConvectionOps */
 /* interface / border condition kinds                         src/boundary.jl:12-50 */
@@ -171,6 +173,29 @@ int32_t pg_capacity_create_from_arrays(pg_mesh* m, const double* V, const double
                                        const double* const* B, const double* const* W, const double* Gamma,
                                        const double* const* C_omega, const double* const* C_gamma,
                                        const double* cell_types, pg_capacity** out);
+/* Capacity(body, SpaceTimeMesh(mesh, [t0, t1])), prescribedmotionsolver/diffusion.jl:251-252 (mesh.jl:129-146): the first
+   time layer of the (N+1)-D capacity of a MOVING ball / half space, N = 1 or 2.  The host evaluates the motion at the
+   time-quadrature nodes it chooses (composite Gauss-Legendre inside (t0, t1), weights adding up to t1 - t0) and at the
+   two time faces; space is integrated exactly as by pg_capacity_create_levelset, time by the given rule.
+   nodes: nq x 10 doubles {tau, weight, c_1, c_2, c_3, r, dc_1/dt, dc_2/dt, dc_3/dt, dr/dt}; half space: c_1 = position,
+   dc_1/dt = its speed, r ignored.  body0 / body1 = {c_1, c_2, c_3, r} at t0 / t1.
+   pg_capacity_get: V, A_d, B_d, W_d, Γ are the first-layer space-time measures, C_ω / C_γ the spatial centroid components;
+   PG_CAP_ST_* give A_(N+1) at the two time faces and the time components of the centroids. */
+typedef struct {
+  int32_t body_kind;   /* PG_BODY_BALL | PG_BODY_HALFSPACE */
+  int32_t flags;       /* PG_FLAG_COMPLEMENT | PG_FLAG_NO_CENTROIDS */
+  int32_t axis;        /* half space: 0-based axis */
+  int32_t nq;
+  double sign;         /* half space: f = sign (x_axis - position(t)) */
+  double t0, t1;
+  const double* nodes; /* nq x 10 */
+  double body0[4], body1[4];
+} pg_motion_desc;
+int32_t pg_capacity_create_spacetime(pg_mesh* m, const pg_motion_desc* motion, pg_capacity** out);
+/* marks a capacity built by pg_capacity_create_from_arrays as the first layer of a space-time capacity (arbitrary moving
+   bodies integrated by the caller): V_t0 / V_t1 = A_(N+1) at the time faces (M doubles each), Ct_* may be NULL */
+int32_t pg_capacity_set_spacetime(pg_capacity* c, double t0, double t1, const double* V_t0, const double* V_t1,
+                                  const double* Ct_omega, const double* Ct_gamma);
 int32_t pg_capacity_destroy(pg_capacity* c);
 /* out: M doubles (global padded layout; with nranks>1 only the planes this rank stores are filled,
    the rest are left untouched) */
@@ -217,6 +242,15 @@ int32_t pg_solver_create_steady_diph(pg_capacity* c1, pg_diffops* o1, pg_capacit
                                      const pg_jump_desc* ic, const pg_border_desc* borders, int32_t nborders,
                                      const double* D1, const double* D2, const double* f1, const double* f2,
                                      pg_solver** out);
+/* One space-time step of solve_MovingDiffusionUnsteadyMono! (prescribedmotionsolver/diffusion.jl:16-35, 100-160, 163-225,
+   249-258): A = [Vn_1 + Id GᵀWꜝG Ψ, -(Vn_1 - Vn) + Id GᵀWꜝH Ψ; Iᵦ HᵀWꜝG, Iᵦ HᵀWꜝH + Iₐ Γ] on the space-time capacity c
+   (Δt is inside it), b from T_prev (2M, or NULL for zeros), border rows as BC_border_mono!.  source_n / source_np1 =
+   f(C_ω.., t) and f(C_ω.., t+Δt) (M doubles or NULL = 0; the first is read by "CN" only).  pg_solver_initial_solve solves
+   it; pg_solver_get_state(-1) is the new state, the T_prev of the next slab's solver.  pg_solver_step refuses. */
+int32_t pg_solver_create_moving_mono(pg_capacity* c, pg_diffops* o, const pg_bc_desc* bc_interface,
+                                     const pg_border_desc* borders, int32_t nborders, const double* Dcoef,
+                                     const double* source_n, const double* source_np1, const double* T_prev,
+                                     int32_t scheme, pg_solver** out);
 int32_t pg_solver_destroy(pg_solver* s);
 
 /* per-step data for time-dependent closures; the host evaluates them at the reference's points and

@@ -22,3 +22,7 @@ from .utils import (  # noqa: F401,E402
     initialize_temperature_square_b, initialize_temperature_uniform_b,
 )
 from .vtk import write_vtk  # noqa: F401,E402
+from .moving import (  # noqa: F401,E402
+    MovingCircle, MovingDiffusionUnsteadyMono, MovingHalfSpace, MovingSphere, SpaceTimeCapacity, SpaceTimeMesh,
+    solve_MovingDiffusionUnsteadyMono_b,
+)

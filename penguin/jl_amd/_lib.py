@@ -25,6 +25,7 @@ class PenguinHipError(RuntimeError):
 PG_BODY_BALL, PG_BODY_MULTIBALL, PG_BODY_HALFSPACE = 1, 2, 3
 PG_FLAG_COMPLEMENT, PG_FLAG_NO_CENTROIDS = 1, 2
 PG_CAP_V, PG_CAP_GAMMA, PG_CAP_CELL_TYPES, PG_CAP_A, PG_CAP_B, PG_CAP_W, PG_CAP_C_OMEGA, PG_CAP_C_GAMMA = range(8)
+PG_CAP_ST_V0, PG_CAP_ST_V1, PG_CAP_ST_CT_OMEGA, PG_CAP_ST_CT_GAMMA = 8, 9, 10, 11   # space-time capacities only
 PG_OP_G, PG_OP_H, PG_OP_WINV = 0, 1, 2
 PG_OP_C0, PG_OP_K0 = 3, 6            # ConvectionOps: C_d = PG_OP_C0 + d, K_d = PG_OP_K0 + d
 PG_BC_NONE, PG_BC_DIRICHLET, PG_BC_NEUMANN, PG_BC_ROBIN, PG_BC_PERIODIC = 0, 1, 2, 3, 4
@@ -49,6 +50,12 @@ class pg_border_desc(C.Structure):
 class pg_jump_desc(C.Structure):
     _fields_ = [("alpha1", C.c_double), ("alpha2", C.c_double), ("g", C.c_double), ("beta1", C.c_double),
                 ("beta2", C.c_double), ("h", C.c_double), ("g_array", c_double_p), ("h_array", c_double_p)]
+
+
+class pg_motion_desc(C.Structure):
+    _fields_ = [("body_kind", C.c_int32), ("flags", C.c_int32), ("axis", C.c_int32), ("nq", C.c_int32), ("sign", C.c_double),
+                ("t0", C.c_double), ("t1", C.c_double), ("nodes", c_double_p), ("body0", C.c_double * 4),
+                ("body1", C.c_double * 4)]
 
 
 class pg_krylov_opts(C.Structure):

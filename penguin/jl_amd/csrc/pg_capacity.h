@@ -15,6 +15,12 @@ struct pg_capacity {
   pg::DevBuf<double> A[3], B[3], W[3], Cw[3], Cg[3];
   double kernel_ms = 0.0;
   pg::i64 n_cut_local = 0;
+  // space-time capacity of ONE time slab [t0, t1] (pg_spacetime.hip): V, A, B, W, Γ above are the time-integrated
+  // measures of the first time layer of the reference's (N+1)-D capacity; Vt = A_(N+1) at the two time faces
+  // (V(t0), V(t1)), Ctw / Ctg = the time components of the space-time centroids C_ω / C_γ
+  bool spacetime = false;
+  double t0 = 0.0, t1 = 0.0;
+  pg::DevBuf<double> Vt[2], Ctw, Ctg;
 };
 
 struct pg_diffops {

@@ -301,6 +301,219 @@ __global__ void k_plane_weights(GeoView g, BallSet bs, i64 plane_lo, i64 plane_h
   }
 }
 
+// ---- space-time capacities of one time slab [t0, t1] ------------------------------------------------------------
+// Capacity(body, SpaceTimeMesh(mesh, [t, t+Δt])) of the reference (prescribedmotionsolver/diffusion.jl:251-252) hands the
+// (N+1)-D cell  (space cell) x [t0, t1]  to libvofi.  Here the body is a ball / half space whose parameters move in
+// time, and every first-layer capacity is the time integral of the corresponding spatial measure (exact in space, as
+// the static kernels; composite Gauss-Legendre in time, nodes supplied by the host which evaluates the motion there):
+//   V = ∫V(τ)dτ   C_ω = ∫∫(x, τ) / V   A_d = ∫A_d(τ)dτ   B_d = ∫|{x_d = C_ω,d} ∩ fluid(τ)|dτ   W_d = ∫|box(C_ω) ∩ fluid(τ)|dτ
+//   Γ = ∫Γ(τ) sqrt(1 + v_n²) dτ  (v_n: normal speed of the interface at the spatial interface centroid)
+//   A_(N+1) at the two time faces = V(t0), V(t1)   ("Vn_1", "Vn" of diffusion.jl:113-114)
+struct MotionNode {
+  double tau, w, c[3], r, dc[3], dr;   // half space: c[0] = position, dc[0] = its speed
+};
+struct MotionView {
+  int kind, complement, axis, nq;
+  double sgn, t0, t1;
+  const MotionNode* q;
+  MotionNode end[2];
+};
+
+__device__ inline void body_at(const MotionView& mv, const MotionNode& q, BallSet& bs) {
+  if (mv.kind == BODY_HALFSPACE) bs.pos = q.c[0];
+  else {
+    for (int d = 0; d < 3; ++d) bs.c[0][d] = q.c[d];
+    bs.r = q.r;
+  }
+}
+
+__device__ inline BallSet body_init(const MotionView& mv, int N) {
+  BallSet bs;
+  bs.N = N; bs.nballs = 1; bs.complement = mv.complement; bs.kind = mv.kind; bs.axis = mv.axis; bs.sgn = mv.sgn;
+  bs.r = 1.0; bs.pos = 0.0;
+  for (int d = 0; d < 3; ++d) bs.c[0][d] = 0.0;
+  return bs;
+}
+
+__global__ void k_st_cells(GeoView g, MotionView mv, i64 Mloc, double* V, double* G, double* ct, double* Cw0, double* Cw1,
+                           double* Cw2, double* Cg0, double* Cg1, double* Cg2, double* Vt0, double* Vt1, double* Ctw,
+                           double* Ctg) {
+  double* Cw[3] = {Cw0, Cw1, Cw2};
+  double* Cg[3] = {Cg0, Cg1, Cg2};
+  const double dt = mv.t1 - mv.t0;
+  for (i64 lc = blockIdx.x * (i64)blockDim.x + threadIdx.x; lc < Mloc; lc += (i64)gridDim.x * blockDim.x) {
+    i64 idx[3];
+    decode_cell(g.N, g.ext, g.plane, g.s0, lc, idx);
+    double v = 0.0, gam = 0.0, t = 0.0, v0 = 0.0, v1 = 0.0, tw = 0.0, tg = 0.0;
+    double cw[3] = {0.0, 0.0, 0.0}, cg[3] = {0.0, 0.0, 0.0};
+    if (is_real_cell(g, idx)) {
+      double lo[3], hi[3];
+      cell_box(g, idx, lo, hi);
+      BallSet bs = body_init(mv, g.N);
+      bool all_full = true, all_empty = true;
+      for (int e = 0; e < 2; ++e) {
+        body_at(mv, mv.end[e], bs);
+        const BoxMeasure m = box_measure(bs, lo, hi, false, c_gl);
+        (e == 0 ? v0 : v1) = m.vol;
+        all_full = all_full && m.type == PG_FULL;
+        all_empty = all_empty && m.type == PG_EMPTY;
+      }
+      double mom[3] = {0.0, 0.0, 0.0}, gm[3] = {0.0, 0.0, 0.0}, momt = 0.0, gmt = 0.0;
+      for (int k = 0; k < mv.nq; ++k) {
+        const MotionNode q = mv.q[k];
+        body_at(mv, q, bs);
+        const BoxMeasure m = box_measure(bs, lo, hi, true, c_gl);
+        all_full = all_full && m.type == PG_FULL;
+        all_empty = all_empty && m.type == PG_EMPTY;
+        const double wv = q.w * m.vol;
+        v += wv;
+        momt += wv * q.tau;
+        for (int d = 0; d < g.N; ++d) mom[d] += wv * m.cen[d];
+        if (m.gamma > 0.0) {
+          double vn;
+          if (mv.kind == BODY_HALFSPACE) vn = q.dc[0];
+          else {
+            double nn = 0.0, dot = 0.0;
+            for (int d = 0; d < g.N; ++d) {
+              const double e = m.cg[d] - q.c[d];
+              nn += e * e;
+              dot += e * q.dc[d];
+            }
+            vn = q.dr + (nn > 0.0 ? dot / sqrt(nn) : 0.0);
+          }
+          const double ws = q.w * m.gamma * sqrt(1.0 + vn * vn);
+          gam += ws;
+          gmt += ws * q.tau;
+          for (int d = 0; d < g.N; ++d) gm[d] += ws * m.cg[d];
+        }
+      }
+      for (int d = 0; d < g.N; ++d) cw[d] = 0.5 * (lo[d] + hi[d]);
+      tw = 0.5 * (mv.t0 + mv.t1);
+      if (all_full) {                       // same bits in every full cell (see full_measure)
+        v = full_measure(g, -1) * dt;
+        v0 = v1 = full_measure(g, -1);
+        t = (double)PG_FULL;
+      } else if (all_empty) {
+        v = 0.0;
+        t = (double)PG_EMPTY;
+      } else {
+        t = (double)PG_CUT;
+        if (v > 0.0) {
+          for (int d = 0; d < g.N; ++d) cw[d] = mom[d] / v;
+          tw = momt / v;
+        }
+        if (gam > 0.0) {
+          for (int d = 0; d < g.N; ++d) cg[d] = gm[d] / gam;
+          tg = gmt / gam;
+        }
+      }
+    }
+    V[lc] = v; G[lc] = gam; ct[lc] = t; Vt0[lc] = v0; Vt1[lc] = v1; Ctw[lc] = tw; Ctg[lc] = tg;
+    for (int d = 0; d < g.N; ++d) {
+      Cw[d][lc] = cw[d];
+      if (Cg[d]) Cg[d][lc] = cg[d];
+    }
+  }
+}
+
+// A_d, B_d: the conventions of k_sections, integrated over the slab
+__global__ void k_st_sections(GeoView g, MotionView mv, i64 Mloc, const double* ct, const double* Cw0, const double* Cw1,
+                              const double* Cw2, double* A0, double* A1, double* A2, double* B0, double* B1, double* B2) {
+  const double* Cw[3] = {Cw0, Cw1, Cw2};
+  double* A[3] = {A0, A1, A2};
+  double* B[3] = {B0, B1, B2};
+  const double dt = mv.t1 - mv.t0;
+  for (i64 lc = blockIdx.x * (i64)blockDim.x + threadIdx.x; lc < Mloc; lc += (i64)gridDim.x * blockDim.x) {
+    i64 idx[3];
+    decode_cell(g.N, g.ext, g.plane, g.s0, lc, idx);
+    const bool real = is_real_cell(g, idx);
+    BallSet bs = body_init(mv, g.N);
+    for (int d = 0; d < g.N; ++d) {
+      bool others_real = true;
+      for (int k = 0; k < g.N; ++k)
+        if (k != d && idx[k] >= g.n[k]) others_real = false;
+      double a = 0.0, b = 0.0;
+      if (others_real) {
+        double lo[3], hi[3];
+        for (int k = 0; k < g.N; ++k) {
+          const i64 ik = idx[k] < g.n[k] ? idx[k] : g.n[k] - 1;
+          lo[k] = g.nodes[k][ik];
+          hi[k] = g.nodes[k][ik + 1];
+        }
+        double t = (double)PG_CUT;
+        if (real) t = ct[lc];
+        else if (idx[d] >= g.n[d] && lc - g.stride[d] >= 0) t = ct[lc - g.stride[d]];
+        if (g.N > 1 && t == (double)PG_FULL) {
+          a = full_measure(g, d) * dt;
+          b = real ? a : 0.0;
+        } else if (g.N > 1 && t == (double)PG_EMPTY) {
+          a = 0.0;
+          b = 0.0;
+        } else {
+          for (int k = 0; k < mv.nq; ++k) {
+            const MotionNode q = mv.q[k];
+            body_at(mv, q, bs);
+            a += q.w * section_measure(bs, d, g.nodes[d][idx[d]], lo, hi, full_measure(g, d));
+            if (real) b += q.w * section_measure(bs, d, Cw[d][lc], lo, hi, full_measure(g, d));
+          }
+        }
+      }
+      A[d][lc] = a;
+      B[d][lc] = b;
+    }
+  }
+}
+
+// W_d: the conventions of k_stagger, integrated over the slab
+__global__ void k_st_stagger(GeoView g, MotionView mv, i64 Mloc, const double* ct, const double* Cw0, const double* Cw1,
+                             const double* Cw2, double* W0, double* W1, double* W2) {
+  const double* Cw[3] = {Cw0, Cw1, Cw2};
+  double* W[3] = {W0, W1, W2};
+  const double dt = mv.t1 - mv.t0;
+  for (i64 lc = blockIdx.x * (i64)blockDim.x + threadIdx.x; lc < Mloc; lc += (i64)gridDim.x * blockDim.x) {
+    i64 idx[3];
+    decode_cell(g.N, g.ext, g.plane, g.s0, lc, idx);
+    BallSet bs = body_init(mv, g.N);
+    for (int d = 0; d < g.N; ++d) {
+      double w = 0.0;
+      bool others_real = true;
+      for (int k = 0; k < g.N; ++k)
+        if (k != d && idx[k] >= g.n[k]) others_real = false;
+      const i64 ip = idx[d] - 1 < 0 ? 0 : idx[d] - 1;
+      const i64 in = idx[d] < g.n[d] - 1 ? idx[d] : g.n[d] - 1;
+      const i64 lp = lc + (ip - idx[d]) * g.stride[d];
+      const i64 ln = lc + (in - idx[d]) * g.stride[d];
+      const bool have = lp >= 0 && ln >= 0 && lp < Mloc && ln < Mloc;
+      if (others_real && have && ip != in) {
+        const double tp = ct[lp], tn = ct[ln];
+        if (!(tp == 0.0 && tn == 0.0)) {
+          double lo[3], hi[3];
+          for (int k = 0; k < g.N; ++k) {
+            if (k == d) continue;
+            lo[k] = g.nodes[k][idx[k]];
+            hi[k] = g.nodes[k][idx[k] + 1];
+          }
+          lo[d] = Cw[d][lp];
+          hi[d] = Cw[d][ln];
+          bool degenerate = false;
+          for (int k = 0; k < g.N; ++k)
+            if (!(hi[k] - lo[k] > 0.0)) degenerate = true;
+          if (!degenerate) {
+            if (tp == 1.0 && tn == 1.0) w = full_measure(g, -1) * dt;
+            else
+              for (int k = 0; k < mv.nq; ++k) {
+                const MotionNode q = mv.q[k];
+                body_at(mv, q, bs);
+                w += q.w * box_measure(bs, lo, hi, false, c_gl).vol;
+              }
+          }
+        }
+      }
+      W[d][lc] = w;
+    }
+  }
+}
+
 GeoView geo_view(pg_mesh* m, const Slab& s) {
   GeoView g;
   g.N = s.N;
@@ -520,6 +733,106 @@ int32_t pg_capacity_create_from_arrays(pg_mesh* m, const double* V, const double
   PG_API_END
 }
 
+int32_t pg_capacity_create_spacetime(pg_mesh* m, const pg_motion_desc* mo, pg_capacity** out) {
+  PG_API_BEGIN
+  require_init();
+  PG_REQUIRE(m && mo && out && mo->nodes, "pg_capacity_create_spacetime: NULL argument");
+  PG_REQUIRE(ctx().nranks == 1 && !ctx().comm, "pg_capacity_create_spacetime: single rank only");
+  const int N = m->N;
+  PG_REQUIRE(N == 1 || N == 2, "space-time capacities: 1-D+t and 2-D+t (the reference's 3-D+t blocks drop the z direction)");
+  PG_REQUIRE(mo->body_kind == PG_BODY_BALL || mo->body_kind == PG_BODY_HALFSPACE, "moving body: PG_BODY_BALL or PG_BODY_HALFSPACE");
+  PG_REQUIRE(mo->nq >= 1 && mo->nq <= 4096, "pg_capacity_create_spacetime: 1 .. 4096 time nodes");
+  PG_REQUIRE(mo->t1 > mo->t0, "pg_capacity_create_spacetime: empty time slab");
+  MotionView mv;
+  std::memset(&mv, 0, sizeof(mv));
+  mv.kind = mo->body_kind == PG_BODY_HALFSPACE ? BODY_HALFSPACE : BODY_BALLS;
+  mv.complement = (mo->flags & PG_FLAG_COMPLEMENT) ? 1 : 0;
+  mv.axis = mo->axis;
+  mv.sgn = mo->sign < 0.0 ? -1.0 : 1.0;
+  mv.nq = mo->nq;
+  mv.t0 = mo->t0;
+  mv.t1 = mo->t1;
+  if (mv.kind == BODY_HALFSPACE) PG_REQUIRE(mv.axis >= 0 && mv.axis < N, "moving half space: axis must be 0 .. N-1");
+  std::vector<MotionNode> hq(mo->nq);
+  double wsum = 0.0;
+  for (int k = 0; k < mo->nq; ++k) {
+    const double* r = mo->nodes + (size_t)k * 10;
+    MotionNode& q = hq[k];
+    q.tau = r[0]; q.w = r[1];
+    for (int d = 0; d < 3; ++d) { q.c[d] = r[2 + d]; q.dc[d] = r[6 + d]; }
+    q.r = r[5]; q.dr = r[9];
+    PG_REQUIRE(q.tau > mo->t0 && q.tau < mo->t1, "time nodes must lie inside (t0, t1)");
+    if (mv.kind == BODY_BALLS) PG_REQUIRE(q.r > 0.0, "ball radius must be positive");
+    wsum += q.w;
+  }
+  PG_REQUIRE(fabs(wsum - (mo->t1 - mo->t0)) <= 1e-12 * (mo->t1 - mo->t0), "time weights must add up to t1 - t0");
+  for (int e = 0; e < 2; ++e) {
+    const double* b = e == 0 ? mo->body0 : mo->body1;
+    std::memset(&mv.end[e], 0, sizeof(MotionNode));
+    mv.end[e].tau = e == 0 ? mo->t0 : mo->t1;
+    for (int d = 0; d < 3; ++d) mv.end[e].c[d] = b[d];
+    mv.end[e].r = b[3];
+    if (mv.kind == BODY_BALLS) PG_REQUIRE(b[3] > 0.0, "ball radius must be positive");
+  }
+  DevBuf<MotionNode> dq(mo->nq);
+  dq.upload(hq.data(), mo->nq);
+  mv.q = dq.p;
+
+  auto* c = new pg_capacity();
+  std::unique_ptr<pg_capacity> guard(c);
+  c->mesh = m;
+  c->N = N;
+  c->from_body = false;        // (the stored body is not the geometry: nothing may re-evaluate it)
+  c->has_cg = !(mo->flags & PG_FLAG_NO_CENTROIDS);
+  c->spacetime = true;
+  c->t0 = mo->t0;
+  c->t1 = mo->t1;
+  c->slab = m->base_slab();
+  ensure_gl();
+  alloc_fields(c);
+  const i64 Ml = c->slab.Mloc();
+  c->Vt[0].alloc(Ml); c->Vt[1].alloc(Ml); c->Ctw.alloc(Ml); c->Ctg.alloc(Ml);
+  hipStream_t st = ctx().stream;
+  GeoView g = geo_view(m, c->slab);
+  EventPair ev;
+  PG_HIP(hipEventRecord(ev.e0, st));
+  const int gr = grid_for(Ml, 64, 256 * 16);
+  hipLaunchKernelGGL(k_st_cells, dim3(gr), dim3(64), 0, st, g, mv, Ml, c->V.p, c->G.p, c->ct.p, c->Cw[0].p, c->Cw[1].p,
+                     c->Cw[2].p, c->Cg[0].p, c->Cg[1].p, c->Cg[2].p, c->Vt[0].p, c->Vt[1].p, c->Ctw.p, c->Ctg.p);
+  PG_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_st_sections, dim3(gr), dim3(64), 0, st, g, mv, Ml, c->ct.p, c->Cw[0].p, c->Cw[1].p, c->Cw[2].p,
+                     c->A[0].p, c->A[1].p, c->A[2].p, c->B[0].p, c->B[1].p, c->B[2].p);
+  PG_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_st_stagger, dim3(gr), dim3(64), 0, st, g, mv, Ml, c->ct.p, c->Cw[0].p, c->Cw[1].p, c->Cw[2].p,
+                     c->W[0].p, c->W[1].p, c->W[2].p);
+  PG_HIP(hipGetLastError());
+  PG_HIP(hipEventRecord(ev.e1, st));
+  PG_HIP(hipEventSynchronize(ev.e1));
+  float ms = 0.f;
+  PG_HIP(hipEventElapsedTime(&ms, ev.e0, ev.e1));
+  c->kernel_ms = ms;
+  *out = guard.release();
+  PG_API_END
+}
+
+int32_t pg_capacity_set_spacetime(pg_capacity* c, double t0, double t1, const double* V_t0, const double* V_t1,
+                                  const double* Ct_omega, const double* Ct_gamma) {
+  PG_API_BEGIN
+  require_init();
+  PG_REQUIRE(c && V_t0 && V_t1, "pg_capacity_set_spacetime: NULL argument");
+  PG_REQUIRE(!c->from_body && ctx().nranks == 1, "pg_capacity_set_spacetime: for capacities built from arrays, single rank");
+  const i64 M = c->slab.M;
+  c->Vt[0].alloc(M); c->Vt[1].alloc(M); c->Ctw.alloc(M); c->Ctg.alloc(M);
+  c->Vt[0].upload(V_t0, M);
+  c->Vt[1].upload(V_t1, M);
+  c->Ctw.zero(); c->Ctg.zero();
+  if (Ct_omega) c->Ctw.upload(Ct_omega, M);
+  if (Ct_gamma) c->Ctg.upload(Ct_gamma, M);
+  c->spacetime = true;
+  c->t0 = t0; c->t1 = t1;
+  PG_API_END
+}
+
 int32_t pg_capacity_destroy(pg_capacity* c) {
   PG_API_BEGIN
   delete c;
@@ -540,6 +853,10 @@ int32_t pg_capacity_get(const pg_capacity* c, int32_t field, int32_t d, double* 
       PG_REQUIRE(d >= 0 && d < c->N, "pg_capacity_get: bad dimension");
       src = field == PG_CAP_A ? &c->A[d] : field == PG_CAP_B ? &c->B[d] : field == PG_CAP_W ? &c->W[d]
           : field == PG_CAP_C_OMEGA ? &c->Cw[d] : &c->Cg[d];
+      break;
+    case PG_CAP_ST_V0: case PG_CAP_ST_V1: case PG_CAP_ST_CT_OMEGA: case PG_CAP_ST_CT_GAMMA:
+      PG_REQUIRE(c->spacetime, "pg_capacity_get: not a space-time capacity");
+      src = field == PG_CAP_ST_V0 ? &c->Vt[0] : field == PG_CAP_ST_V1 ? &c->Vt[1] : field == PG_CAP_ST_CT_OMEGA ? &c->Ctw : &c->Ctg;
       break;
     default: throw Error("pg_capacity_get: unknown field");
   }

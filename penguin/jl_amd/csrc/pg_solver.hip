@@ -61,6 +61,9 @@ struct pg_solver {
   i64 steps_done = 0;
   DevBuf<double> red_scratch;  // max-abs partials
   DevBuf<i64> border_cells_lin;  // global linear index of each border cell (mesh order), lazily uploaded
+  // moving body (pg_solver_create_moving_mono): one space-time step; Ψn1 = psip.(Vn, Vn_1), Ψn = psim.(Vn, Vn_1)
+  bool moving = false;
+  DevBuf<double> psi_p, psi_m;
 };
 
 namespace {
@@ -108,7 +111,7 @@ __global__ void k_row_static(SysParams P, RowSegs seg, i64 n_own, const int* row
         fx = 1;
         bv = (bk == PG_BC_PERIODIC) ? 0.0 : kv.v[key];
       } else {
-        m = P.mass * P.cap[ph].V[lc];
+        m = P.mv_psi_w ? P.mv_v1[lc] : P.mass * P.cap[ph].V[lc];   // moving: b1 = Vn Tω + ...  (diffusion.jl:214,216)
       }
     } else if (P.nphase == 2) {
       fx = 1;   // jump rows: b2 = g, b4 = Γ₂h for both schemes (diffusion.jl:415-416)
@@ -129,7 +132,7 @@ struct SrcView {
 
 // time-data part of the right-hand side                 diffusion.jl:257-261, 409-416
 __global__ void k_bconst(SysParams P, RowSegs seg, i64 n_own, const int* row_cell, SrcView s, int scheme, double dt,
-                         const unsigned char* fixed, const double* bcv, double* bconst) {
+                         const unsigned char* fixed, const double* bcv, double* bconst, int moving) {
   for (i64 r = blockIdx.x * (i64)blockDim.x + threadIdx.x; r < n_own; r += (i64)gridDim.x * blockDim.x) {
     const int k = seg_kind(seg, r);
     const i64 lc = row_cell[r];
@@ -151,7 +154,7 @@ __global__ void k_bconst(SysParams P, RowSegs seg, i64 n_own, const int* row_cel
     } else if (P.nphase == 1) {
       const double G = P.cap[0].G[lc];
       const double g1 = s.g_np1 ? s.g_np1[lc] : s.g_const;
-      if (scheme == PG_SCHEME_CN) {
+      if (scheme == PG_SCHEME_CN && !moving) {   // moving: b2 = Γ g under both schemes (diffusion.jl:218)
         const double g0 = s.g_n ? s.g_n[lc] : s.g_const;
         v = dt / 2 * G * (g0 + g1);
       } else {
@@ -299,17 +302,37 @@ __global__ void k_scale_state(i64 n, const double* __restrict__ ds, const double
 // K8, constructor form: T0 and K*T0 live in the padded layout (T0 may be non-zero at eliminated unknowns)
 __global__ void k_rhs_first(RowSegs seg, i64 n, i64 Mloc, int scheme, const int* row_cell, const double* T0pad,
                             const double* ypad, const double* mass, const double* bconst,
-                            const unsigned char* fixed, double* braw, double* x0) {
+                            const unsigned char* fixed, double* braw, double* x0, int moving) {
   for (i64 r = blockIdx.x * (i64)blockDim.x + threadIdx.x; r < n; r += (i64)gridDim.x * blockDim.x) {
     const int k = seg_kind(seg, r);
     const i64 q = (i64)k * Mloc + row_cell[r];
     const double T = T0pad[q];
     double v;
     if (fixed[r]) v = bconst[r];
+    else if (moving && (k & 1)) v = bconst[r];                                        // b2 = Γ g
+    else if (moving && scheme == PG_SCHEME_CN) v = mass[r] * T - ypad[q] + bconst[r];   // (Vn - Id GᵀWꜝGΨn)Tω - ½Id GᵀWꜝH Tγ + ...
     else if (scheme == PG_SCHEME_CN) v = 2.0 * (mass[r] * T) - ypad[q] + bconst[r];
     else v = mass[r] * T + bconst[r];
     braw[r] = v;
     x0[r] = T;
+  }
+}
+
+// Ψn1 = psip.(Vn, Vn_1), Ψn = psim.(Vn, Vn_1)      prescribedmotionsolver/diffusion.jl:55-98 (the live definitions)
+__global__ void k_psi(i64 Mloc, int scheme, const double* __restrict__ vn_1 /*lower face*/, const double* __restrict__ vn,
+                      double* __restrict__ psip, double* __restrict__ psim) {
+  for (i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x; i < Mloc; i += (i64)gridDim.x * blockDim.x) {
+    const bool z1 = vn[i] == 0.0, z2 = vn_1[i] == 0.0;   // args = (Vn, Vn_1)
+    double pp, pm;
+    if (scheme == PG_SCHEME_CN) {
+      pp = (z1 && z2) ? 0.0 : (!z1 && !z2) ? 0.5 : (z1 && !z2) ? 0.5 : 1.0;   // psip_cn
+      pm = (z1 && z2) ? 0.0 : (!z1 && !z2) ? 0.5 : (z1 && !z2) ? 0.5 : 0.0;   // psim_cn
+    } else {
+      pp = (z1 && z2) ? 0.0 : 1.0;                                            // psip_be
+      pm = 0.0;                                                               // psim_be
+    }
+    psip[i] = pp;
+    psim[i] = pm;
   }
 }
 
@@ -380,6 +403,25 @@ SysParams make_params(const pg_solver* s, int scheme) {
   }
   for (int k = 0; k < 6; ++k) P.border_kind[k] = s->border_kind[k];
   P.inv_dx = s->inv_dx;
+  if (s->moving) {            // Δt lives inside the space-time capacities
+    P.theta = 1.0;
+    P.gscale = 1.0;
+    P.mass = 1.0;
+    P.mv_v0 = s->cap[0]->Vt[0].p;
+    P.mv_v1 = s->cap[0]->Vt[1].p;
+    P.mv_psi_w = s->psi_p.p;
+    P.mv_psi_g = s->psi_p.p;
+  }
+  return P;
+}
+
+// the explicit operator of the moving Crank-Nicolson right-hand side (diffusion.jl:214)
+SysParams make_params_moving_explicit(const pg_solver* s) {
+  SysParams P = make_params(s, PG_SCHEME_CN);
+  P.mv_psi_w = s->psi_m.p;
+  P.mv_psi_g = nullptr;
+  P.mv_gconst = 0.5;
+  P.mv_explicit = 1;
   return P;
 }
 
@@ -408,7 +450,7 @@ void ensure_bconst(pg_solver* s, int scheme) {
   if (n > 0) {
     const SysParams P = make_params(s, scheme);
     hipLaunchKernelGGL(k_bconst, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, st, P, make_segs(s->nb), n, s->nb.row_cell.p,
-                       src_view(s), scheme, s->dt, s->fixed.p, s->bcv.p, s->bconst.p);
+                       src_view(s), scheme, s->dt, s->fixed.p, s->bcv.p, s->bconst.p, s->moving ? 1 : 0);
     PG_HIP(hipGetLastError());
   }
   s->bconst_scheme = scheme;
@@ -426,13 +468,13 @@ void build_first_rhs(pg_solver* s) {
   if (s->scheme_ctor == PG_SCHEME_CN) {
     ypad.alloc((i64)s->K * s->Mloc);
     ypad.zero();
-    apply_rows_padded(P, s->slab, s->T0pad.p, ypad.p);
+    apply_rows_padded(s->moving ? make_params_moving_explicit(s) : P, s->slab, s->T0pad.p, ypad.p);
   }
   if (n > 0) {
     DevBuf<double> braw(n);
     hipLaunchKernelGGL(k_rhs_first, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, st, make_segs(s->nb), n, s->Mloc,
                        s->scheme_ctor, s->nb.row_cell.p, s->T0pad.p, ypad.p, s->mass.p, s->bconst.p, s->fixed.p, braw.p,
-                       s->x.p);
+                       s->x.p, s->moving ? 1 : 0);
     PG_HIP(hipGetLastError());
     apply_left(s->A_ctor, braw.p, s->b.p, st);   // b̂ = B⁻¹ S b
     PG_HIP(hipStreamSynchronize(st));
@@ -597,6 +639,7 @@ void do_initial(pg_solver* s, const pg_krylov_opts* opts, SolveStats& st) {
 
 void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& st) {
   PG_REQUIRE(s->scheme_ctor != PG_SCHEME_STEADY, "a steady solver has no time loop");
+  PG_REQUIRE(!s->moving, "a moving-body solver is one space-time step: create the next one from the next time slab");
   PG_REQUIRE(s->initial_done, "Solver is not initialized. Call pg_solver_initial_solve first.");
   const pg_krylov_opts o = opts ? *opts : default_opts();
   hipStream_t stream = ctx().stream;
@@ -686,6 +729,47 @@ int32_t pg_solver_create_unsteady_mono(pg_capacity* c, pg_diffops* o, const pg_b
   require_init();
   PG_REQUIRE(scheme == PG_SCHEME_BE || scheme == PG_SCHEME_CN, "scheme must be BE or CN");
   create_mono(c, o, bc_interface, borders, nborders, Dcoef, source, dt, T0, scheme, out);
+  PG_API_END
+}
+
+int32_t pg_solver_create_moving_mono(pg_capacity* c, pg_diffops* o, const pg_bc_desc* bc_interface,
+                                     const pg_border_desc* borders, int32_t nborders, const double* Dcoef,
+                                     const double* source_n, const double* source_np1, const double* T_prev,
+                                     int32_t scheme, pg_solver** out) {
+  PG_API_BEGIN
+  require_init();
+  PG_REQUIRE(scheme == PG_SCHEME_BE || scheme == PG_SCHEME_CN, "scheme must be BE or CN");
+  PG_REQUIRE(c && o && bc_interface && out, "solver constructor: NULL argument");
+  PG_REQUIRE(o->cap == c, "operators were built from a different capacity");
+  PG_REQUIRE(c->spacetime, "pg_solver_create_moving_mono needs a space-time capacity (pg_capacity_create_spacetime)");
+  PG_REQUIRE(!o->has_velocity, "the moving diffusion solver takes no convection operators");
+  PG_REQUIRE(ctx().nranks == 1 && !ctx().comm, "space-time steps are single-rank");
+  auto* s = new pg_solver();
+  std::unique_ptr<pg_solver> guard(s);
+  s->nphase = 1;
+  s->cap[0] = c;
+  s->ops[0] = o;
+  s->slab = c->slab;
+  s->dt = 1.0;            // Δt is inside the space-time capacities
+  s->moving = true;
+  s->scheme_ctor = scheme;
+  s->bc_i = *bc_interface;
+  const i64 Ml = s->slab.Mloc();
+  s->psi_p.alloc(Ml);
+  s->psi_m.alloc(Ml);
+  hipLaunchKernelGGL(k_psi, dim3(grid_for(Ml, BLOCK)), dim3(BLOCK), 0, ctx().stream, Ml, (int)scheme, c->Vt[0].p, c->Vt[1].p,
+                     s->psi_p.p, s->psi_m.p);
+  PG_HIP(hipGetLastError());
+  if (Dcoef) upload_local(s->Id[0], Dcoef, s->slab);
+  if (source_np1) upload_local(s->f_np1[0], source_np1, s->slab);
+  if (source_n) upload_local(s->f_n[0], source_n, s->slab);
+  if (bc_interface->value_array) {
+    upload_local(s->g_np1, bc_interface->value_array, s->slab);
+    upload_local(s->g_n, bc_interface->value_array, s->slab);
+  }
+  s->bc_i.value_array = nullptr;
+  setup_common(s, borders, nborders, T_prev);
+  *out = guard.release();
   PG_API_END
 }
 

@@ -30,6 +30,17 @@ struct SysParams {
   double mass;           // coefficient of V in the bulk rows: 1 (unsteady), 0 (steady: A_mono_stead_diff, diffusion.jl:30-43)
   int border_kind[6];    // per PG_KEY_*
   double inv_dx;         // 1/Δx for the 1-D Neumann border row
+  // moving body, mono (prescribedmotionsolver/diffusion.jl:100-160): cap[0] holds SPACE-TIME capacities (Δt is inside
+  // them: theta = gscale = 1) and the bulk rows become
+  //   [ Vn_1 + Id GᵀWꜝG Ψ ,  -(Vn_1 - Vn) + Id GᵀWꜝH Ψ ]      Ψ = diag(psip.(Vn, Vn_1)) scales COLUMNS
+  // mv_psi_w == nullptr: static problem (everything below unused)
+  const double* mv_v0;     // "Vn_1" = A_t at the lower time face, V(t_n)
+  const double* mv_v1;     // "Vn"   = A_t at the upper time face, V(t_n + Δt)
+  const double* mv_psi_w;  // per cell: scaling of the ω columns
+  const double* mv_psi_g;  // per cell: scaling of the γ columns; nullptr: the constant mv_gconst
+  double mv_gconst;
+  int mv_explicit;         // 1: the explicit Crank-Nicolson operator [Id GᵀWꜝG Ψn, ½ Id GᵀWꜝH] of :214 -- bulk rows only, no
+                           // volume terms; interface rows are empty (b2 = Γ g carries no T term there)
 };
 
 __host__ __device__ inline int nkinds(const SysParams& P) { return P.nphase == 1 ? 2 : 4; }
@@ -101,6 +112,8 @@ __device__ inline void eval_row(const SysParams& P, int kind, i64 lc, const i64*
   const bool bulk = (kind & 1) == 0;  // ω row / γ row
   const CapView& c0 = P.cap[0];
   const int N = c0.N;
+  const bool mv = P.mv_psi_w != nullptr;
+  if (mv && P.mv_explicit && !bulk) return;
 
   if (bulk) {
     int key = -1;
@@ -167,6 +180,17 @@ __device__ inline void eval_row(const SysParams& P, int kind, i64 lc, const i64*
             cm = -0.5 * a0;
             dC += 0.5 * (a1 - a0);
           }
+          if (mv) {       // column scaling Ψ (no convection in the moving solver)
+            if (L.has_p) {
+              emit(kw, lc + st, scale * (L.gl_p * L.w_p * L.gd_p) * P.mv_psi_w[lc + st]);
+              emit(kg, lc + st, scale * (L.gl_p * L.w_p * L.hd_p) * (P.mv_psi_g ? P.mv_psi_g[lc + st] : P.mv_gconst));
+            }
+            if (L.has_m) {
+              emit(kw, lc - st, scale * (L.gd_j * L.w_j * L.gl_j) * P.mv_psi_w[lc - st]);
+              emit(kg, lc - st, scale * (L.gd_j * L.w_j * L.hl_j) * (P.mv_psi_g ? P.mv_psi_g[lc - st] : P.mv_gconst));
+            }
+            continue;
+          }
           if (L.has_p) {
             emit(kw, lc + st, scale * (L.gl_p * L.w_p * L.gd_p) + P.theta * cp);
             emit(kg, lc + st, scale * (L.gl_p * L.w_p * L.hd_p));
@@ -190,7 +214,12 @@ __device__ inline void eval_row(const SysParams& P, int kind, i64 lc, const i64*
         }
       }
     }
-    if (bulk) {
+    if (bulk && mv) {
+      const double pw = P.mv_psi_w[lc], pg = P.mv_psi_g ? P.mv_psi_g[lc] : P.mv_gconst;
+      const double v0 = P.mv_explicit ? 0.0 : P.mv_v0[lc], v1 = P.mv_explicit ? 0.0 : P.mv_v1[lc];
+      emit(kw, lc, v0 + scale * dW * pw);               // Vn_1 + (Id GᵀWꜝG Ψ)_jj
+      emit(kg, lc, -(v0 - v1) + scale * dG * pg);       // -(Vn_1 - Vn) + (Id GᵀWꜝH Ψ)_jj
+    } else if (bulk) {
       const double ck = P.conv_k[q] ? P.conv_k[q][lc] : 0.0;          // 0.5 sum(K): on both diagonals (A11 and A12)
       emit(kw, lc, P.mass * c.V[lc] + scale * dW + P.theta * (dC + ck));   // V + θ(Id·GᵀWꜝG + ΣC + ½ΣK)_jj  (steady: no V)
       emit(kg, lc, scale * dG + P.theta * ck);

@@ -1,0 +1,186 @@
+"""GPU parity of the prescribed-motion path: pg_capacity_create_spacetime + pg_solver_create_moving_mono
+through penguin.jl_amd.moving against oracle/spacetime.py.
+
+* capacities: same time rule on both sides -> agreement to rounding (the spatial code and every padding convention);
+  a 4x finer rule on the oracle's side -> the time-quadrature error of the default rule, bounded here;
+* algebra: the oracle assembles and solves (direct `\\`) with the capacities the HIP path computed -> states <= 1e-10."""
+import numpy as np
+import pytest
+
+from oracle import penguin_oracle as po
+from oracle import spacetime as ost
+from tests.common import rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL_T = 1e-10
+
+
+def _bodies_1d(pj):
+    pos, dpos = (lambda t: 0.21 + 0.9 * t + 0.5 * t * t), (lambda t: 0.9 + t)
+    return pj.MovingHalfSpace(0, pos, 1.0, dposition=dpos), ost.MovingHalfSpace(0, pos, 1.0, dposition=dpos)
+
+
+def _bodies_2d(pj, complement=False):
+    cen, dcen = (lambda t: (2.01 + 0.8 * t, 1.97 - 0.5 * t)), (lambda t: (0.8, -0.5))
+    rad, drad = (lambda t: 1.0 + 0.4 * t), (lambda t: 0.4)
+    return (pj.MovingSphere(cen, rad, complement, dcenter=dcen, dradius=drad),
+            ost.MovingBall(cen, rad, complement, dcenter=dcen, dradius=drad))
+
+
+def _cases(pj):
+    return {
+        "1d": (pj.Mesh((40,), (1.0,), (0.0,)), po.Mesh((40,), (1.0,), (0.0,)), _bodies_1d(pj), 0.01),
+        "2d": (pj.Mesh((16, 16), (4.0, 4.0), (0.0, 0.0)), po.Mesh((16, 16), (4.0, 4.0), (0.0, 0.0)), _bodies_2d(pj), 0.05),
+        "2d_outside": (pj.Mesh((16, 16), (4.0, 4.0), (0.0, 0.0)), po.Mesh((16, 16), (4.0, 4.0), (0.0, 0.0)),
+                       _bodies_2d(pj, True), 0.05),
+    }
+
+
+def _oracle_cap(cap, omesh, t0, t1, obody=None) -> po.Capacity:
+    """The (N+1)-D oracle capacity holding the fields the HIP path computed (second time layer: A_(N+1) only)."""
+    N = omesh.N
+    z = np.zeros_like(cap.V)
+    two = lambda a: np.concatenate([a, z])
+    A = tuple(two(a) for a in cap.A) + (np.concatenate([cap.Vn_1, cap.Vn]),)
+    B = tuple(two(b) for b in cap.B) + (two(z),)
+    W = tuple(two(w) for w in cap.W) + (two(z),)
+    zz = np.zeros((len(z), N + 1))
+    return po.Capacity(A, B, two(cap.V), W, np.vstack([cap.C_ω_st, zz]), np.vstack([cap.C_γ_st, zz]), two(cap.Γ),
+                       two(cap.cell_types), ost.SpaceTimeMesh(omesh, [t0, t1]), obody)
+
+
+@pytest.mark.parametrize("name", ["1d", "2d", "2d_outside"])
+def test_spacetime_capacities_match_oracle(pj, name):
+    mesh, omesh, (body, obody), dt = _cases(pj)[name]
+    N, M = omesh.N, int(np.prod(omesh.ext))
+    h = float(omesh.nodes[0][1] - omesh.nodes[0][0])
+    t0 = 0.1
+    cap = pj.Capacity(body, pj.SpaceTimeMesh(mesh, [t0, t0 + dt]), time_panels=8, time_order=4)
+    assert isinstance(cap, pj.SpaceTimeCapacity)
+    same = ost.make_spacetime_capacity(obody, omesh, t0, t0 + dt, panels=8, order=4)
+    lay = ost.spatial_layer(same, omesh)
+    cellm, facem = h ** N * dt, h ** (N - 1) * dt
+    assert np.array_equal(cap.cell_types, lay.cell_types)                       # classification bit for bit
+    assert np.array_equal(np.flatnonzero(cap.Γ > 0), np.flatnonzero(lay.G > 0))
+    assert np.max(np.abs(cap.V - lay.V)) <= 1e-12 * cellm
+    assert np.max(np.abs(cap.Vn_1 - same.A[N][:M])) <= 1e-12 * h ** N and np.max(np.abs(cap.Vn - same.A[N][M:])) <= 1e-12 * h ** N
+    assert np.max(np.abs(cap.Γ - lay.G)) <= 1e-11 * facem
+    big = lay.V > 1e-3 * cellm
+    assert np.max(np.abs(cap.C_ω_st[big] - same.C_w[:M][big])) <= 1e-9 * h
+    cut = lay.G > 1e-3 * facem
+    assert np.max(np.abs(cap.C_γ_st[cut] - same.C_g[:M][cut])) <= 1e-9 * h
+    for d in range(N):
+        assert np.max(np.abs(cap.A[d] - lay.A[d])) <= 1e-12 * facem
+        assert np.max(np.abs(cap.B[d] - lay.B[d])) <= 1e-7 * facem               # through C_ω of tiny cells
+        assert np.max(np.abs(cap.W[d] - lay.W[d])) <= 1e-7 * cellm
+    # reference layout: N+1 face capacities of length 2M, the last one = [Vn_1; Vn]
+    assert len(cap.A_st) == N + 1 and all(len(a) == 2 * M for a in cap.A_st)
+    # the default time rule (16 x 4) against a 4x finer one: kinks of V(τ) where the interface passes a cell corner
+    dflt = pj.Capacity(body, pj.SpaceTimeMesh(mesh, [t0, t0 + dt]))
+    fine = ost.spatial_layer(ost.make_spacetime_capacity(obody, omesh, t0, t0 + dt, panels=64, order=4), omesh)
+    assert np.max(np.abs(dflt.V - fine.V)) <= 2e-4 * cellm
+    for d in range(N):
+        assert np.max(np.abs(dflt.A[d] - fine.A[d])) <= (2e-2 if N == 1 else 2e-3) * facem   # 1-D: A_d(τ) is a step function
+
+
+@pytest.mark.parametrize("name,scheme,bc_kind", [
+    ("1d", "BE", "dirichlet"), ("1d", "CN", "dirichlet"), ("1d", "BE", "robin"),
+    ("2d", "BE", "dirichlet"), ("2d", "CN", "dirichlet"), ("2d", "CN", "robin"), ("2d_outside", "BE", "dirichlet"),
+])
+def test_moving_steps_match_oracle(pj, name, scheme, bc_kind):
+    """MovingDiffusionUnsteadyMono + solve_MovingDiffusionUnsteadyMono! (diffusion.jl:16-35, 227-268): 1 + 4 slabs, sources,
+    variable D, time-dependent border and interface data, fresh and dead cells (the interface crosses cell faces)."""
+    mesh, omesh, (body, obody), dt = _cases(pj)[name]
+    N, M = omesh.N, int(np.prod(omesh.ext))
+    f = lambda x, y, z, t: 0.3 + 0.2 * x + 0.5 * t            # (x, t_c, 0, t) in 1-D+t, (x, y, t_c, t) in 2-D+t
+    D = lambda x, y, z: 1.0 + 0.1 * x
+    if bc_kind == "robin":
+        g = lambda x, y, z=0.0: 0.5 + 0.1 * x
+        bc, obc = pj.Robin(0.7, 1.3, g), po.Robin(0.7, 1.3, g)
+    else:
+        g = lambda x, y, z=0.0: 1.0 + 0.2 * x + 0.3 * y       # y = t_c in 1-D+t
+        bc, obc = pj.Dirichlet(g), po.Dirichlet(g)
+    keys = ("bottom",) if N == 1 else ("left", "right", "top", "bottom")
+    bval = lambda *a: 0.2 + 0.1 * a[-1]                       # value(x.., t)
+    bcb = pj.BorderConditions({k: pj.Dirichlet(bval) for k in keys})
+    obcb = po.BorderConditions({k: po.Dirichlet(bval) for k in keys})
+    rng = np.random.default_rng(7)
+    T0 = rng.random(2 * M)
+    caps = {}
+
+    def capacity_fn(t0, t1):
+        c = pj.Capacity(body, pj.SpaceTimeMesh(mesh, [t0, t1]))
+        caps[t0] = c
+        return _oracle_cap(c, omesh, t0, t1, obody)
+
+    cap0 = pj.Capacity(body, pj.SpaceTimeMesh(mesh, [0.0, dt]))
+    ph = pj.Phase(cap0, pj.DiffusionOps(cap0), f, D)
+    s = pj.MovingDiffusionUnsteadyMono(ph, bcb, bc, dt, T0, mesh, scheme)
+    pj.solve_MovingDiffusionUnsteadyMono_b(s, ph, body, dt, 0.0, 3.5 * dt, bcb, bc, mesh, scheme, method="bicgstab", reltol=1e-14)
+    ocap0 = _oracle_cap(cap0, omesh, 0.0, dt, obody)
+    oph = po.Phase(ocap0, po.make_diffusion_ops(ocap0), f, D)
+    so = ost.MovingDiffusionUnsteadyMono(oph, obcb, obc, dt, T0, omesh, scheme)
+    # the loop of diffusion.jl:227-268 written out (ost.solve_MovingDiffusionUnsteadyMono), so that every slab's system can
+    # be probed: `sens` = how far the ORACLE's own direct solution moves when its matrix entries move by one rounding error.
+    # Robin / Neumann rows on the arbitrarily small space-time cut cells a moving interface leaves behind are sensitive
+    # (the small-cell problem); the parity bar is 1e-10 wherever the system itself is determined that well.
+    sens, t = [], 0.0
+
+    def solve_and_probe():
+        po.solve_system(so)
+        so.states.append(so.x)
+        A, b = so.last_A_reduced, so.last_b_reduced
+        Ap = A.copy()
+        Ap.data = Ap.data * (1.0 + 2.2e-16 * np.random.default_rng(1).standard_normal(len(Ap.data)))
+        import scipy.sparse.linalg as spla
+        sens.append(rel_l2(spla.spsolve(Ap.tocsc(), b), spla.spsolve(A.tocsc(), b)))
+
+    solve_and_probe()
+    while t < 3.5 * dt:
+        t += dt
+        ocap = capacity_fn(t, t + dt)
+        oop = po.make_diffusion_ops(ocap)
+        so.A = ost.A_mono_unstead_diff_moving(oop, ocap, D, obc, scheme)
+        so.b = ost.b_mono_unstead_diff_moving(oop, ocap, D, f, obc, so.states[-1], dt, t, scheme)
+        so.A, so.b = po.BC_border_mono(so.A, so.b, obcb, omesh, t=t)
+        solve_and_probe()
+    assert len(s.states) == len(so.states) == 5
+    assert s.unconverged == 0
+    nact = set()
+    for k, (x, xo) in enumerate(zip(s.states, so.states)):
+        assert np.array_equal(np.flatnonzero(x != 0.0), np.flatnonzero(xo != 0.0)), f"active set of state {k}"
+        tol = max(TOL_T, 50.0 * max(sens[: k + 1]))
+        if bc_kind == "dirichlet":
+            assert tol == TOL_T, f"state {k}: a Dirichlet system this sensitive ({max(sens):.1e}) is not expected"
+        assert rel_l2(x, xo) <= tol, f"state {k}: {rel_l2(x, xo):.2e} (bar {tol:.1e})"
+        nact.add(int(np.count_nonzero(xo)))
+    assert len(nact) > 1          # the active set did change from slab to slab (fresh / dead cells were exercised)
+
+
+def test_moving_uniform_state_is_preserved(pj):
+    """no cell changes phase during these slabs: T = Tγ = g = border value must stay exactly that (Vn_1 - (Vn_1 - Vn) = Vn)."""
+    mesh = pj.Mesh((20,), (1.0,), (0.0,))
+    body = pj.MovingHalfSpace(0, lambda t: 0.301 + 0.3 * t, 1.0, dposition=lambda t: 0.3)
+    dt, M = 0.01, 21
+    for scheme in ("BE", "CN"):
+        cap = pj.Capacity(body, pj.SpaceTimeMesh(mesh, [0.0, dt]))
+        ph = pj.Phase(cap, pj.DiffusionOps(cap), lambda x, y, z, t: 0.0, lambda x, y, z: 1.0)
+        bc, bcb = pj.Dirichlet(1.0), pj.BorderConditions({"bottom": pj.Dirichlet(1.0)})
+        s = pj.MovingDiffusionUnsteadyMono(ph, bcb, bc, dt, np.ones(2 * M), mesh, scheme)
+        pj.solve_MovingDiffusionUnsteadyMono_b(s, ph, body, dt, 0.0, 3 * dt, bcb, bc, mesh, scheme)
+        assert len(s.states) == 4
+        for x in s.states:
+            act = x != 0.0
+            assert act.sum() >= 6 and np.abs(x[act] - 1.0).max() < 1e-11
+
+
+def test_moving_solver_refuses_what_it_cannot_do(pj):
+    mesh = pj.Mesh((8, 8, 8), (1.0,) * 3, (0.0,) * 3)
+    body = pj.MovingSphere(lambda t: (0.5, 0.5, 0.5), lambda t: 0.3 + t)
+    with pytest.raises(pj.PenguinHipError, match="1-D\\+t and 2-D\\+t"):
+        pj.Capacity(body, pj.SpaceTimeMesh(mesh, [0.0, 0.1]))
+    m1 = pj.Mesh((20,), (1.0,), (0.0,))
+    static = pj.Capacity(pj.HalfSpace(0, 0.3), m1)
+    ph = pj.Phase(static, pj.DiffusionOps(static), lambda x, y, z, t: 0.0, 1.0)
+    with pytest.raises(pj.PenguinHipError, match="space-time capacity"):
+        pj.MovingDiffusionUnsteadyMono(ph, pj.BorderConditions({}), pj.Dirichlet(0.0), 0.1, np.zeros(42), m1, "BE")
