@@ -184,3 +184,34 @@ def test_moving_solver_refuses_what_it_cannot_do(pj):
     ph = pj.Phase(static, pj.DiffusionOps(static), lambda x, y, z, t: 0.0, 1.0)
     with pytest.raises(pj.PenguinHipError, match="space-time capacity"):
         pj.MovingDiffusionUnsteadyMono(ph, pj.BorderConditions({}), pj.Dirichlet(0.0), 0.1, np.zeros(42), m1, "BE")
+
+
+@pytest.mark.parametrize("scheme", ["BE", "CN"])
+def test_moving_interface_similarity_solution(pj, scheme):
+    """The HIP path against the analytic field of a growing half line (tests/test_oracle_spacetime.py::similarity_problem):
+    second order in h with Δt = 2h², the same error levels as the oracle's run."""
+    from tests.test_oracle_spacetime import similarity_problem
+    pos, dpos, exact = similarity_problem()
+    errs = []
+    for nx in (40, 80):
+        h = 1.0 / nx
+        dt = 2.0 * h * h
+        mesh, M = pj.Mesh((nx,), (1.0,), (0.0,)), nx + 1
+        body = pj.MovingHalfSpace(0, pos, 1.0, dposition=dpos)
+        cap = pj.Capacity(body, pj.SpaceTimeMesh(mesh, [0.0, dt]), time_panels=32)
+        ph = pj.Phase(cap, pj.DiffusionOps(cap), lambda x, y, z, t: 0.0, 1.0)
+        bcb = pj.BorderConditions({"bottom": pj.Dirichlet(lambda x, t: exact(x + h, t + dt))})
+        c0 = pj.Capacity(pj.HalfSpace(0, pos(0.0)), mesh)
+        T0 = np.concatenate([np.where(c0.V > 0, exact(c0.C_ω[:, 0], 0.0), 0.0), np.zeros(M)])
+        s = pj.MovingDiffusionUnsteadyMono(ph, bcb, pj.Dirichlet(0.0), dt, T0, mesh, scheme)
+        pj.solve_MovingDiffusionUnsteadyMono_b(s, ph, body, dt, 0.0, 0.1, bcb, pj.Dirichlet(0.0), mesh, scheme, time_panels=32)
+        assert s.unconverged == 0
+        tf = dt * len(s.states)
+        cf = pj.Capacity(pj.HalfSpace(0, pos(tf)), mesh)
+        x = s.states[-1][:M]
+        sel = (cf.V > 0.5 * h) & (x != 0.0)
+        errs.append(float(np.abs(x[sel] - exact(cf.C_ω[sel, 0], tf)).max()))
+    if scheme == "BE":
+        assert errs[0] < 2.5e-3 and errs[1] < 0.4 * errs[0], errs
+    else:       # an order below BE at these sizes; the error then stalls near the interface (fresh cells restart from 0)
+        assert errs[0] < 3e-4 and errs[1] < 3e-4, errs

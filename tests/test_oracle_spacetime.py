@@ -129,3 +129,47 @@ def test_moving_interface_heats_the_fluid_it_uncovers():
     assert len(act) > 15                                   # the fluid domain grew from 4 to ~8 cells... and beyond
     assert Tw.min() >= -1e-12 and Tw.max() <= 1.0 + 1e-12
     assert np.all(np.diff(Tw[act]) > -1e-12)               # rises towards the hot interface
+
+
+def similarity_problem(lam=0.6, t_shift=0.05):
+    """Heat conduction in 0 < x < s(t) = 2λ√(t + t_shift) with T(0) = 1, T(s) = 0: T = 1 - erf(x / 2√(t + t_shift)) / erf(λ)
+    (the temperature field of the one-phase Stefan problem; examples/1D/SolidMoving/MovingHeat.jl moves its interface the
+    same way, `xf + c√t`).  The clock is shifted so that the run starts at t = 0 with a smooth state."""
+    import math
+    from scipy.special import erf
+    pos = lambda t: 2 * lam * math.sqrt(t + t_shift)
+    dpos = lambda t: lam / math.sqrt(t + t_shift)
+    exact = lambda x, t: 1.0 - erf(np.asarray(x) / (2 * np.sqrt(t + t_shift))) / erf(lam)
+    return pos, dpos, exact
+
+
+def run_similarity_oracle(nx, scheme, Te=0.1):
+    pos, dpos, exact = similarity_problem()
+    h = 1.0 / nx
+    dt = 2.0 * h * h
+    mesh, M = po.Mesh((nx,), (1.0,), (0.0,)), nx + 1
+    body = ost.MovingHalfSpace(0, pos, 1.0, dposition=dpos)
+    mk = lambda a, b: ost.make_spacetime_capacity(body, mesh, a, b, panels=32)
+    cap = mk(0.0, dt)
+    ph = po.Phase(cap, po.make_diffusion_ops(cap), lambda x, y, z, t=0.0: 0.0, lambda x, y, z: 1.0)
+    # the first cell spans [h/2, 3h/2] although mesh.centers[0] = 0 (src/mesh.jl:49-50): its unknown sits at x = h; the border
+    # rows are applied with the time of the slab's START while the unknown lives at its end
+    bcb = po.BorderConditions({"bottom": po.Dirichlet(lambda x, t: float(exact(x + h, t + dt)))})
+    c0 = po.make_capacity(body.at(0.0), mesh)
+    T0 = np.concatenate([np.where(c0.V > 0, exact(c0.C_w[:, 0], 0.0), 0.0), np.zeros(M)])
+    s = ost.MovingDiffusionUnsteadyMono(ph, bcb, po.Dirichlet(0.0), dt, T0, mesh, scheme)
+    ost.solve_MovingDiffusionUnsteadyMono(s, ph, body, dt, 0.0, Te, bcb, po.Dirichlet(0.0), mesh, scheme, capacity_fn=mk)
+    tf = dt * len(s.states)
+    cf = po.make_capacity(body.at(tf), mesh)
+    x = s.states[-1][:M]
+    sel = (cf.V > 0.5 * h) & (x != 0.0)
+    return float(np.abs(x[sel] - exact(cf.C_w[sel, 0], tf)).max())
+
+
+@pytest.mark.parametrize("scheme", ["BE", "CN"])
+def test_moving_interface_similarity_solution(scheme):
+    """known answer for the moving blocks as restated (names Vn_1 / Vn, Ψ, the swept-volume term): the error against the
+    similarity solution falls at second order in h with Δt = 2h²."""
+    e20, e40 = run_similarity_oracle(20, scheme), run_similarity_oracle(40, scheme)
+    assert e20 < 8e-3 and e40 < 2.5e-3
+    assert e40 < 0.4 * e20
