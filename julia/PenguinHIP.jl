@@ -20,6 +20,8 @@ export Mesh, nC, Capacity, capacity_from_arrays, Sphere, MultiSphere, HalfSpace,
        ConvectionOps, AdvectionDiffusionSteadyMono, solve_AdvectionDiffusionSteadyMono!, AdvectionDiffusionSteadyDiph,
        solve_AdvectionDiffusionSteadyDiph!, AdvectionDiffusionUnsteadyMono, solve_AdvectionDiffusionUnsteadyMono!,
        AdvectionDiffusionUnsteadyDiph, solve_AdvectionDiffusionUnsteadyDiph!,
+       SpaceTimeMesh, MovingSphere, MovingHalfSpace, SpaceTimeCapacity, MovingDiffusionUnsteadyMono,
+       solve_MovingDiffusionUnsteadyMono!,
        ∇, ∇₋, gmres, bicgstabl, cg
 
 const libpg = get(ENV, "PENGUIN_HIP_LIB", joinpath(@__DIR__, "..", "penguin", "jl_amd", "lib", "libpenguin_hip.so"))
@@ -624,6 +626,202 @@ end
 function solve_AdvectionDiffusionUnsteadyDiph!(s::Solver, p1::Phase, p2::Phase, Δt::Float64, Tₑ, bc_b, ic, scheme::String; kwargs...)
     scheme == "BE" || error("solve_AdvectionDiffusionUnsteadyDiph!: only scheme \"BE\" is available on the HIP path")
     solve_DiffusionUnsteadyDiph!(s, p1, p2, Δt, Tₑ, bc_b, ic, "BE"; kwargs...)
+end
+
+# ---------------------------------------------------------------------------------- prescribed motion (prescribedmotionsolver/diffusion.jl)
+# SpaceTimeMesh (src/mesh.jl:129-146), Capacity(body, STmesh), MovingDiffusionUnsteadyMono (:16-35) and
+# solve_MovingDiffusionUnsteadyMono! (:227-268).  The moving level set is a tagged body whose parameters are functions of
+# time; every slab's capacity is built on the GPU (pg_capacity_create_spacetime: exact in space, composite Gauss-Legendre
+# in time) and the moving blocks are assembled there (pg_solver_create_moving_mono).  1-D and 2-D in space.
+struct SpaceTimeMesh{M} <: AbstractMesh
+    nodes::NTuple{M, Vector{Float64}}
+    centers::NTuple{M, Vector{Float64}}
+    tag
+    dims::NTuple{M, Int}
+    space::Mesh
+end
+function SpaceTimeMesh(spaceMesh::Mesh{N}, time::Vector{Float64}; tag=spaceMesh.tag) where N
+    length(time) == 2 || error("SpaceTimeMesh: one time cell [t, t+Δt]")
+    nodes = ntuple(i -> i <= N ? spaceMesh.nodes[i] : time, N + 1)
+    centers = ntuple(i -> i <= N ? spaceMesh.centers[i] : [(time[1] + time[2]) / 2], N + 1)
+    SpaceTimeMesh{N + 1}(nodes, centers, tag, ntuple(i -> length(centers[i]), N + 1), spaceMesh)
+end
+nC(m::SpaceTimeMesh) = prod(m.dims)
+
+abstract type MovingBody <: Function end
+"f(x, t) = |x - center(t)| - radius(t)  (complement: -f, the growing disc of examples/2D/SolidMoving/MovingHeat.jl:19)"
+struct MovingSphere <: MovingBody
+    center::Function; radius::Function; complement::Bool
+end
+MovingSphere(center, radius; complement::Bool=false) = MovingSphere(center, radius, complement)
+"f(x, t) = sign (x_axis - position(t))  (examples/1D/SolidMoving/MovingHeat.jl:18); axis is 1-based as everywhere in Julia"
+struct MovingHalfSpace <: MovingBody
+    axis::Int; position::Function; sign::Float64; complement::Bool
+end
+MovingHalfSpace(axis, position; sign::Float64=1.0, complement::Bool=false) = MovingHalfSpace(axis, position, sign, complement)
+function (b::MovingSphere)(xt...)
+    x, t = xt[1:end-1], xt[end]
+    c = b.center(t)
+    f = sqrt(sum((x[d] - c[d])^2 for d in 1:length(c))) - b.radius(t)
+    b.complement ? -f : f
+end
+function (b::MovingHalfSpace)(xt...)
+    f = b.sign * (xt[b.axis] - b.position(xt[end]))
+    b.complement ? -f : f
+end
+_mstate(b::MovingSphere, t, N) = (c = b.center(t); Float64[ntuple(d -> d <= N ? Float64(c[d]) : 0.0, 3)..., Float64(b.radius(t))])
+_mstate(b::MovingHalfSpace, t, N) = Float64[Float64(b.position(t)), 0.0, 0.0, 1.0]
+_mrate(b::MovingBody, t, N, h) = (_mstate(b, t + h, N) .- _mstate(b, t - h, N)) ./ (2h)       # only enters Γ
+
+struct pg_motion_desc
+    body_kind::Int32; flags::Int32; axis::Int32; nq::Int32
+    sign::Float64; t0::Float64; t1::Float64
+    nodes::Ptr{Float64}
+    body0::NTuple{4, Float64}; body1::NTuple{4, Float64}
+end
+const PG_CAP_ST_V0, PG_CAP_ST_V1, PG_CAP_ST_CT_OMEGA, PG_CAP_ST_CT_GAMMA = 8:11
+
+# Gauss-Legendre nodes / weights on [-1, 1] (Newton on P_n; no package needed)
+function _gauss(n::Int)
+    x, w = zeros(n), zeros(n)
+    for i in 1:n
+        z = cos(π * (i - 0.25) / (n + 0.5))
+        dp = 1.0
+        for _ in 1:100
+            p0, p1 = 1.0, z
+            for k in 2:n
+                p0, p1 = p1, ((2k - 1) * z * p1 - (k - 1) * p0) / k
+            end
+            dp = n * (z * p1 - p0) / (z^2 - 1)
+            dz = p1 / dp
+            z -= dz
+            abs(dz) < 1e-15 && break
+        end
+        x[i], w[i] = z, 2 / ((1 - z^2) * dp^2)
+    end
+    x, w
+end
+
+"The first time layer of the (N+1)-D capacity: the N-D fields of `Capacity{N}` plus the time-face capacities and the time
+components of the centroids.  `A_st` has the reference's layout (N+1 diagonal matrices of size 2M, the last = [Vn_1; Vn])."
+mutable struct SpaceTimeCapacity{N} <: AbstractCapacity
+    layer::Capacity{N}
+    Vn_1::Vector{Float64}; Vn::Vector{Float64}
+    Ct_ω::Vector{Float64}; Ct_γ::Vector{Float64}
+    mesh::SpaceTimeMesh
+    body::Function
+end
+function Base.getproperty(c::SpaceTimeCapacity{N}, s::Symbol) where N
+    s in (:layer, :Vn_1, :Vn, :Ct_ω, :Ct_γ, :mesh, :body) && return getfield(c, s)
+    s === :handle && return getfield(c, :layer).handle
+    if s === :A_st
+        l = getfield(c, :layer); z = zeros(length(getfield(c, :Vn)))
+        return (ntuple(d -> _diag(vcat(Vector(diag(l.A[d])), z)), N)..., _diag(vcat(getfield(c, :Vn_1), getfield(c, :Vn))))
+    end
+    getproperty(getfield(c, :layer), s)              # A, B, V, W, Γ, C_ω, C_γ, cell_types of the layer
+end
+
+function Capacity(body::MovingBody, mesh::SpaceTimeMesh; method::String="VOFI", compute_centroids::Bool=true,
+                  time_panels::Int=16, time_order::Int=4)
+    init()
+    sp = mesh.space
+    N = length(sp.dims)
+    t0, t1 = mesh.nodes[end][1], mesh.nodes[end][2]
+    gx, gw = _gauss(time_order)
+    edges = range(t0, t1; length=time_panels + 1)
+    nq = time_panels * time_order
+    nodes = zeros(10, nq)                              # column k = {tau, w, c1, c2, c3, r, dc1, dc2, dc3, dr}
+    h = 1e-6 * (t1 - t0)
+    k = 0
+    for p in 1:time_panels, i in 1:time_order
+        k += 1
+        a, b = edges[p], edges[p + 1]
+        τ = (a + b) / 2 + (b - a) / 2 * gx[i]
+        nodes[1, k], nodes[2, k] = τ, (b - a) / 2 * gw[i]
+        nodes[3:6, k] .= _mstate(body, τ, N)
+        nodes[7:10, k] .= _mrate(body, τ, N, h)
+    end
+    nodes[2, :] .*= (t1 - t0) / sum(nodes[2, :])
+    flags = Int32((body.complement ? 1 : 0) | (compute_centroids ? 0 : 2))
+    kind = body isa MovingSphere ? Int32(1) : Int32(3)
+    axis = body isa MovingHalfSpace ? Int32(body.axis - 1) : Int32(0)
+    sgn = body isa MovingHalfSpace ? body.sign : 1.0
+    hnd = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve nodes begin
+        desc = Ref(pg_motion_desc(kind, flags, axis, Int32(nq), sgn, t0, t1, pointer(nodes),
+                                  Tuple(_mstate(body, t0, N)), Tuple(_mstate(body, t1, N))))
+        check(ccall((:pg_capacity_create_spacetime, libpg), Int32, (Ptr{Cvoid}, Ptr{pg_motion_desc}, Ptr{Ptr{Cvoid}}), sp.handle, desc, hnd))
+    end
+    layer = _wrap_capacity(hnd[], sp, body, compute_centroids)
+    M = prod(sp.dims .+ 1)
+    SpaceTimeCapacity{N}(layer, _field(hnd[], PG_CAP_ST_V0, 0, M), _field(hnd[], PG_CAP_ST_V1, 0, M),
+                         _field(hnd[], PG_CAP_ST_CT_OMEGA, 0, M), compute_centroids ? _field(hnd[], PG_CAP_ST_CT_GAMMA, 0, M) : Float64[],
+                         mesh, body)
+end
+DiffusionOps(cap::SpaceTimeCapacity) = DiffusionOps(cap.layer)
+
+# closures see the space-time centroids padded to three coordinates (build_source / build_g_g on the (N+1)-D capacity)
+_st_coords(C, Ct) = [coords3((c..., Ct[i])) for (i, c) in enumerate(C)]
+function _moving_step!(s::Solver, phase::Phase, bc_b::BorderConditions, bc_i::AbstractBoundary, Δt::Float64, Tᵢ::Vector{Float64},
+                       mesh::Mesh, scheme::String, t::Float64)
+    cap = phase.capacity
+    cap isa SpaceTimeCapacity || error("the moving solver needs a space-time capacity: Capacity(body, SpaceTimeMesh(mesh, [t, t+Δt]))")
+    Cω = _st_coords(cap.C_ω, cap.Ct_ω)
+    g = bc_i.value isa Function ? Float64[Float64(bc_i.value(c...)) for c in _st_coords(cap.C_γ, cap.Ct_γ)] : Float64[]   # :172
+    D = Float64[Float64(phase.Diffusion_coeff(c...)) for c in Cω]
+    fn1 = Float64[Float64(phase.source(c..., t + Δt)) for c in Cω]                                                       # :171
+    fn = Float64[Float64(phase.source(c..., t)) for c in Cω]                                                             # :170
+    borders = _border_descs(bc_b)
+    s.handle != C_NULL && ccall((:pg_solver_destroy, libpg), Int32, (Ptr{Cvoid},), s.handle)
+    s.handle = C_NULL
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve g D fn fn1 Tᵢ borders begin
+        desc = Ref(_interface_desc(bc_i, g))
+        check(ccall((:pg_solver_create_moving_mono, libpg), Int32,
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{pg_bc_desc}, Ptr{pg_border_desc}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                     Ptr{Float64}, Int32, Ptr{Ptr{Cvoid}}),
+                    cap.handle, phase.operator.handle, desc, borders, length(borders), D, fn, fn1, Tᵢ, _scheme(scheme), h))
+    end
+    s.handle = h[]
+    _has_border_functions(bc_b) && _set_border_values!(s, bc_b, mesh, t)
+    s.A = (cap, phase.operator)          # keeps the device capacity alive as long as this slab's solver
+    s
+end
+
+function MovingDiffusionUnsteadyMono(phase::Phase, bc_b::BorderConditions, bc_i::AbstractBoundary, Δt::Float64, Tᵢ::Vector{Float64},
+                                     mesh::AbstractMesh, scheme::String)
+    println("Solver Creation:"); println("- Moving problem"); println("- Monophasic problem"); println("- Unsteady problem"); println("- Diffusion problem")
+    s = _new_solver(:Unsteady, :Monophasic, :Diffusion, Ptr{Cvoid}(C_NULL), length(Tᵢ))
+    _moving_step!(s, phase, bc_b, bc_i, Δt, Tᵢ, mesh, scheme, 0.0)          # t = 0.0 in b and in the border rows (:27-33)
+end
+
+function solve_MovingDiffusionUnsteadyMono!(s::Solver, phase::Phase, body::Function, Δt::Float64, Tₛ::Float64, Tₑ::Float64,
+                                            bc_b::BorderConditions, bc::AbstractBoundary, mesh::AbstractMesh, scheme::String;
+                                            method::Function=gmres, algorithm=nothing, geometry_method="VOFI", kwargs...)
+    (s.handle == C_NULL) && error("Solver is not initialized. Call a solver constructor first.")
+    kw = Dict{Symbol, Any}(kwargs)
+    log = get(kw, :log, false)
+    opts = Ref(_opts(method, kw))
+    info = pg_step_info()
+    function solve!()
+        check(ccall((:pg_solver_initial_solve, libpg), Int32, (Ptr{Cvoid}, Ptr{pg_krylov_opts}, Ref{pg_step_info}), s.handle, opts, info))
+        _record!(s, info, log)
+        println("Solver Extremum : ", maximum(abs.(s.x)))
+    end
+    t = Tₛ
+    println("Time : $(t)")
+    solve!()                                                                 # :240-244
+    Tᵢ = s.x
+    while t < Tₑ                                                             # :247
+        t += Δt
+        println("Time : $(t)")
+        capacity = Capacity(body, SpaceTimeMesh(mesh, [t, t + Δt], tag=mesh.tag); compute_centroids=true, method=geometry_method)
+        ph = Phase(capacity, DiffusionOps(capacity), phase.source, phase.Diffusion_coeff)
+        _moving_step!(s, ph, bc_b, bc, Δt, Tᵢ, mesh, scheme, t)              # A, b, BC_border_mono!(...; t=t)   :254-258
+        solve!()
+        Tᵢ = s.x
+    end
+    s
 end
 
 end # module
