@@ -36,7 +36,7 @@ typedef struct pg_diffops pg_diffops;   /* Penguin.DiffusionOps{N}    src/operat
 typedef struct pg_solver pg_solver;     /* Penguin.Solver             src/solver.jl:33-42      */
 
 /* ---- enums --------------------------------------------------------------------------- */
-enum { PG_BODY_BALL = 1, PG_BODY_MULTIBALL = 2, PG_BODY_HALFSPACE = 3 }; /* closed-form level sets evaluated in-kernel */
+enum { PG_BODY_BALL = 1, PG_BODY_MULTIBALL = 2, PG_BODY_HALFSPACE = 3, PG_BODY_ELLIPSOID = 4 }; /* closed-form level sets evaluated in-kernel */
 enum { PG_FLAG_COMPLEMENT = 1, PG_FLAG_NO_CENTROIDS = 2 };
 /* capacity fields for pg_capacity_get (d = dimension for A,B,W,C_omega,C_gamma) */
 enum { PG_CAP_V = 0, PG_CAP_GAMMA = 1, PG_CAP_CELL_TYPES = 2, PG_CAP_A = 3, PG_CAP_B = 4,
@@ -164,7 +164,10 @@ int32_t pg_mesh_get_border_cells(const pg_mesh* m, int64_t* idx, double* pos, in
 /* ---- Capacity                      replaces Capacity(body, mesh; method="VOFI"), capacity.jl:51-123 */
 /* BALL: params = {c_1..c_N, r}.  MULTIBALL: params = {r, nballs, c^1_1..c^1_N, c^2_1, ...}.
    HALFSPACE: params = {axis (0-based), position, sign}: f(x) = sign (x_axis - position), fluid where f < 0 -- the
-   reference's 1-D diphasic bodies `(x,_=0) -> x - xint` (test/convergence_test.jl:111,230) and their N-D extrusions. */
+   reference's 1-D diphasic bodies `(x,_=0) -> x - xint` (test/convergence_test.jl:111,230) and their N-D extrusions.
+   ELLIPSOID: params = {c_1..c_N, a_1..a_N}: f(x) = sqrt(sum ((x_d - c_d)/a_d)^2) - 1, axis-aligned semi-axes a_d > 0
+   (volumes, faces, sections exact through the unit ball of the scaled coordinates; the interface measure by
+   Gauss-Legendre along the arcs with the weight of the affine map). */
 int32_t pg_capacity_create_levelset(pg_mesh* m, int32_t body_kind, const double* params, int32_t nparams,
                                     int32_t flags, pg_capacity** out);
 /* fallback for arbitrary Julia bodies: arrays computed by the caller (single rank only).

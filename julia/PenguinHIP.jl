@@ -13,7 +13,7 @@ module PenguinHIP
 
 using SparseArrays, StaticArrays, LinearAlgebra
 
-export Mesh, nC, Capacity, capacity_from_arrays, Sphere, MultiSphere, HalfSpace, DiffusionOps, Phase,
+export Mesh, nC, Capacity, capacity_from_arrays, Sphere, MultiSphere, HalfSpace, Ellipsoid, DiffusionOps, Phase,
        Dirichlet, Neumann, Robin, Periodic, ScalarJump, FluxJump, BorderConditions, InterfaceConditions, Solver,
        DiffusionUnsteadyMono, solve_DiffusionUnsteadyMono!, DiffusionUnsteadyDiph, solve_DiffusionUnsteadyDiph!,
        DiffusionSteadyMono, solve_DiffusionSteadyMono!, DiffusionSteadyDiph, solve_DiffusionSteadyDiph!,
@@ -165,6 +165,18 @@ function _abi(s::HalfSpace, ::Val{N}) where N
     1 <= s.axis <= N || error("HalfSpace: axis $(s.axis) does not exist on a $(N)-D mesh")
     (Int32(3), [Float64(s.axis - 1), s.position, s.sign], s.complement)
 end
+"f(x) = sqrt(sum(((x_d - c_d) / a_d)^2)) - 1 with axis-aligned semi-axes (PG_BODY_ELLIPSOID); complement: -f"
+struct Ellipsoid{N} <: TaggedBody
+    center::NTuple{N, Float64}
+    semi_axes::NTuple{N, Float64}
+    complement::Bool
+end
+Ellipsoid(center::NTuple{N, Float64}, semi_axes::NTuple{N, Float64}; complement::Bool=false) where N = Ellipsoid{N}(center, semi_axes, complement)
+function (s::Ellipsoid{N})(x...) where N
+    f = sqrt(sum(((x[d] - s.center[d]) / s.semi_axes[d])^2 for d in 1:N)) - 1.0
+    s.complement ? -f : f
+end
+_abi(s::Ellipsoid{N}, ::Val{N}) where N = (Int32(4), Float64[s.center..., s.semi_axes...], s.complement)
 
 # ---------------------------------------------------------------------------------- Capacity (src/capacity.jl:25-36)
 abstract type AbstractCapacity end

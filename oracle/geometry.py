@@ -422,3 +422,162 @@ class HalfSpace:
             if k != self.axis:
                 m = m * (hi[k] - lo[k])
         return m
+
+
+# ----------------------------------------------------------------------------
+# axis-aligned ellipsoid
+# ----------------------------------------------------------------------------
+_GL24 = np.polynomial.legendre.leggauss(24)
+
+
+def _arcs_weighted(rho: float, a: float, b: float, t0: float, t1: float, w) -> Tuple[float, float, float]:
+    """disc_arcs with a weight: int w, int w cos, int w sin over the parts of the circle of radius rho inside
+    [a,b]x[t0,t1]; w(phi) is smooth, 24-point Gauss-Legendre per angular interval."""
+    if rho <= 0.0:
+        return 0.0, 0.0, 0.0
+    cand = []
+    for xv in (a, b):
+        if -rho < xv < rho:
+            al = math.atan2(math.sqrt((rho - xv) * (rho + xv)), xv)
+            cand += [al, -al]
+    for yv in (t0, t1):
+        if -rho < yv < rho:
+            al = math.atan2(yv, math.sqrt((rho - yv) * (rho + yv)))
+            cand += [al, (math.pi - al) if al >= 0 else (-math.pi - al)]
+
+    def inside(phi: float) -> bool:
+        return a <= rho * math.cos(phi) <= b and t0 <= rho * math.sin(phi) <= t1
+
+    if not cand:
+        if not inside(0.3):
+            return 0.0, 0.0, 0.0
+        cand = [-math.pi, 0.0, math.pi]      # the whole circle, in two pieces
+        pieces = [(-math.pi, 0.0), (0.0, math.pi)]
+    else:
+        cand = sorted(set(cand))
+        m = len(cand)
+        pieces = []
+        for k in range(m):
+            p1 = cand[k]
+            p2 = cand[(k + 1) % m] + (2.0 * math.pi if k == m - 1 else 0.0)
+            if p2 > p1 and inside(0.5 * (p1 + p2)):
+                pieces.append((p1, p2))
+    x, wt = _GL24
+    tot = ic = isn = 0.0
+    for p1, p2 in pieces:
+        ph = 0.5 * (p1 + p2) + 0.5 * (p2 - p1) * x
+        ww = 0.5 * (p2 - p1) * wt * w(ph)
+        tot += float(np.sum(ww))
+        ic += float(np.sum(ww * np.cos(ph)))
+        isn += float(np.sum(ww * np.sin(ph)))
+    return tot, ic, isn
+
+
+class Ellipsoid:
+    """Level set f(x) = sqrt(sum ((x_d - c_d)/a_d)^2) - 1 (axis-aligned semi-axes a_d), fluid where f <= 0.
+
+    Everything with the dimension of a volume / a section is the unit ball's measure in the scaled coordinates
+    x' = (x - c)/a times the product of the semi-axes involved (the map is affine).  The interface measure is not affine
+    invariant: a surface element of the unit sphere with normal n maps to one of area sqrt(sum_d (n_d prod_(k!=d) a_k)^2)
+    (Nanson), integrated here along the arcs of the scaled sections (2-D: the ellipse's arc length)."""
+
+    def __init__(self, center: Sequence[float], semi_axes: Sequence[float], complement: bool = False):
+        self.c = tuple(float(v) for v in center)
+        self.a = tuple(float(v) for v in semi_axes)
+        assert len(self.c) == len(self.a) and all(v > 0 for v in self.a)
+        self.complement = bool(complement)
+        self.N = len(self.c)
+        self._unit = Ball(tuple(0.0 for _ in self.c), 1.0, False)
+
+    def __call__(self, *x):
+        f = math.sqrt(sum(((x[d] - self.c[d]) / self.a[d]) ** 2 for d in range(self.N))) - 1.0
+        return -f if self.complement else f
+
+    def _scaled(self, lo, hi):
+        n = self.N
+        return ([(lo[d] - self.c[d]) / self.a[d] for d in range(n)], [(hi[d] - self.c[d]) / self.a[d] for d in range(n)])
+
+    def _surface(self, slo, shi):
+        """interface measure and its first moments (scaled coordinates about the centre) inside the scaled box"""
+        n = self.N
+        if n == 2:
+            k0, k1 = self.a[1], self.a[0]
+            w = lambda ph: np.sqrt((k0 * np.cos(ph)) ** 2 + (k1 * np.sin(ph)) ** 2)
+            g, gx, gy = _arcs_weighted(1.0, slo[0], shi[0], slo[1], shi[1], w)
+            return g, (gx, gy)
+        from scipy.integrate import quad_vec
+        k = (self.a[1] * self.a[2], self.a[0] * self.a[2], self.a[0] * self.a[1])
+        z0, z1 = max(slo[2], -1.0), min(shi[2], 1.0)
+        if z1 <= z0:
+            return 0.0, (0.0, 0.0, 0.0)
+        crit = [0.0]
+        for xv in (slo[0], shi[0]):
+            crit.append(abs(xv))
+            for yv in (slo[1], shi[1]):
+                crit.append(math.hypot(xv, yv))
+        for yv in (slo[1], shi[1]):
+            crit.append(abs(yv))
+        pts = sorted({s for rc in crit if rc < 1.0 for s in (math.sqrt(1 - rc * rc), -math.sqrt(1 - rc * rc)) if z0 < s < z1})
+
+        def integrand(z):
+            rho = math.sqrt(max(1.0 - z * z, 0.0))
+            w = lambda ph: np.sqrt((k[0] * rho * np.cos(ph)) ** 2 + (k[1] * rho * np.sin(ph)) ** 2 + (k[2] * z) ** 2)
+            g, ic, isn = _arcs_weighted(rho, slo[0], shi[0], slo[1], shi[1], w)
+            return np.array([g, rho * ic, rho * isn, z * g])
+
+        res, _ = quad_vec(integrand, z0, z1, epsabs=1e-15, epsrel=1e-12, points=pts or None, limit=400)
+        return float(res[0]), (float(res[1]), float(res[2]), float(res[3]))
+
+    def box(self, lo, hi, want_surface: bool = True) -> BoxMeasure:
+        n = self.N
+        if n == 1:
+            return Ball(self.c, self.a[0], self.complement).box(lo, hi, want_surface)
+        ext = [hi[d] - lo[d] for d in range(n)]
+        ctr = tuple(0.5 * (lo[d] + hi[d]) for d in range(n))
+        zero = tuple(0.0 for _ in range(n))
+        slo, shi = self._scaled(lo, hi)
+        t = ball_box_type(self._unit.c, 1.0, slo, shi)
+        if any(e <= 0.0 for e in ext) or t != CUT:
+            if self.complement and t != CUT:
+                t = 1 - t
+            return BoxMeasure(t, _prod(ext) if (t == FULL and all(e > 0.0 for e in ext)) else 0.0, ctr, 0.0, zero)
+        full = _prod(ext)
+        J = _prod(list(self.a))
+        vol, mom, _, _ = _ball_box_moments(self._unit.c, 1.0, slo, shi, want_surface=False)
+        vol = vol * J
+        mom = tuple(mom[d] * J * self.a[d] for d in range(n))
+        if self.complement:
+            vol, mom = full - vol, tuple(full * (ctr[d] - self.c[d]) - mom[d] for d in range(n))
+        cen = tuple(self.c[d] + mom[d] / vol for d in range(n)) if vol > 0.0 else ctr
+        g, cg = 0.0, zero
+        if want_surface:
+            g, gm = self._surface(slo, shi)
+            if g > 0.0:
+                cg = tuple(self.c[d] + self.a[d] * gm[d] / g for d in range(n))
+        return BoxMeasure(CUT, vol, cen, g, cg)
+
+    def section(self, d: int, s: float, lo, hi) -> float:
+        n = self.N
+        if n == 1:
+            return Ball(self.c, self.a[0], self.complement).section(d, s, lo, hi)
+        others = [k for k in range(n) if k != d]
+        full = _prod([hi[k] - lo[k] for k in others])
+        plo, phi = list(lo), list(hi)
+        plo[d] = phi[d] = s
+        slo, shi = self._scaled(plo, phi)
+        t = ball_box_type(self._unit.c, 1.0, slo, shi)
+        if t != CUT:
+            if self.complement:
+                t = 1 - t
+            return full if t == FULL else 0.0
+        dz = (s - self.c[d]) / self.a[d]
+        rho2 = (1.0 - dz) * (1.0 + dz)
+        rho = math.sqrt(rho2) if rho2 > 0.0 else 0.0
+        a = [slo[k] for k in others]
+        b = [shi[k] for k in others]
+        if n == 2:
+            m, _ = seg_overlap(rho, a[0], b[0])
+        else:
+            m, _, _ = disc_rect(rho, a[0], b[0], a[1], b[1])
+        m = m * _prod([self.a[k] for k in others])
+        return (full - m) if self.complement else m

@@ -10,7 +10,7 @@ from .api import (  # noqa: F401
     AdvectionDiffusionSteadyDiph, AdvectionDiffusionSteadyMono, AdvectionDiffusionUnsteadyDiph,
     AdvectionDiffusionUnsteadyMono, ConvectionOps, solve_AdvectionDiffusionUnsteadyDiph_b,
     solve_AdvectionDiffusionSteadyDiph_b, solve_AdvectionDiffusionSteadyMono_b, solve_AdvectionDiffusionUnsteadyMono_b,
-    BorderConditions, Capacity, Circle, DarcyFlow, DarcyFlowUnsteady, DiffusionOps, DiffusionSteadyDiph, DiffusionSteadyMono, DiffusionUnsteadyDiph,
+    BorderConditions, Capacity, Circle, Ellipse, Ellipsoid, DarcyFlow, DarcyFlowUnsteady, DiffusionOps, DiffusionSteadyDiph, DiffusionSteadyMono, DiffusionUnsteadyDiph,
     DiffusionUnsteadyMono, Dirichlet,
     FluxJump, HalfSpace, InterfaceConditions, Mesh, MultiSphere, Neumann, Periodic, Phase, Robin, ScalarJump, Solver, Sphere,
     check_convergence, check_convergence_diph, div, grad, lp_norm, nC, solve_DarcyFlow_b, solve_DarcyFlowUnsteady_b, solve_darcy_velocity, solve_DiffusionSteadyDiph_b, solve_DiffusionSteadyMono_b,

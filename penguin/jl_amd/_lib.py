@@ -22,7 +22,7 @@ class PenguinHipError(RuntimeError):
 
 
 # ---- enums (mirror include/penguin_hip.h) ---------------------------------------------------
-PG_BODY_BALL, PG_BODY_MULTIBALL, PG_BODY_HALFSPACE = 1, 2, 3
+PG_BODY_BALL, PG_BODY_MULTIBALL, PG_BODY_HALFSPACE, PG_BODY_ELLIPSOID = 1, 2, 3, 4
 PG_FLAG_COMPLEMENT, PG_FLAG_NO_CENTROIDS = 1, 2
 PG_CAP_V, PG_CAP_GAMMA, PG_CAP_CELL_TYPES, PG_CAP_A, PG_CAP_B, PG_CAP_W, PG_CAP_C_OMEGA, PG_CAP_C_GAMMA = range(8)
 PG_CAP_ST_V0, PG_CAP_ST_V1, PG_CAP_ST_CT_OMEGA, PG_CAP_ST_CT_GAMMA = 8, 9, 10, 11   # space-time capacities only

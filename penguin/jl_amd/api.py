@@ -168,6 +168,31 @@ class HalfSpace:
 # =============================================================================== Capacity
 
 
+class Ellipsoid:
+    """Tagged level set f(x) = sqrt(sum ((x_d - c_d)/a_d)^2) - 1 with axis-aligned semi-axes a_d (fluid where f <= 0; an
+    ellipse in 2-D).  `complement=True` gives -f."""
+
+    def __init__(self, center: Sequence[float], semi_axes: Sequence[float], complement: bool = False):
+        self.center = tuple(float(v) for v in center)
+        self.semi_axes = tuple(float(v) for v in semi_axes)
+        if len(self.center) != len(self.semi_axes) or min(self.semi_axes) <= 0.0:
+            raise ValueError("Ellipsoid: one positive semi-axis per coordinate")
+        self.complement = bool(complement)
+
+    def __call__(self, *x):
+        f = np.sqrt(sum(((np.asarray(x[d]) - self.center[d]) / self.semi_axes[d]) ** 2 for d in range(len(self.center)))) - 1.0
+        return -f if self.complement else f
+
+    def _abi(self, N: int):
+        if len(self.center) != N:
+            raise ValueError("body dimension does not match the mesh")
+        return (L.PG_BODY_ELLIPSOID, np.array(list(self.center) + list(self.semi_axes)),
+                (L.PG_FLAG_COMPLEMENT if self.complement else 0))
+
+
+Ellipse = Ellipsoid
+
+
 class Capacity:
     """Capacity(body, mesh; method="VOFI", compute_centroids=true) -- src/capacity.jl:51-123.
 

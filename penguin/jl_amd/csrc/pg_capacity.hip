@@ -331,7 +331,7 @@ __device__ inline BallSet body_init(const MotionView& mv, int N) {
   BallSet bs;
   bs.N = N; bs.nballs = 1; bs.complement = mv.complement; bs.kind = mv.kind; bs.axis = mv.axis; bs.sgn = mv.sgn;
   bs.r = 1.0; bs.pos = 0.0;
-  for (int d = 0; d < 3; ++d) bs.c[0][d] = 0.0;
+  for (int d = 0; d < 3; ++d) { bs.c[0][d] = 0.0; bs.ax[d] = 1.0; }
   return bs;
 }
 
@@ -593,6 +593,7 @@ int32_t pg_capacity_create_levelset(pg_mesh* m, int32_t body_kind, const double*
   std::memset(&bs, 0, sizeof(bs));
   bs.N = N;
   bs.complement = (flags & PG_FLAG_COMPLEMENT) ? 1 : 0;
+  for (int d = 0; d < 3; ++d) bs.ax[d] = 1.0;
   if (body_kind == PG_BODY_BALL) {
     PG_REQUIRE(nparams == N + 1, "PG_BODY_BALL expects params = {c_1..c_N, r}");
     bs.nballs = 1;
@@ -616,6 +617,17 @@ int32_t pg_capacity_create_levelset(pg_mesh* m, int32_t body_kind, const double*
     bs.nballs = 1;
     bs.r = 1.0;
     PG_REQUIRE(bs.axis >= 0 && bs.axis < N && (double)bs.axis == params[0], "PG_BODY_HALFSPACE: axis must be 0 .. N-1");
+  } else if (body_kind == PG_BODY_ELLIPSOID) {
+    PG_REQUIRE(nparams == 2 * N, "PG_BODY_ELLIPSOID expects params = {c_1..c_N, a_1..a_N}");
+    bs.nballs = 1;
+    bs.r = 1.0;
+    for (int d = 0; d < N; ++d) {
+      bs.c[0][d] = params[d];
+      bs.ax[d] = params[N + d];
+      PG_REQUIRE(bs.ax[d] > 0.0, "PG_BODY_ELLIPSOID: semi-axes must be positive");
+    }
+    if (N == 1) bs.r = bs.ax[0];                 // an interval: the 1-D ball
+    else bs.kind = BODY_ELLIPSOID;
   } else {
     throw Error("pg_capacity_create_levelset: unknown body kind (arbitrary bodies: use pg_capacity_create_from_arrays)");
   }

@@ -34,7 +34,7 @@ struct GLTable {
   double w[NGL];
 };
 
-constexpr int BODY_BALLS = 0, BODY_HALFSPACE = 1;
+constexpr int BODY_BALLS = 0, BODY_HALFSPACE = 1, BODY_ELLIPSOID = 2;
 
 struct BallSet {
   int N;          // spatial dimension 1..3
@@ -47,6 +47,11 @@ struct BallSet {
   int kind;
   int axis;
   double pos, sgn;
+  // axis-aligned ellipsoid (kind == BODY_ELLIPSOID): f(x) = sqrt(sum ((x_d - c_d) / ax_d)^2) - 1, centre c[0].  Everything is
+  // computed on the unit ball in the scaled coordinates x' = (x - c) / ax: volumes, sections and their moments scale with
+  // products of the semi-axes; the interface measure does not (it is not affine invariant) and carries the weight
+  // |F^-T n| det F = sqrt(sum_d (n_d prod_(k != d) ax_k)^2) of the unit normal n along the arcs (ellipse_weight)
+  double ax[3];
 };
 
 struct BoxMeasure {
@@ -94,7 +99,11 @@ struct Sec2 {
 };
 
 // disc(rho) ∩ [a,b] x [t0,t1], coordinates relative to the disc centre.
-PG_HD Sec2 disc_rect_all(double rho, double a, double b, double t0, double t1, bool want_arcs) {
+// ew != nullptr (ellipsoids): the arc integrals carry the weight w = sqrt((ew[0] u)^2 + (ew[1] t)^2 + ew[2]) of the point
+// (u, t) = rho (sin α, ±cos α) of the circle, integrated with the Gauss-Legendre rule `gl` in α over every arc piece
+// (ew[0], ew[1] = the products of the OTHER semi-axes, ew[2] = (ew_z z)^2 of the section's height on the unit sphere)
+PG_HD Sec2 disc_rect_all(double rho, double a, double b, double t0, double t1, bool want_arcs, const double* ew = nullptr,
+                         const GLTable* gl = nullptr) {
   Sec2 o;
   o.area = o.mx = o.my = o.phi = o.ic = o.is = 0.0;
   if (!(rho > 0.0)) return o;
@@ -157,7 +166,20 @@ PG_HD Sec2 disc_rect_all(double rho, double a, double b, double t0, double t1, b
     const double Qu = up_arc ? dR : t1 * t1 * du;   // int upper^2 du
     const double Ql = lo_arc ? dR : t0 * t0 * du;
     o.my += 0.5 * (Qu - Ql);
-    if (want_arcs) {
+    if (want_arcs && ew && (up_arc || lo_arc)) {
+      const double al0 = asin_r(x0, s0), al1 = asin_r(x1, s1);
+      const double am = 0.5 * (al0 + al1), ah = 0.5 * (al1 - al0);
+      double p = 0.0, pc = 0.0, ps = 0.0;
+      for (int q = 0; q < NGL; ++q) {
+        const double al = am + ah * gl->x[q];
+        const double sa = sin(al), ca = cos(al);
+        const double u = rho * sa, t = rho * ca;
+        const double wq = gl->w[q] * ah * sqrt(ew[0] * ew[0] * (u * u) + ew[1] * ew[1] * (t * t) + ew[2]);
+        p += wq; pc += wq * sa; ps += wq * ca;
+      }
+      if (up_arc) { o.phi += p; o.ic += pc; o.is += ps; }
+      if (lo_arc) { o.phi += p; o.ic += pc; o.is -= ps; }
+    } else if (want_arcs) {
       if (up_arc) { o.phi += dAs; o.ic += (s0 - s1) * inv_rho; o.is += du * inv_rho; }
       if (lo_arc) { o.phi += dAs; o.ic += (s0 - s1) * inv_rho; o.is -= du * inv_rho; }
     }
@@ -182,8 +204,11 @@ struct Mom {
 // (the piece structure is a function of the box alone, so cooperating lanes walk it identically); the returned moments
 // are then PARTIAL sums that the caller adds up over its group.  The closed-form 1-D / 2-D cases have no quadrature:
 // lane 0 returns the whole result, the others zero.  (0, 1) = everything, the host / oracle-checked form.
+// ek != nullptr: unit ball in an ellipsoid's scaled coordinates (r == 1), ek[d] = prod_(k != d) ax_k: the interface
+// measure and its moments are those of the ELLIPSOID's surface (in scaled coordinates about the centre)
 PG_HD Mom ball_box_moments(const double* c, double r, const double* lo, const double* hi, int N,
-                           bool want_surface, const GLTable& gl, int qlane = 0, int qstride = 1) {
+                           bool want_surface, const GLTable& gl, int qlane = 0, int qstride = 1,
+                           const double* ek = nullptr) {
   Mom o;
   o.vol = o.gamma = 0.0;
   for (int d = 0; d < 3; ++d) o.m[d] = o.gm[d] = 0.0;
@@ -197,7 +222,9 @@ PG_HD Mom ball_box_moments(const double* c, double r, const double* lo, const do
     return o;
   }
   if (N == 2) {
-    Sec2 s = disc_rect_all(r, a[0], b[0], a[1], b[1], want_surface);
+    double ew[3] = {0.0, 0.0, 0.0};
+    if (ek) { ew[0] = ek[0]; ew[1] = ek[1]; }
+    Sec2 s = disc_rect_all(r, a[0], b[0], a[1], b[1], want_surface, ek ? ew : nullptr, &gl);
     o.vol = s.area; o.m[0] = s.mx; o.m[1] = s.my;
     o.gamma = r * s.phi; o.gm[0] = r * r * s.ic; o.gm[1] = r * r * s.is;
     return o;
@@ -275,7 +302,9 @@ PG_HD Mom ball_box_moments(const double* c, double r, const double* lo, const do
         const double jw = gl.w[q] * zh * 1.5 * (1.0 - t * t);
         const double z = zm + zh * g;
         const double rho = sroot(r, z);
-        const Sec2 s = disc_rect_all(rho, a[0], b[0], a[1], b[1], want_surface);
+        double ew[3] = {0.0, 0.0, 0.0};
+        if (ek) { ew[0] = ek[0]; ew[1] = ek[1]; ew[2] = (ek[2] * z) * (ek[2] * z); }
+        const Sec2 s = disc_rect_all(rho, a[0], b[0], a[1], b[1], want_surface, ek ? ew : nullptr, &gl);
         acc[0] += jw * s.area;
         acc[1] += jw * s.mx;
         acc[2] += jw * s.my;
@@ -331,6 +360,13 @@ PG_HD int pick_ball(const BallSet& bs, const double* lo, const double* hi, int& 
   if (bs.kind == BODY_HALFSPACE) {
     double flo, fhi;
     type = hs_interval(bs, lo[bs.axis], hi[bs.axis], flo, fhi, false);
+    return 0;
+  }
+  if (bs.kind == BODY_ELLIPSOID) {
+    double slo[3], shi[3];
+    const double zero[3] = {0.0, 0.0, 0.0};
+    for (int d = 0; d < bs.N; ++d) { slo[d] = (lo[d] - bs.c[0][d]) / bs.ax[d]; shi[d] = (hi[d] - bs.c[0][d]) / bs.ax[d]; }
+    type = ball_box_type(zero, 1.0, slo, shi, bs.N);
     return 0;
   }
   int t = PG_EMPTY;
@@ -391,7 +427,24 @@ PG_HD BoxMeasure box_measure(const BallSet& bs, const double* lo, const double* 
   }
   const double* c = bs.c[s];
   const double full = prod_ext(lo, hi, N, -1);
-  Mom m = ball_box_moments(c, bs.r, lo, hi, N, want_surface, gl, qlane, qstride);
+  Mom m;
+  if (bs.kind == BODY_ELLIPSOID) {
+    double slo[3], shi[3], ek[3] = {1.0, 1.0, 1.0};
+    const double zero[3] = {0.0, 0.0, 0.0};
+    double J = 1.0;
+    for (int d = 0; d < N; ++d) {
+      slo[d] = (lo[d] - c[d]) / bs.ax[d];
+      shi[d] = (hi[d] - c[d]) / bs.ax[d];
+      J = J * bs.ax[d];
+      for (int k = 0; k < N; ++k)
+        if (k != d) ek[d] = ek[d] * bs.ax[k];
+    }
+    m = ball_box_moments(zero, 1.0, slo, shi, N, want_surface, gl, qlane, qstride, ek);
+    m.vol = m.vol * J;                                        // back to physical measures about the centre
+    for (int d = 0; d < N; ++d) { m.m[d] = m.m[d] * (J * bs.ax[d]); m.gm[d] = m.gm[d] * bs.ax[d]; }
+  } else {
+    m = ball_box_moments(c, bs.r, lo, hi, N, want_surface, gl, qlane, qstride);
+  }
   group(m);
   if (bs.complement) {
     m.vol = full - m.vol;
@@ -440,6 +493,28 @@ PG_HD double section_measure(const BallSet& bs, int d, double s, const double* l
     return m;
   }
   const double* c = bs.c[sb];
+  if (bs.kind == BODY_ELLIPSOID) {     // (N >= 2: a 1-D ellipsoid is parsed as a ball)
+    const double full = full_measure >= 0.0 ? full_measure : prod_ext(lo, hi, N, d);
+    if (t != PG_CUT) {
+      if (bs.complement) t = 1 - t;
+      return t == PG_FULL ? full : 0.0;
+    }
+    const double dz = (s - c[d]) / bs.ax[d];
+    const double rho = sroot(1.0, dz);
+    double a[2], b[2], scale = 1.0;
+    int q = 0;
+    for (int k = 0; k < N; ++k)
+      if (k != d) { a[q] = (lo[k] - c[k]) / bs.ax[k]; b[q] = (hi[k] - c[k]) / bs.ax[k]; scale = scale * bs.ax[k]; ++q; }
+    double m;
+    if (N == 2) {
+      double m1;
+      seg_overlap(rho, a[0], b[0], m, m1);
+    } else {
+      m = disc_rect_all(rho, a[0], b[0], a[1], b[1], false).area;
+    }
+    m = m * scale;
+    return bs.complement ? (full - m) : m;
+  }
   if (N == 1) {
     double f = fabs(s - c[0]) - bs.r;
     if (bs.complement) f = -f;

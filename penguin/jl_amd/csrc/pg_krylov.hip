@@ -264,7 +264,8 @@ struct SpmvTimer {
   std::vector<int> iter_of;   // Krylov iteration each launch belongs to
   std::vector<char> lean_of;  // 1: lean launch (no dots), 0: launch with fused dots
   std::vector<char> second_of;   // 1: launch of the second half of its iteration (skipped when the half step was accepted)
-  int cur = 0;
+  std::vector<int> count_of;     // launches between the two events (a chain of lean launches is bracketed as a whole)
+  int cur = 0, cur_count = 1;
   bool cur_lean = false, cur_second = false;
   bool armed = false;
   explicit SpmvTimer(bool on_) : on(on_) {}
@@ -285,14 +286,16 @@ struct SpmvTimer {
     PG_HIP(hipEventCreate(&e));
     return e;
   }
-  void begin(hipStream_t st, int iteration, bool lean = false, bool second = false) {
+  void begin(hipStream_t st, int iteration, bool lean = false, bool second = false, int count = 1) {
     cur = iteration;
     cur_lean = lean;
     cur_second = second;
-    // every `sample`-th launch is bracketed (PG_PROFILE_SAMPLE, default 7 -- coprime with the 2m launches of an
-    // iteration for every degree in use, so lean and closing launches of both halves are all sampled in turn): two event
-    // records per launch cost the stream a few microseconds each, a measurable share of what is being measured
-    static const int sample = getenv("PG_PROFILE_SAMPLE") ? std::max(1, atoi(getenv("PG_PROFILE_SAMPLE"))) : 7;
+    cur_count = count;
+    // every `sample`-th bracket is timed (PG_PROFILE_SAMPLE, default 3 -- coprime with the 4 brackets of an iteration: the
+    // chain of lean launches and the closing launch of each half, so all four are sampled in turn).  A pair of event
+    // records costs the stream ~10 µs (the kernel behind a record starts late): a lean chain is bracketed as a WHOLE so
+    // that this cost is spread over its m - 1 launches; rocprofv3's per-kernel durations (profiles/) are the cross-check
+    static const int sample = getenv("PG_PROFILE_SAMPLE") ? std::max(1, atoi(getenv("PG_PROFILE_SAMPLE"))) : 3;
     static thread_local unsigned long long counter = 0;
     armed = on && (counter++ % sample == 0);
     if (!armed) return;
@@ -307,6 +310,7 @@ struct SpmvTimer {
     iter_of.push_back(cur);
     lean_of.push_back(cur_lean ? 1 : 0);
     second_of.push_back(cur_second ? 1 : 0);
+    count_of.push_back(cur_count);
   }
   // launches queued after convergence return at their first instruction (done flag): they are not SpMVs and are
   // left out of the launch count and of the average
@@ -317,7 +321,7 @@ struct SpmvTimer {
       (void)hipEventSynchronize(pr.second);
       const bool ran = iter_of[q] < iters_done && !(half_exit && iter_of[q] == iters_done - 1 && second_of[q]);
       if (ran && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
-        if (lean_of[q]) { s.spmv_lean_ms += ms; s.spmv_lean_launches += 1; }
+        if (lean_of[q]) { s.spmv_lean_ms += ms; s.spmv_lean_launches += count_of[q]; }
         else { s.spmv_ms += ms; s.spmv_launches += 1; }
       }
       pool().push_back(pr.first);
@@ -327,6 +331,7 @@ struct SpmvTimer {
     iter_of.clear();
     lean_of.clear();
     second_of.clear();
+    count_of.clear();
   }
 };
 
@@ -449,15 +454,15 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
         auto apply = [&](double* in, double* out, int phase, int nslots) {
           const bool second = phase == PH_BICG_2;
           double* src = in;
+          if (m > 1) timer.begin(st, launched + it, true, second, m - 1);
           for (int k = 0; k + 1 < m; ++k) {
             double* dst = (k & 1) ? w.wb.p : w.wa.p;
             FinArgs f{nullptr, nullptr, PH_NONE, 0, 0, nullptr};
             f.pc0 = 1.0; f.pc1 = -tau[k];
-            timer.begin(st, launched + it, true, second);
             spmv_with_halo(4, A, nb, slab, src, dst, nullptr, nullptr, w.sc.p, G, st, &f);   // w <- w - τ_k Â w
-            timer.end(st);
             src = dst;
           }
+          if (m > 1) timer.end(st);
           // the scalar phase that follows is evaluated by the last block of the launch (stencil-slice kernel); with
           // several ranks the halo exchange of the input overlaps the rows that need no ghost value (spmv_with_halo)
           FinArgs f{w.ticket.p, w.sc.p, phase, nslots, derive_here, nullptr};
@@ -533,8 +538,8 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
     }
   }
   if (getenv("PG_DEBUG"))
-    fprintf(stderr, "[pg_krylov] done=%g iters=%g rr=%g tol2=%g rho=%g rho_old=%g alpha=%g omega=%g beta=%g red0=%g red1=%g\n",
-            w.h_sc[S_DONE], w.h_sc[S_ITERS], w.h_sc[S_RR], w.h_sc[S_TOL2], w.h_sc[S_RHO], w.h_sc[S_RHO_OLD], w.h_sc[S_ALPHA],
+    fprintf(stderr, "[pg_krylov] done=%g iters=%g rr0=%g rr=%g tol2=%g rho=%g rho_old=%g alpha=%g omega=%g beta=%g red0=%g red1=%g\n",
+            w.h_sc[S_DONE], w.h_sc[S_ITERS], w.h_sc[S_RR0], w.h_sc[S_RR], w.h_sc[S_TOL2], w.h_sc[S_RHO], w.h_sc[S_RHO_OLD], w.h_sc[S_ALPHA],
             w.h_sc[S_OMEGA], w.h_sc[S_BETA], w.h_sc[S_RED0], w.h_sc[S_RED1]);
   stats.iters = (int)w.h_sc[S_ITERS];
   w.last_iters = stats.iters;

@@ -6,7 +6,7 @@ namespace pg {
 
 // device scalar block of one Krylov solve (KrylovWork::sc)
 enum { S_RHO = 0, S_RHO_OLD, S_ALPHA, S_OMEGA, S_BETA, S_RR, S_BB, S_TOL2, S_DONE, S_ITERS, S_RELTOL2, S_ABSTOL2,
-       S_RESTART, S_RHAT2, S_FORCE, S_PENDING3, S_RRW, S_HALF,
+       S_RESTART, S_RHAT2, S_FORCE, S_PENDING3, S_RRW, S_HALF, S_RR0 /* initial (r,r)_W: diagnostics */,
        S_RED0, S_RED1, S_RED2, S_RED3, S_RED4, S_COUNT };
 
 constexpr int BLOCK = 256;
@@ -69,6 +69,7 @@ __device__ inline void derive(int phase, double* sc) {
       const double t2 = sc[S_RELTOL2] * bbw;
       sc[S_TOL2] = t2 > sc[S_ABSTOL2] ? t2 : sc[S_ABSTOL2];
       sc[S_DONE] = (rrw <= sc[S_TOL2]) ? 1.0 : 0.0;
+      sc[S_RR0] = rrw;
       break;
     }
     case PH_CG_INIT: {

@@ -231,6 +231,9 @@ static void test_geometry(std::mt19937_64& rng) {
     const bool hs = rep % 4 == 3;
     if (hs) {
       bs.kind = BODY_HALFSPACE; bs.axis = (int)(rng() % bs.N); bs.pos = U(rng); bs.sgn = rng() % 2 ? 1.0 : -1.0; bs.nballs = 1; bs.r = 1.0;
+    } else if (rep % 4 == 2 && bs.N > 1) {
+      bs.kind = BODY_ELLIPSOID; bs.nballs = 1; bs.r = 1.0;
+      for (int d = 0; d < 3; ++d) { bs.c[0][d] = U(rng); bs.ax[d] = 0.05 + 0.6 * U(rng); }
     } else {
       bs.kind = BODY_BALLS; bs.nballs = 1 + (int)(rng() % 3); bs.r = 0.05 + 0.3 * U(rng);
       if (bs.nballs > 1) bs.complement = 0;
@@ -243,7 +246,7 @@ static void test_geometry(std::mt19937_64& rng) {
       const double a = U(rng) * (hs ? 1.0 : 1.2), h = mode == 0 ? 0.0 : (mode == 1 ? 1e-12 : 0.02 + 0.2 * U(rng));
       lo[d] = a; hi[d] = a + h;
     }
-    if (mode == 2 && !hs) for (int d = 0; d < bs.N; ++d) { lo[d] = bs.c[0][d]; hi[d] = bs.c[0][d] + bs.r; }   // corner on the surface
+    if (mode == 2 && !hs) for (int d = 0; d < bs.N; ++d) { lo[d] = bs.c[0][d]; hi[d] = bs.c[0][d] + bs.r * (bs.kind == BODY_ELLIPSOID ? bs.ax[d] : 1.0); }   // corner on the surface
     if (mode == 3 && hs) { hi[bs.axis] = bs.pos + (hi[bs.axis] - lo[bs.axis]); lo[bs.axis] = bs.pos; }      // face in the plane
     const BoxMeasure m = box_measure(bs, lo, hi, true, gl);
     double full = 1.0;

@@ -141,3 +141,79 @@ def test_boxes_tangent_to_the_ball_at_an_interior_point_of_a_face(lib, N):
             for comp in (0, 1):
                 ref = Ball(c, r, complement=bool(comp)).section(d, s, lo, hi)
                 assert abs(csec(lib, N, c, r, d, s, np.array(lo), np.array(hi), comp) - ref) <= 1e-12
+
+
+# ------------------------------------------------------------------------------------------------ ellipsoids
+def _ebox(lib, N, c, ax, lo, hi, comp=0, surf=1):
+    out = np.zeros(9)
+    arrs = [np.ascontiguousarray(v, dtype=float) for v in (c, ax, lo, hi)]
+    lib.geom_ellipsoid_box(N, comp, *[a.ctypes.data_as(P) for a in arrs], surf, out.ctypes.data_as(P))
+    return out
+
+
+def _esec(lib, N, c, ax, d, s, lo, hi, comp=0):
+    lib.geom_ellipsoid_section.restype = C.c_double
+    arrs = [np.ascontiguousarray(v, dtype=float) for v in (c, ax, lo, hi)]
+    return lib.geom_ellipsoid_section(N, comp, arrs[0].ctypes.data_as(P), arrs[1].ctypes.data_as(P), d, C.c_double(s),
+                                      arrs[2].ctypes.data_as(P), arrs[3].ctypes.data_as(P))
+
+
+def test_ellipse_perimeter_and_area_are_the_closed_forms(lib):
+    """whole ellipse in one box cut into four quadrant boxes: area π a b, perimeter 4 a E(e) (scipy.special.ellipe)."""
+    from scipy.special import ellipe
+    from oracle.geometry import Ellipsoid
+    c, ax = (0.3, -0.2), (1.7, 0.6)
+    area = per = 0.0
+    for lo, hi in (((-3, -2), (0.3, -0.2)), ((0.3, -2), (3, -0.2)), ((-3, -0.2), (0.3, 2)), ((0.3, -0.2), (3, 2))):
+        o = _ebox(lib, 2, c, ax, lo, hi)
+        area += o[1]
+        per += o[5]
+        ob = Ellipsoid(c, ax).box(lo, hi)
+        assert abs(o[1] - ob.vol) < 1e-13 and abs(o[5] - ob.gamma) < 1e-12
+    assert abs(area - np.pi * 1.7 * 0.6) < 1e-13
+    assert abs(per - 4 * 1.7 * ellipe(1 - (0.6 / 1.7) ** 2)) < 1e-11     # 16 nodes over a whole quadrant of an e = 0.94 ellipse
+
+
+@pytest.mark.parametrize("N", [2, 3])
+def test_ellipsoid_boxes_and_sections_match_oracle(lib, N):
+    """random boxes around the surface: classification identical; volumes, centroids, sections to rounding; the interface
+    measure and its centroid to the accuracy of the two (different) quadratures."""
+    from oracle.geometry import Ellipsoid
+    rng = np.random.default_rng(5 + N)
+    c = (0.11, -0.23, 0.31)[:N]
+    ax = (1.3, 0.7, 0.45)[:N]
+    E, Ec = Ellipsoid(c, ax), Ellipsoid(c, ax, True)
+    ncut = 0
+    for _ in range(60 if N == 2 else 14):
+        u = rng.standard_normal(N)
+        u /= np.linalg.norm(u)
+        p = np.array(c) + np.array(ax) * u                     # a point of the surface
+        h = rng.uniform(0.05, 0.4, N)
+        lo = p - h * rng.uniform(0.1, 0.9, N)
+        hi = lo + h
+        for comp, body in ((0, E), (1, Ec)):
+            o, ob = _ebox(lib, N, c, ax, lo, hi, comp), body.box(list(lo), list(hi))
+            assert int(o[0]) == ob.type
+            if ob.type != -1:
+                continue
+            ncut += 1
+            cell = float(np.prod(h))
+            assert abs(o[1] - ob.vol) <= 1e-11 * cell
+            if ob.vol > 1e-3 * cell:
+                assert np.max(np.abs(o[2:2 + N] - np.array(ob.centroid))) <= 1e-9 * h.max()
+            assert abs(o[5] - ob.gamma) <= 1e-9 * max(ob.gamma, cell ** ((N - 1) / N))
+            if ob.gamma > 1e-3 * cell ** ((N - 1) / N):
+                assert np.max(np.abs(o[6:6 + N] - np.array(ob.cgamma))) <= 1e-8 * h.max()
+            for d in range(N):
+                for s in (lo[d], 0.5 * (lo[d] + hi[d]), hi[d]):
+                    assert abs(_esec(lib, N, c, ax, d, s, lo, hi, comp) - body.section(d, float(s), list(lo), list(hi))) <= 1e-12 * cell / h[d]
+    assert ncut > 20
+
+
+def test_ellipsoid_with_equal_axes_is_the_ball(lib):
+    for N in (2, 3):
+        c, r = (0.2, 0.1, -0.3)[:N], 0.9
+        lo, hi = [0.5, 0.3, 0.1][:N], [1.1, 0.9, 0.7][:N]
+        e, b = _ebox(lib, N, c, (r,) * N, lo, hi), cbox(lib, N, [c], r, lo, hi)
+        assert int(e[0]) == int(b[0])
+        assert np.allclose(e[1:], b[1:], rtol=1e-11, atol=1e-14)

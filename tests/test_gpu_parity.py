@@ -1096,3 +1096,60 @@ def test_polynomial_preconditioner_is_admitted_and_follows_the_host_restatement(
     ph2 = pj.Phase(cap, ph.operator, lambda x, y, z, t=0.0: 1.0, lambda x, y, z: 1.0)
     st = pj.DiffusionSteadyMono(ph2, pj.BorderConditions({}), pj.Dirichlet(0.0))
     assert st.system_info(2).neumann_ok == 0
+
+
+# ------------------------------------------------------------------------------------ ellipsoids
+@pytest.mark.parametrize("N,n,L,x0,c,ax", [
+    (1, 40, 2.0, -1.0, (0.13,), (0.61,)),
+    (2, 32, 4.0, 0.0, (2.03, 1.96), (1.4, 0.7)),
+    (2, 24, 2.0, -1.0, (0.05, -0.02), (0.35, 0.8)),
+    (3, 12, 2.0, -1.0, (0.03, -0.04, 0.02), (0.8, 0.5, 0.65)),
+])
+def test_ellipsoid_capacities_match_oracle(pj, N, n, L, x0, c, ax):
+    """PG_BODY_ELLIPSOID: classification bit for bit; volumes / faces / sections exact through the unit ball of
+    the scaled coordinates; the interface measure by Gauss-Legendre along the arcs (oracle: its own angular-interval
+    formulation with 24 nodes, adaptive in z)."""
+    from oracle.geometry import Ellipsoid
+    mesh, omesh = pj.Mesh((n,) * N, (L,) * N, (x0,) * N), po.Mesh((n,) * N, (L,) * N, (x0,) * N)
+    h = L / n
+    for comp in (False, True):
+        cap = pj.Capacity(pj.Ellipsoid(c, ax, complement=comp), mesh)
+        ocap = po.make_capacity(Ellipsoid(c, ax, comp), omesh)
+        _caps_close(cap, ocap, N, h)
+        cut = ocap.G > 1e-3 * max(h ** (N - 1), 1e-300)
+        if N > 1:
+            assert cut.sum() > 10
+            assert np.max(np.abs(cap.C_γ[cut] - ocap.C_g[cut])) <= 1e-8 * h
+    if N == 2:      # the whole interface is inside the domain: its measure is the ellipse's perimeter
+        from scipy.special import ellipe
+        a, b = max(ax), min(ax)
+        cap = pj.Capacity(pj.Ellipsoid(c, ax), mesh)
+        assert abs(cap.Γ.sum() - 4 * a * ellipe(1 - (b / a) ** 2)) <= 1e-11
+        assert abs(cap.V.sum() - np.pi * a * b) <= 1e-12
+
+
+@pytest.mark.parametrize("bc_kind", ["dirichlet", "robin"])
+def test_ellipse_heat_matches_oracle(pj, bc_kind):
+    """unsteady diffusion inside an ellipse (BE first solve, CN steps): the Robin rows use the ellipse's Γ."""
+    from oracle.geometry import Ellipsoid
+    n, L, c, ax = 28, 4.0, (2.03, 1.96), (1.5, 0.8)
+    mesh, omesh = pj.Mesh((n, n), (L, L), (0.0, 0.0)), po.Mesh((n, n), (L, L), (0.0, 0.0))
+    cap = pj.Capacity(pj.Ellipsoid(c, ax), mesh)
+    ocap = oracle_capacity_from_product(cap, omesh, Ellipsoid(c, ax))
+    g = lambda x, y, z, t=0.0: 1.0 + 0.3 * x - 0.2 * y + 0.5 * t
+    f = lambda x, y, z, t: 0.4 * x + t
+    bc, obc = (pj.Robin(1.0, 0.5, g), po.Robin(1.0, 0.5, g)) if bc_kind == "robin" else (pj.Dirichlet(g), po.Dirichlet(g))
+    M = (n + 1) ** 2
+    dt = 0.5 * (L / n) ** 2
+    T0 = np.random.default_rng(3).random(2 * M)
+    ph = pj.Phase(cap, pj.DiffusionOps(cap), f, 1.0)
+    oph = po.Phase(ocap, po.make_diffusion_ops(ocap), f, lambda x, y, z: 1.0)
+    bcb, obcb = pj.BorderConditions({}), po.BorderConditions({})
+    s = pj.DiffusionUnsteadyMono(ph, bcb, bc, dt, T0, "BE")
+    pj.solve_DiffusionUnsteadyMono_b(s, ph, dt, 4 * dt, bcb, bc, "CN", method="bicgstab", reltol=1e-14)
+    so = po.DiffusionUnsteadyMono(oph, obcb, obc, dt, T0, "BE")
+    po.solve_DiffusionUnsteadyMono(so, oph, dt, 4 * dt, obcb, obc, "CN")
+    assert len(s.states) == len(so.states) and s.unconverged == 0
+    for x, xo in zip(s.states, so.states):
+        assert np.array_equal(np.flatnonzero(x != 0.0), np.flatnonzero(xo != 0.0))
+        assert rel_l2(x, xo) <= TOL_T

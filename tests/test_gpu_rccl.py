@@ -29,9 +29,12 @@ def _run(cmd, env_extra, timeout=600):
 
 
 def _gpu_count() -> int:
-    import torch
-
-    return torch.cuda.device_count()      # (does not initialise the GPU on this image)
+    """In a child process: importing torch INTO a process that has already initialised libpenguin_hip.so brings a second
+    copy of the HIP runtime (torch bundles its own) whose exit handlers then collide with the first one's -- the test
+    process aborts at interpreter exit with `double free or corruption` after all tests have passed."""
+    r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True,
+                       timeout=300)
+    return int(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else 0
 
 
 def test_one_rank_rccl_communicator_matches_plain_init(tmp_path):
