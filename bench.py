@@ -182,7 +182,15 @@ def main() -> None:
     # THAT format (unit + slice records, P/G streams, x and y once) -- pricing it with the CSR figure would credit bytes
     # it never has to move (DESIGN.md "SpMV")
     sliced = os.environ.get("PG_SPMV_VARIANT", "70") in ("70", "66")
-    b_fmt = int(sysinfo.spmv_bytes) if sliced else b_csr
+    b_fmt_full = int(sysinfo.spmv_bytes) if sliced else b_csr
+    # the warm loop iterates on the same matrix without the Dirichlet interface unknowns (rows of the identity, solved before
+    # the iteration: pg_reduce.hip); the step's first product (right-hand side, start residual) uses the full matrix
+    loopinfo = s.system_info(7)
+    n_full = n_rows
+    reduced = sliced and int(loopinfo.spmv_bytes) != int(sysinfo.spmv_bytes)
+    if reduced:
+        n_rows = int(sysinfo.n_omega)
+    b_fmt = int(loopinfo.spmv_bytes) if sliced else b_csr
     m = int(run.poly_degree)                           # products per application of the preconditioned operator (0: plain)
     # launches timed in the loop: LEAN (a factor of the preconditioner polynomial: x in, y out, the matrix) and CLOSING
     # launches (fused dots: + r-hat and the chain's input vector, read as the subtrahend / dot operand: + 16 n)
@@ -259,11 +267,14 @@ def main() -> None:
                                  "bytes_per_launch": b_dots, "avg_launch_ms": dots_ms, "launches_timed": int(run.spmv_launches),
                                  "achieved": b_dots / (dots_ms * 1e-3) / 1e9 if dots_ms > 0 else 0.0,
                                  "frac": b_dots / (dots_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if dots_ms > 0 else 0.0},
-            "csr_bytes_per_launch": b_csr,
-            "csr_equivalent_GBs": b_csr / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0,
-            "rows_marched": int(sysinfo.rows_marched), "march_units": int(sysinfo.spmv_units),
-            "rows_uniform": int(sysinfo.rows_uniform), "rows_pattern": int(sysinfo.rows_pattern),
-            "rows_irregular": int(sysinfo.rows_irregular), "slices": int(sysinfo.spmv_slices),
+            "csr_bytes_per_launch": 12 * int(loopinfo.nnz) + 20 * n_rows if reduced else b_csr,
+            "csr_equivalent_GBs": (12 * int(loopinfo.nnz) + 20 * n_rows if reduced else b_csr) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0,
+            "rows_marched": int(loopinfo.rows_marched), "march_units": int(loopinfo.spmv_units),
+            "rows_uniform": int(loopinfo.rows_uniform), "rows_pattern": int(loopinfo.rows_pattern),
+            "rows_irregular": int(loopinfo.rows_irregular), "slices": int(loopinfo.spmv_slices),
+            "rows_in_the_iteration": n_rows, "nnz_in_the_iteration": int(loopinfo.nnz),
+            "dirichlet_interface_rows_solved_before_the_iteration": n_full - n_rows,
+            "full_matrix": {"rows": n_full, "nnz": nnz, "bytes_per_launch": b_fmt_full, "rows_irregular": int(sysinfo.rows_irregular)},
         },
     }
 
@@ -278,10 +289,10 @@ def main() -> None:
     # divided by the measured wall time of the step (launch gaps, host polls and the per-step kernels included).
     if m >= 2:
         per_apply = (m - 1) * b_fmt + (b_fmt + 16.0 * n_rows)
-        step_bytes = (2.0 * iters_eff) * per_apply + iters * (40.0 + 72.0) * n_rows + b_fmt + (74.0 + 8.0) * n_rows \
+        step_bytes = (2.0 * iters_eff) * per_apply + iters * (40.0 + 72.0) * n_rows + b_fmt_full + 74.0 * n_full + 8.0 * n_rows \
             + (m - 1) * (b_fmt + 16.0 * n_rows) + 24.0 * n_rows
     else:
-        step_bytes = (2.0 * iters + 1.0) * b_fmt + iters * (12.0 + 40.0 + 72.0) * n_rows + 74.0 * n_rows
+        step_bytes = 2.0 * iters * b_fmt + b_fmt_full + iters * (12.0 + 40.0 + 72.0) * n_rows + 74.0 * n_full
     step_gbs = step_bytes / (elapsed / args.steps) / 1e9
     out["step_roofline"] = {
         "what": "one CN time step of the loop on rank 0: every launch's operand vectors once and the matrix in the streamed "

@@ -277,7 +277,10 @@ int32_t pg_solver_num_states(const pg_solver* s, int64_t* out);
 int32_t pg_solver_get_state(const pg_solver* s, int64_t state_index, double* x, int64_t len);
 /* which: 0 = constructor system, 1 = run (loop) system: the reference's reduced A x = b;
           2 / 3 = the same two systems as the Krylov solver iterates on them, left-preconditioned and
-          equilibrated: (B^-1 S A S) y = B^-1 S b, x = S y (DESIGN.md "Preconditioner"); nnz differs. */
+          equilibrated: (B^-1 S A S) y = B^-1 S b, x = S y (DESIGN.md "Preconditioner"); nnz differs.
+          pg_solver_system_info only: 6 / 7 = what the warm time loop iterates on: the same matrix without the interface
+          unknowns of a Dirichlet problem (rows of the identity, solved before the iteration -- DESIGN.md "Dirichlet
+          interface rows") once a loop step has built it; identical to 2 / 3 otherwise. */
 int32_t pg_solver_system_info(const pg_solver* s, int32_t which, pg_system_info* out);
 /* reduced system of this rank as CSR (rowptr n_own+1, col nnz (local numbering: owned then ghosts), val nnz)
    plus b (n_own) and the map idx[n_own] -> index in the full 2M/4M vector (the reference's common_idx). */

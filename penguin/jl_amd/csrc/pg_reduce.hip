@@ -1,0 +1,228 @@
+// pg_reduce.hip -- the Krylov iteration without the interface unknowns of a Dirichlet problem.
+//
+// With a Dirichlet interface condition (Iᵦ = 0, src/solver.jl:203-223) the γ rows of the block system are  Γ Tγ = Γ g
+// (src/solver/diffusion.jl:229-232: block3 = 0, block4 = IₐΓ), and after the cell-block preconditioner they are rows of
+// the identity (to rounding: s_j a_jj s_j):  Â = [Â_ωω Â_ωγ; 0 D], D ≈ I.  Their solution is the right-hand side itself.  The reference solves them with
+// everything else; the time loop here fixes  x_γ = b̂_γ  before the iteration, moves the change through the coupling
+// block into the residual,  r_ω ← r_ω − Â_ωγ (b̂_γ − x_γ),  and iterates on  Â_ωω  alone.  Same solution (the γ rows are
+// solved exactly instead of to the tolerance); the SpMV loses the γ rows and -- what matters -- the γ COLUMNS of the
+// cut cells' and their neighbours' rows, which are most of the bytes of the packed irregular rows (G chunks): many of
+// those rows become plain stencil rows with their own values (P slices).
+//
+// Vectors: the reduced unknowns are the first n_ω entries of the full ones (kind 0 comes first in the numbering), so the
+// reduced system works on prefixes of the solver's vectors -- no gather, no copy.  That needs a system without ghost
+// columns in the ω rows: one rank, or slabs whose rows reference no ghost (A.halo_needed == false).
+#include "pg_krylov.h"
+#include "pg_scan.h"
+#include "pg_spmv.h"
+#include "pg_reduce.h"
+
+namespace pg {
+namespace {
+
+using pg::BLOCK;
+
+// are rows [n_w, n) diagonal rows  d_j x_j = b_j ?  (d_j = 1 up to the rounding of the equilibration s_j a_jj s_j)  count
+// the offenders, keep the diagonal
+__global__ void k_identity_rows(i64 n_w, i64 n, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                const double* __restrict__ val, double* __restrict__ gdiag, unsigned long long* bad) {
+  unsigned long long c = 0;
+  for (i64 r = n_w + blockIdx.x * (i64)blockDim.x + threadIdx.x; r < n; r += (i64)gridDim.x * blockDim.x) {
+    const int a = rowptr[r], b = rowptr[r + 1];
+    const bool ok = b - a == 1 && col[a] == (int)r && fabs(val[a] - 1.0) <= 1e-12;
+    gdiag[r - n_w] = ok ? val[a] : 1.0;
+    if (!ok) ++c;
+  }
+  if (c) atomicAdd(bad, c);
+}
+
+// per ω row: entries kept (col < n_w), entries of the coupling block (n_w <= col < n), ghost references (col >= n)
+__global__ void k_split_count(i64 n_w, i64 n, const int* __restrict__ rowptr, const int* __restrict__ col, int* cnt_w,
+                              int* has_g, int* cnt_g, unsigned long long* ghosts) {
+  unsigned long long gh = 0;
+  for (i64 r = blockIdx.x * (i64)blockDim.x + threadIdx.x; r < n_w; r += (i64)gridDim.x * blockDim.x) {
+    int cw = 0, cg = 0;
+    for (int e = rowptr[r]; e < rowptr[r + 1]; ++e) {
+      const int c = col[e];
+      if (c < n_w) ++cw;
+      else if (c < n) ++cg;
+      else ++gh;
+    }
+    cnt_w[r] = cw;
+    cnt_g[r] = cg;
+    has_g[r] = cg > 0 ? 1 : 0;
+  }
+  if (gh) atomicAdd(ghosts, gh);
+}
+
+__global__ void k_split_fill(i64 n_w, const int* __restrict__ rowptr, const int* __restrict__ col,
+                             const double* __restrict__ val, const int* __restrict__ rp_w, int* col_w, double* val_w,
+                             const int* __restrict__ has_g, const int* __restrict__ pos_g, const int* __restrict__ cnt_g,
+                             int* wg_rows, int* wg_cnt) {
+  for (i64 r = blockIdx.x * (i64)blockDim.x + threadIdx.x; r < n_w; r += (i64)gridDim.x * blockDim.x) {
+    int at = rp_w[r];
+    for (int e = rowptr[r]; e < rowptr[r + 1]; ++e)
+      if (col[e] < n_w) { col_w[at] = col[e]; val_w[at] = val[e]; ++at; }
+    if (has_g[r]) {
+      wg_rows[pos_g[r]] = (int)r;
+      wg_cnt[pos_g[r]] = cnt_g[r];
+    }
+  }
+}
+
+__global__ void k_coupling_fill(i64 n_wg, i64 n_w, i64 n, const int* __restrict__ wg_rows, const int* __restrict__ wg_ptr,
+                                const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val,
+                                int* wg_col, double* wg_val) {
+  for (i64 q = blockIdx.x * (i64)blockDim.x + threadIdx.x; q < n_wg; q += (i64)gridDim.x * blockDim.x) {
+    const int r = wg_rows[q];
+    int at = wg_ptr[q];
+    for (int e = rowptr[r]; e < rowptr[r + 1]; ++e)
+      if (col[e] >= n_w && col[e] < n) { wg_col[at] = col[e] - (int)n_w; wg_val[at] = val[e]; ++at; }
+  }
+}
+
+// γ rows  d_j x_j = b̂_j  with the residual r_j = b̂_j - d_j x_j at hand: δ = r_j / d_j, x_j += δ, r_j = 0; flag: some δ is
+// more than rounding noise
+__global__ void k_gamma_snap(i64 n_w, i64 n, double* __restrict__ x, double* __restrict__ r, double* __restrict__ rhat,
+                             double* __restrict__ p, const double* __restrict__ gdiag, double* __restrict__ delta, int* flag) {
+  int f = 0;
+  for (i64 j = n_w + blockIdx.x * (i64)blockDim.x + threadIdx.x; j < n; j += (i64)gridDim.x * blockDim.x) {
+    const double d = r[j] / gdiag[j - n_w], xo = x[j];
+    delta[j - n_w] = d;
+    x[j] = xo + d;
+    r[j] = 0.0; rhat[j] = 0.0; p[j] = 0.0;
+    if (fabs(d) > 1e-12 * fabs(xo)) f = 1;
+  }
+  if (f) atomicOr(flag, 1);
+}
+
+// coupled ω rows: r -= Â_ωγ δ
+__global__ void k_gamma_couple(i64 n_wg, const int* __restrict__ wg_rows, const int* __restrict__ wg_ptr,
+                               const int* __restrict__ wg_col, const double* __restrict__ wg_val,
+                               const double* __restrict__ delta, double* __restrict__ r, double* __restrict__ rhat,
+                               double* __restrict__ p) {
+  for (i64 q = blockIdx.x * (i64)blockDim.x + threadIdx.x; q < n_wg; q += (i64)gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int e = wg_ptr[q]; e < wg_ptr[q + 1]; ++e) s += wg_val[e] * delta[wg_col[e]];
+    if (s != 0.0) {
+      const int i = wg_rows[q];
+      const double v = r[i] - s;
+      r[i] = v; rhat[i] = v; p[i] = v;
+    }
+  }
+}
+
+// the start sums of k_rhs_init, slots 0 = (r,r) and 2 = (r,r)_W, again -- only if the residual really changed
+__global__ __launch_bounds__(BLOCK) void k_renorm(i64 n_w, const int* __restrict__ flag, const double* __restrict__ r,
+                                                  const double* __restrict__ ds, double* __restrict__ partials) {
+  __shared__ double s_red[BLOCK / 64];
+  if (*flag == 0) return;
+  double acc = 0.0, accw = 0.0;
+  for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n_w; i += (i64)gridDim.x * BLOCK) {
+    const double v = r[i], d = ds[i];
+    acc += v * v;
+    accw += (d * v) * (d * v);
+  }
+  const double t = block_sum(acc, s_red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+  const double tw = block_sum(accw, s_red);
+  if (threadIdx.x == 0) partials[2 * (size_t)gridDim.x + blockIdx.x] = tw;
+}
+
+}  // namespace
+
+void build_gamma_elim(const CsrMatrix& A, const Numbering& nb, GammaElim& E) {
+  E.tried = true;
+  E.active = false;
+  Context& cx = ctx();
+  hipStream_t st = cx.stream;
+  static const bool enabled = getenv("PG_GAMMA_ELIM") ? atoi(getenv("PG_GAMMA_ELIM")) != 0 : true;
+  if (!enabled || nb.K != 2 || A.n <= 0 || !A.rowptr.p) return;
+  const i64 n = A.n, n_w = nb.cnt_own[0];
+  if (n_w <= 0 || n_w >= n) return;
+  if ((cx.nranks > 1 || cx.comm) && A.halo_needed) return;      // ω rows may reference ghosts: prefixes would not do
+  DevBuf<unsigned long long> bad(2);
+  bad.zero();
+  E.gdiag.alloc(n - n_w);
+  hipLaunchKernelGGL(k_identity_rows, dim3(grid_for(n - n_w, 256)), dim3(256), 0, st, n_w, n, A.rowptr.p, A.col.p, A.val.p, E.gdiag.p,
+                     bad.p);
+  DevBuf<int> cnt_w(n_w + 1), has_g(n_w + 1), cnt_g(n_w), pos_g(n_w + 1), tot(2);
+  hipLaunchKernelGGL(k_split_count, dim3(grid_for(n_w, 256, 256 * 16)), dim3(256), 0, st, n_w, n, A.rowptr.p, A.col.p, cnt_w.p,
+                     has_g.p, cnt_g.p, bad.p + 1);
+  PG_HIP(hipGetLastError());
+  unsigned long long hb[2];
+  bad.download(hb, 2);
+  if (hb[0] != 0 || hb[1] != 0) {                                // not a Dirichlet block structure / ghost references
+    if (getenv("PG_DEBUG"))
+      fprintf(stderr, "[pg_reduce] no reduction: %llu of %lld interface rows are not rows of the identity, %llu ghost references\n",
+              hb[0], (long long)(n - n_w), hb[1]);
+    return;
+  }
+  CsrMatrix& R = E.A;
+  R.n = n_w;
+  R.scheme = A.scheme;
+  R.rowptr.alloc(n_w + 1);
+  scan_exclusive<int>(cnt_w.p, R.rowptr.p, n_w, R.rowptr.p + n_w, st);
+  scan_exclusive<int>(has_g.p, pos_g.p, n_w, tot.p, st);
+  int nnz = 0, n_wg = 0;
+  R.rowptr.download(&nnz, 1, n_w);
+  tot.download(&n_wg, 1);
+  R.nnz = nnz;
+  R.col.alloc(nnz + 8); R.val.alloc(nnz + 8);
+  R.col.zero(); R.val.zero();
+  E.n_wg = n_wg;
+  E.wg_rows.alloc(n_wg + 1);
+  DevBuf<int> wg_cnt(n_wg + 1);
+  hipLaunchKernelGGL(k_split_fill, dim3(grid_for(n_w, 256, 256 * 16)), dim3(256), 0, st, n_w, A.rowptr.p, A.col.p, A.val.p,
+                     R.rowptr.p, R.col.p, R.val.p, has_g.p, pos_g.p, cnt_g.p, E.wg_rows.p, wg_cnt.p);
+  PG_HIP(hipGetLastError());
+  E.wg_ptr.alloc(n_wg + 1);
+  int nnz_g = 0;
+  if (n_wg > 0) {
+    scan_exclusive<int>(wg_cnt.p, E.wg_ptr.p, n_wg, E.wg_ptr.p + n_wg, st);
+    E.wg_ptr.download(&nnz_g, 1, n_wg);
+  } else {
+    E.wg_ptr.zero();
+  }
+  E.wg_col.alloc(nnz_g + 1); E.wg_val.alloc(nnz_g + 1);
+  if (n_wg > 0)
+    hipLaunchKernelGGL(k_coupling_fill, dim3(grid_for(n_wg, 256)), dim3(256), 0, st, (i64)n_wg, n_w, n, E.wg_rows.p, E.wg_ptr.p,
+                       A.rowptr.p, A.col.p, A.val.p, E.wg_col.p, E.wg_val.p);
+  PG_HIP(hipGetLastError());
+  R.ds.alloc(n_w);
+  PG_HIP(hipMemcpyAsync(R.ds.p, A.ds.p, sizeof(double) * (size_t)n_w, hipMemcpyDeviceToDevice, st));
+  PG_HIP(hipStreamSynchronize(st));
+  R.halo_needed = false;
+  R.poly_ok = A.poly_ok;        // Gershgorin already left the identity rows' columns out (decide_poly)
+  R.gersh = A.gersh;
+  R.nnz_raw = nnz;
+  build_spmv_chunks(R);
+  E.nb = Numbering();
+  E.nb.K = 1;
+  E.nb.Mloc = nb.Mloc;
+  E.nb.n_own = n_w;
+  E.nb.n_ghost = 0;
+  E.nb.cnt_own[0] = n_w;
+  E.n_w = n_w;
+  E.n_g = n - n_w;
+  E.delta.alloc(E.n_g);
+  E.flag.alloc(1);
+  E.active = true;
+  if (getenv("PG_DEBUG"))
+    fprintf(stderr, "[pg_reduce] Dirichlet interface rows left out of the iteration: %lld of %lld rows, %lld of %lld entries; coupling block %d rows, %d entries; "
+            "irregular rows %lld -> %lld\n", (long long)(n - n_w), (long long)n, (long long)(A.nnz - nnz), (long long)A.nnz, n_wg, nnz_g,
+            (long long)A.rows_g, (long long)R.rows_g);
+}
+
+void gamma_fix(const GammaElim& E, double* x, double* r, double* rhat, double* p, double* partials, int grid, hipStream_t st) {
+  PG_HIP(hipMemsetAsync(E.flag.p, 0, sizeof(int), st));
+  hipLaunchKernelGGL(k_gamma_snap, dim3(grid_for(E.n_g, 256)), dim3(256), 0, st, E.n_w, E.n_w + E.n_g, x, r, rhat, p, E.gdiag.p,
+                     E.delta.p, E.flag.p);
+  if (E.n_wg > 0)
+    hipLaunchKernelGGL(k_gamma_couple, dim3(grid_for(E.n_wg, 256)), dim3(256), 0, st, E.n_wg, E.wg_rows.p, E.wg_ptr.p, E.wg_col.p,
+                       E.wg_val.p, E.delta.p, r, rhat, p);
+  hipLaunchKernelGGL(k_renorm, dim3(grid), dim3(BLOCK), 0, st, E.n_w, E.flag.p, r, E.A.ds.p, partials);
+  PG_HIP(hipGetLastError());
+}
+
+}  // namespace pg

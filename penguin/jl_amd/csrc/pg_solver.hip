@@ -14,6 +14,7 @@
 #include <memory>
 
 #include "pg_krylov.h"
+#include "pg_reduce.h"
 #include "pg_spmv.h"
 
 using namespace pg;
@@ -40,6 +41,7 @@ struct pg_solver {
   // numbering + matrices
   Numbering nb;
   CsrMatrix A_ctor, A_run;
+  GammaElim elim_ctor, elim_run;   // the same matrices without the Dirichlet interface unknowns (pg_reduce.hip), on first use
   bool have_run = false;
   int scheme_run = -1;
   // per-row data
@@ -664,8 +666,16 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
     hipLaunchKernelGGL(k_rhs_init, dim3(w.grid), dim3(BLOCK), 0, stream, n, s->nb.n_vec(), scheme, s->z.p, s->y.p, A.ds.p,
                        s->mass.p, s->bconst.p, s->fixed.p, A.isblk.p, s->b.p, w.r.p, w.rhat.p, w.p.p, w.partials.p);
     PG_HIP(hipGetLastError());
-    // y0 = z (in place), r0 = b̂ - ŷ: same solution as a zero start, fewer iterations
-    krylov_solve(A, s->nb, s->slab, s->b.p, s->z.p, w, o, st, nullptr, nullptr, true);
+    // Dirichlet interface: the γ rows are rows of the identity -- solved here, the iteration runs on Â_ωω (pg_reduce.hip)
+    GammaElim& E = (&A == &s->A_ctor) ? s->elim_ctor : s->elim_run;
+    if (!E.tried) build_gamma_elim(A, s->nb, E);
+    if (E.active) {
+      gamma_fix(E, s->z.p, w.r.p, w.rhat.p, w.p.p, w.partials.p, w.grid, stream);
+      krylov_solve(E.A, E.nb, s->slab, s->b.p, s->z.p, w, o, st, nullptr, nullptr, true);
+    } else {
+      // y0 = z (in place), r0 = b̂ - ŷ: same solution as a zero start, fewer iterations
+      krylov_solve(A, s->nb, s->slab, s->b.p, s->z.p, w, o, st, nullptr, nullptr, true);
+    }
     s->x_valid = false;
   } else {
     // cold start / CG: the reference's zero initial guess, on the unscaled state
@@ -1001,9 +1011,13 @@ int32_t pg_solver_get_state(const pg_solver* s, int64_t state_index, double* x, 
 int32_t pg_solver_system_info(const pg_solver* s, int32_t which, pg_system_info* out) {
   PG_API_BEGIN
   PG_REQUIRE(s && out, "pg_solver_system_info: NULL argument");
-  const CsrMatrix& A = ((which & 1) == 0 || !s->have_run) ? s->A_ctor : run_matrix(s);
+  const CsrMatrix& Af = ((which & 1) == 0 || !s->have_run) ? s->A_ctor : run_matrix(s);
+  // which & 4: the matrix the warm time loop iterates on -- Â without the Dirichlet interface unknowns when that reduction
+  // is active for this system (pg_reduce.hip), else Â itself; n_own / n_omega / n_gamma always describe the full system
+  const GammaElim& E = (&Af == &s->A_ctor) ? s->elim_ctor : s->elim_run;
+  const CsrMatrix& A = ((which & 4) && E.active) ? E.A : Af;
   out->n_own = s->nb.n_own;
-  out->nnz = (which & 2) ? A.nnz : A.nnz_raw;
+  out->nnz = (which & 6) ? A.nnz : A.nnz_raw;
   out->n_ghost = s->nb.n_ghost;
   i64 nw = 0, ng = 0;
   for (int k = 0; k < s->K; ++k) ((k & 1) ? ng : nw) += s->nb.cnt_own[k];

@@ -1153,3 +1153,46 @@ def test_ellipse_heat_matches_oracle(pj, bc_kind):
     for x, xo in zip(s.states, so.states):
         assert np.array_equal(np.flatnonzero(x != 0.0), np.flatnonzero(xo != 0.0))
         assert rel_l2(x, xo) <= TOL_T
+
+
+# ------------------------------------------------------------------------------------ Dirichlet interface rows
+@pytest.mark.parametrize("kind", ["dirichlet", "dirichlet_time", "robin"])
+def test_dirichlet_interface_rows_are_solved_before_the_iteration(pj, kind):
+    """pg_reduce.hip: with a Dirichlet interface condition the γ rows of Â are rows of the identity; the warm loop fixes
+    x_γ = b̂_γ, pushes the change through Â_ωγ into the residual and iterates on Â_ωω.  Same states as the oracle's direct
+    solve of the full system -- constant data (nothing changes: the fix is a no-op), data that change every step (the
+    coupling correction and the refreshed start sums are exercised), and Robin (no reduction: the rows are not identity)."""
+    n, L = 20, 4.0
+    N = 3
+    mesh, omesh = pj.Mesh((n,) * N, (L,) * N, (0.0,) * N), po.Mesh((n,) * N, (L,) * N, (0.0,) * N)
+    cap = pj.Capacity(pj.Sphere((2.03, 1.98, 2.01), 1.1), mesh)
+    ocap = oracle_capacity_from_product(cap, omesh, Ball((2.03, 1.98, 2.01), 1.1))
+    if kind == "dirichlet":
+        g = 1.0
+        bc, obc = pj.Dirichlet(g), po.Dirichlet(g)
+    elif kind == "dirichlet_time":
+        g = lambda x, y, z, t: 1.0 + 0.3 * x + 4.0 * t
+        bc, obc = pj.Dirichlet(g), po.Dirichlet(g)
+    else:
+        bc, obc = pj.Robin(1.0, 0.4, 0.7), po.Robin(1.0, 0.4, 0.7)
+    M = (n + 1) ** N
+    dt = 0.4 * (L / n) ** 2
+    T0 = np.random.default_rng(11).random(2 * M)
+    f = lambda x, y, z, t: 0.2 * x
+    ph = pj.Phase(cap, pj.DiffusionOps(cap), f, 1.0)
+    oph = po.Phase(ocap, po.make_diffusion_ops(ocap), f, lambda x, y, z: 1.0)
+    bcb, obcb = pj.BorderConditions({}), po.BorderConditions({})
+    s = pj.DiffusionUnsteadyMono(ph, bcb, bc, dt, T0, "BE")
+    pj.solve_DiffusionUnsteadyMono_b(s, ph, dt, 5 * dt, bcb, bc, "CN", method="bicgstab", reltol=1e-14)
+    so = po.DiffusionUnsteadyMono(oph, obcb, obc, dt, T0, "BE")
+    po.solve_DiffusionUnsteadyMono(so, oph, dt, 5 * dt, obcb, obc, "CN")
+    assert len(s.states) == len(so.states) and s.unconverged == 0
+    for x, xo in zip(s.states, so.states):
+        assert np.array_equal(np.flatnonzero(x != 0.0), np.flatnonzero(xo != 0.0))
+        assert rel_l2(x, xo) <= TOL_T
+    full, loop = s.system_info(3), s.system_info(7)
+    if kind == "robin":
+        assert loop.nnz == full.nnz and loop.spmv_bytes == full.spmv_bytes
+    else:
+        assert loop.nnz < full.nnz - full.n_gamma and loop.rows_irregular <= full.rows_irregular   # γ rows AND γ columns gone
+        assert loop.spmv_bytes < full.spmv_bytes
