@@ -204,13 +204,14 @@ def main() -> None:
     iters = run.total_iters / max(run.steps, 1)
     iters_eff = (run.total_iters - 0.5 * run.half_exits) / max(run.steps, 1)
 
-    traffic = None
+    traffic = trace_us = None
     tf = ROOT / "profiles" / "r02_spmv_traffic.json"
     if tf.exists():
         try:
-            traffic = json.loads(tf.read_text()).get("hbm_bytes_per_launch")
+            tj = json.loads(tf.read_text())
+            traffic, trace_us = tj.get("hbm_bytes_per_launch"), tj.get("lean_launch_kernel_trace_avg_us")
         except Exception:
-            traffic = None
+            traffic = trace_us = None
 
     halo = ghosts_g > 0
     out = {
@@ -263,6 +264,10 @@ def main() -> None:
             "bytes_per_launch": k_bytes,
             "avg_launch_ms": k_ms,
             "launches_timed": int(run.spmv_lean_launches if dominant_lean else run.spmv_launches),
+            # HIP events bracket whole chains of launches back to back, i.e. kernel + the gap to the next dependent kernel;
+            # rocprofv3's kernel trace of the same command (profiles/, copied into the traffic JSON) times the kernel alone
+            "timing": "HIP events around each chain of m - 1 lean launches on the compute stream, every 3rd bracket",
+            "kernel_trace_avg_launch_ms_from_profiles": trace_us / 1e3 if (trace_us and dominant_lean) else None,
             "closing_launches": {"what": "last product of a chain: + the chain's input vector and r-hat, fused dots, in-launch scalar phase",
                                  "bytes_per_launch": b_dots, "avg_launch_ms": dots_ms, "launches_timed": int(run.spmv_launches),
                                  "achieved": b_dots / (dots_ms * 1e-3) / 1e9 if dots_ms > 0 else 0.0,
@@ -285,12 +290,12 @@ def main() -> None:
     #       (m - 1) lean launches (b_fmt) + the closing launch (b_fmt + 16 n);  plain iteration: one launch, b_fmt + 8 n (+ 8 n)
     #   per iteration: k_bicg_s (r, v, r-hat, S -> s: 5 x 8 n) + k_bicg_xrp (y, p, s: read + written, t, v, S: 9 x 8 n)
     #   per step: the right-hand side's SpMV (b_fmt) + k_rhs_init (74 n) + y = 0 (8 n) + the recovery x = x0 + q(A) y:
-    #       (m - 1) launches that also update x (b_fmt + 16 n) + the last term (24 n)
+    #       (m - 1) Horner launches (b_fmt + 8 n: the y vector as a third stream) + x += tau_0 u (24 n)
     # divided by the measured wall time of the step (launch gaps, host polls and the per-step kernels included).
     if m >= 2:
         per_apply = (m - 1) * b_fmt + (b_fmt + 16.0 * n_rows)
         step_bytes = (2.0 * iters_eff) * per_apply + iters * (40.0 + 72.0) * n_rows + b_fmt_full + 74.0 * n_full + 8.0 * n_rows \
-            + (m - 1) * (b_fmt + 16.0 * n_rows) + 24.0 * n_rows
+            + (m - 1) * (b_fmt + 8.0 * n_rows) + 24.0 * n_rows
     else:
         step_bytes = 2.0 * iters * b_fmt + b_fmt_full + iters * (12.0 + 40.0 + 72.0) * n_rows + 74.0 * n_full
     step_gbs = step_bytes / (elapsed / args.steps) / 1e9

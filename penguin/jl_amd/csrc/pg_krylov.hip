@@ -513,17 +513,35 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
     if (!done && poly && launched >= poly_give_up) { poly_failed = true; done = true; }
   }
   if (poly) {
-    // x = x0 + q(Â) y,  q(Â) y = Σ_k τ_k w_(k-1),  w_0 = y, w_k = w_(k-1) - τ_k Â w_(k-1): the chain once more, every launch
-    // adding its term to x (mode 7), the last term by a vector kernel.  (No done flag here: it is set.)
+    // x = x0 + q(Â) y,  q(Â) y = Σ_k τ_k w_k,  w_0 = y, w_(k+1) = (I - τ_k Â) w_k  -- evaluated by Horner's rule from the inside,
+    //   u_(m-1) = τ_(m-1) y,   u_k = τ_k y + (I - τ_k Â) u_(k+1),   q(Â) y = u_0,
+    // in the scaled variable ũ_k = u_k / τ_k so that a launch needs no scaled copy of y:
+    //   ũ_(m-1) = y,   ũ_k = y + c_k (ũ_(k+1) - τ_k Â ũ_(k+1)),  c_k = τ_(k+1) / τ_k      (mode 8: x in, y-vector, out)
+    // m - 1 launches of three vector streams each (the accumulating form, mode 7, read and wrote x as a fourth in every
+    // launch); the factors are applied in the reverse of the chain's order, which alternates between the two ends of the
+    // spectrum either way.  (No done flag here: it is set.)
+    static const bool horner = getenv("PG_RECOVERY_HORNER") ? atoi(getenv("PG_RECOVERY_HORNER")) != 0 : true;
     double* src = w.ya.p;
-    for (int k = 0; k + 1 < m; ++k) {
-      double* dst = (k & 1) ? w.wb.p : w.wa.p;
-      FinArgs f{nullptr, nullptr, PH_NONE, 0, 0, nullptr};
-      f.pc0 = 1.0; f.pc1 = -tau[k]; f.accv = x; f.pc2 = tau[k];
-      spmv_with_halo(7, A, nb, slab, src, dst, nullptr, nullptr, nullptr, G, st, &f);
-      src = dst;
+    if (horner) {
+      for (int k = m - 2; k >= 0; --k) {
+        double* dst = (k & 1) ? w.wb.p : w.wa.p;
+        FinArgs f{nullptr, nullptr, PH_NONE, 0, 0, nullptr};
+        const double c = tau[k + 1] / tau[k];
+        f.pc0 = c; f.pc1 = -c * tau[k]; f.base = w.ya.p;
+        spmv_with_halo(8, A, nb, slab, src, dst, nullptr, nullptr, nullptr, G, st, &f);
+        src = dst;
+      }
+      hipLaunchKernelGGL(k_axpy, dim3(G), dim3(BLOCK), 0, st, n, tau[0], (const double*)src, x);
+    } else {
+      for (int k = 0; k + 1 < m; ++k) {
+        double* dst = (k & 1) ? w.wb.p : w.wa.p;
+        FinArgs f{nullptr, nullptr, PH_NONE, 0, 0, nullptr};
+        f.pc0 = 1.0; f.pc1 = -tau[k]; f.accv = x; f.pc2 = tau[k];
+        spmv_with_halo(7, A, nb, slab, src, dst, nullptr, nullptr, nullptr, G, st, &f);
+        src = dst;
+      }
+      hipLaunchKernelGGL(k_axpy, dim3(G), dim3(BLOCK), 0, st, n, tau[m - 1], (const double*)src, x);
     }
-    hipLaunchKernelGGL(k_axpy, dim3(G), dim3(BLOCK), 0, st, n, tau[m - 1], (const double*)src, x);
     PG_HIP(hipGetLastError());
     if (poly_failed) {
       if (getenv("PG_DEBUG")) fprintf(stderr, "[pg_krylov] polynomial preconditioner (m = %d) stagnated after %d iterations: plain iteration\n", m, launched);

@@ -290,13 +290,14 @@ __device__ inline double mode4_out(double xown, double ax, double pc0, double pc
 //   5  y = B - (pc0 own + pc1 s);     acc0 += A y                                   A = aux, B = base
 //   6  y = A - (pc0 own + pc1 s);     acc0 += A y, acc1 += y y, acc2 += B y         A = dotx, B = aux
 //   7  y = pc0 own + pc1 s;           A_row += pc2 own  (A = accv, read and written)
+//   8  y = B + (pc0 own + pc1 s)                                                     B = base  (Horner step of x = x0 + q(Â)y)
 // 5 / 6 close a chain of mode-4 launches: v = p - R(Â)p with (r̂,v), t = s - R(Â)s with (t,s), (t,t), (r̂,t); 7 is a step of
 // the same chain that also accumulates q(Â)y = Σ τ_k w_(k-1) (pg_krylov.hip).
 template <int MODE>
 struct ModeInfo {
   static constexpr bool OWN = MODE >= 4;
   static constexpr bool HAS_A = MODE == 1 || MODE == 2 || MODE == 3 || MODE == 5 || MODE == 6 || MODE == 7;
-  static constexpr bool HAS_B = MODE == 3 || MODE == 5 || MODE == 6;
+  static constexpr bool HAS_B = MODE == 3 || MODE == 5 || MODE == 6 || MODE == 8;
   static constexpr bool DOT0 = MODE == 1 || MODE == 2 || MODE == 3 || MODE == 5 || MODE == 6;
   static constexpr bool DOT1 = MODE == 2 || MODE == 3 || MODE == 6;
   static constexpr bool DOT2 = MODE == 3 || MODE == 6;
@@ -308,6 +309,7 @@ __device__ __forceinline__ double mode_out(double s, double own, double a, doubl
   if (MODE == 4 || MODE == 7) return mode4_out(own, s, pc0, pc1);
   if (MODE == 5) return b - mode4_out(own, s, pc0, pc1);
   if (MODE == 6) return a - mode4_out(own, s, pc0, pc1);
+  if (MODE == 8) return b + mode4_out(own, s, pc0, pc1);
   return s;
 }
 
@@ -604,7 +606,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_spmv_s(i64 nslices, const int* __r
   const double* __restrict__ dx = fin.dotx ? fin.dotx : x;   // operand of the (y, .) dot of modes 2 / 3 / 6
   // operand vectors A and B of the epilogue (ModeInfo)
   const double* __restrict__ pa = (MODE == 1 || MODE == 5) ? aux : ((MODE == 2 || MODE == 3 || MODE == 6) ? dx : (MODE == 7 ? fin.accv : nullptr));
-  const double* __restrict__ pb = (MODE == 3 || MODE == 6) ? aux : (MODE == 5 ? fin.base : nullptr);
+  const double* __restrict__ pb = (MODE == 3 || MODE == 6) ? aux : ((MODE == 5 || MODE == 8) ? fin.base : nullptr);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   double* __restrict__ sv = s_val[wave];
@@ -1319,6 +1321,7 @@ bool launch_spmv(int mode, const CsrMatrix& A, const double* x, double* y, const
   if (mode == 5) return launch_mode<5>(v, A, x, y, aux, partials, sc, grid, st, fin);
   if (mode == 6) return launch_mode<6>(v, A, x, y, aux, partials, sc, grid, st, fin);
   if (mode == 7) return launch_mode<7>(v, A, x, y, aux, partials, sc, grid, st, fin);
+  if (mode == 8) return launch_mode<8>(v, A, x, y, aux, partials, sc, grid, st, fin);
   PG_REQUIRE(mode == 3, "unknown SpMV launch mode");
   return launch_mode<3>(v, A, x, y, aux, partials, sc, grid, st, fin);
 }
@@ -1354,6 +1357,7 @@ bool spmv_with_halo(int mode, const CsrMatrix& A, const Numbering& nb, const Sla
   else if (mode == 5) { PG_SPLIT(5); }
   else if (mode == 6) { PG_SPLIT(6); }
   else if (mode == 7) { PG_SPLIT(7); }
+  else if (mode == 8) { PG_SPLIT(8); }
   else { PG_SPLIT(3); }
 #undef PG_SPLIT
   return folded;

@@ -45,4 +45,15 @@ lean = out.get("k_spmv_s<mode 4>", {})
 if "hbm_bytes_per_launch" in lean:
     res["hbm_bytes_per_launch"] = lean["hbm_bytes_per_launch"]
     res["hbm_bytes_per_launch_note"] = "lean launch (mode 4: w <- w - tau A w), the launch bench.py reports as the dominant kernel"
+# kernel-trace statistics of the bench run itself (no counters): the per-kernel durations bench.py's HIP-event figures are
+# cross-checked against (events bracket launches back to back: they include the gap between dependent kernels)
+if len(sys.argv) > 2:
+    stats = {}
+    for r in csv.DictReader(open(sys.argv[2])):
+        m = re.search(r"k_spmv_s<(\d)", r["Name"])
+        if m:
+            stats[f"k_spmv_s<mode {m.group(1)}>"] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3}
+    res["kernel_trace_stats_of_the_bench_run"] = stats
+    if "k_spmv_s<mode 4>" in stats:
+        res["lean_launch_kernel_trace_avg_us"] = stats["k_spmv_s<mode 4>"]["avg_us"]
 print(json.dumps(res, indent=1))
