@@ -13,6 +13,10 @@ struct KrylovWork {
   int grid = 1;
   DevBuf<unsigned> ticket;              // arrival counter of the in-launch scalar phases (pg_spmv.h)
   int last_iters = 0;                   // iterations of the previous solve (sizes the first launch batch)
+  // degree of the preconditioner polynomial chosen from the previous solve on the same matrix (auto mode, pg_krylov.hip):
+  // adapt_m products per application, adapt_h applications expected
+  const void* adapt_matrix = nullptr;
+  int adapt_m = 0, adapt_h = 0;
   // polynomial right preconditioner (pg_krylov.hip), n_vec each, on first use: the accumulated solution of the
   // preconditioned system (x = x0 + q(Â) ya) and the two work vectors the chain of products alternates between
   DevBuf<double> ya, wa, wb;

@@ -401,6 +401,11 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
   int m = 0;
   if (poly_env && opts.precond >= 0 && !cg && A.poly_ok && spmv_supports_preconditioner_product() && n > 0)
     m = std::min(opts.precond > 0 ? opts.precond : degree_env, 16);
+  // auto mode: the degree that fits the number of products the previous solve on this matrix would have needed (below)
+  static const bool adapt_env = getenv("PG_POLY_ADAPT") ? atoi(getenv("PG_POLY_ADAPT")) != 0 : !getenv("PG_POLY_DEGREE");
+  const bool adaptive = adapt_env && m >= 2 && opts.precond == 0 && preinit;
+  int expect_halves = 0;
+  if (adaptive && w.adapt_matrix == &A && w.adapt_m >= 2) { m = w.adapt_m; expect_halves = w.adapt_h; }
   if (m < 2) m = 0;
   const bool poly = m > 0;
   stats.poly_degree = m;
@@ -444,6 +449,7 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
   while (!done) {
     int want = check_every;
     if (w.last_iters > 1) want = polls == 0 ? w.last_iters - 1 : (polls <= 4 ? 1 : check_every);
+    if (expect_halves > 0) want = polls == 0 ? (expect_halves + 1) / 2 : (polls <= 4 ? 1 : check_every);   // the predicted count at once
     const int batch = std::max(1, std::min(want, maxiter - launched));
     ++polls;
     for (int it = 0; it < batch; ++it) {
@@ -566,6 +572,31 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
   stats.resnorm = std::sqrt(cg ? w.h_sc[S_RRW] : w.h_sc[S_RR]);   // the weighted norms of the convergence test
   stats.bnorm = std::sqrt(w.h_sc[S_BB]);
   timer.collect(stats, stats.iters, w.h_sc[S_HALF] != 0.0);
+  // Degree for the next solve on this matrix (the loop's warm solves: the start residual and the tolerance move slowly from
+  // step to step).  This solve applied P = (2 iters - half) m products and took (r,r)_W from rr0 to rr; at that rate the
+  // tolerance needed  P log(tol²/rr0) / log(rr/rr0)  of them.  An application of the operator costs its m - 1 lean launches
+  // + one closing launch with its vector kernel (≈ 3.2 lean launches): take the (applications h, degree m) with h m >= need
+  // that is cheapest -- 27 products are 3 x 9, not 5 x 6 (2.5 iterations of 12) or 2 x 16 of degree 8.  No safety margin: a
+  // miss costs one more application once, and the next estimate is made from that solve (335 -> 370 steps/s at 512^3).
+  w.adapt_matrix = nullptr;
+  if (adaptive && stats.converged && stats.iters > 0) {
+    const double rr0 = w.h_sc[S_RR0], rr = w.h_sc[S_HALF] != 0.0 ? w.h_sc[S_RED4] : w.h_sc[S_RR], tol2 = w.h_sc[S_TOL2];
+    const double P = (2.0 * stats.iters - stats.half_exit) * m;
+    if (rr0 > tol2 && rr > 0.0 && rr < rr0 && tol2 > 0.0) {
+      static const double margin = getenv("PG_POLY_MARGIN") ? atof(getenv("PG_POLY_MARGIN")) : 1.0;
+      static const double slack = getenv("PG_POLY_SLACK") ? atof(getenv("PG_POLY_SLACK")) : 0.0;
+      const double need = std::min(P, P * std::log(tol2 / rr0) / std::log(rr / rr0)) * margin + slack;
+      double best = 1e300;
+      for (int h = 1; h <= 16; ++h) {
+        const int mm = (int)std::ceil(need / h);
+        if (mm < 4 || mm > 10) continue;
+        const double cost = h * ((mm - 1) + 3.2);
+        if (cost < best) { best = cost; w.adapt_m = mm; w.adapt_h = h; }
+      }
+      if (best < 1e300) w.adapt_matrix = &A;
+      if (getenv("PG_DEBUG")) fprintf(stderr, "[pg_krylov] degree %d used %g products, needed %.1f -> next: %d applications of degree %d\n", m, P, need, w.adapt_h, w.adapt_m);
+    }
+  }
 }
 
 }  // namespace pg
