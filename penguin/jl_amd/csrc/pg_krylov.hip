@@ -590,7 +590,7 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
       for (int h = 1; h <= 16; ++h) {
         const int mm = (int)std::ceil(need / h);
         if (mm < 4 || mm > 10) continue;
-        const double cost = h * ((mm - 1) + 3.2);
+        const double cost = h * ((mm - 1) + 3.2) + 1.25 * (mm - 1);   // + the recovery's mm - 1 Horner launches
         if (cost < best) { best = cost; w.adapt_m = mm; w.adapt_h = h; }
       }
       if (best < 1e300) w.adapt_matrix = &A;
