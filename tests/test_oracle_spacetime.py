@@ -173,3 +173,39 @@ def test_moving_interface_similarity_solution(scheme):
     e20, e40 = run_similarity_oracle(20, scheme), run_similarity_oracle(40, scheme)
     assert e20 < 8e-3 and e40 < 2.5e-3
     assert e40 < 0.4 * e20
+
+
+def test_reference_3d_plus_time_selection_keeps_x_and_y_only():
+    """Why the HIP path refuses 3-D+t (pg_capacity_create_spacetime: N = 1, 2): on a 3-D space mesh the `[1:end÷2]` halves of
+    diffusion.jl:145-151 are the first half of 4 blocks of 2M rows = the x and y blocks (both time layers), never z.  Shown on
+    the literal (N+1)-D restatement with arbitrary positive capacities: the moving blocks equal the operators built from the
+    x and y capacities of the first layer alone, and differ from the full 3-D ones."""
+    rng = np.random.default_rng(4)
+    mesh = po.Mesh((3, 3, 3), (1.0, 1.0, 1.0), (0.0, 0.0, 0.0))
+    st = ost.SpaceTimeMesh(mesh, [0.0, 0.1])
+    M = int(np.prod(mesh.ext))
+    M2 = 2 * M
+    pos = lambda: rng.uniform(0.5, 1.5, M2)
+    cap = po.Capacity(tuple(pos() for _ in range(4)), tuple(pos() for _ in range(4)), pos(), tuple(pos() for _ in range(4)),
+                      rng.random((M2, 4)), rng.random((M2, 4)), pos(), -np.ones(M2), st, None)
+    op = po.make_diffusion_ops(cap)
+    assert op.G.shape == (4 * M2, M2)
+    A = ost.A_mono_unstead_diff_moving(op, cap, 1.0, po.Robin(0.7, 1.3, 0.0), "BE")
+    assert A.shape == (2 * M, 2 * M)
+
+    def blocks(dims):
+        lay = po.Capacity(tuple(cap.A[d][:M] for d in dims), tuple(cap.B[d][:M] for d in dims), cap.V[:M],
+                          tuple(cap.W[d][:M] for d in dims), cap.C_w[:M, :3], cap.C_g[:M, :3], cap.G[:M], cap.cell_types[:M], mesh, None)
+        # Kronecker operators of the chosen space directions on the 3-D mesh
+        D_m = [po.build_differential_operator(po.delta_m, mesh, d) for d in dims]
+        G = sp.vstack([D_m[i] @ sp.diags(lay.B[i]) for i in range(len(dims))], format="csr")
+        H = sp.vstack([sp.diags(lay.A[i]) @ D_m[i] - D_m[i] @ sp.diags(lay.B[i]) for i in range(len(dims))], format="csr")
+        w = np.concatenate([lay.W[i] for i in range(len(dims))])
+        Wi = sp.diags(1.0 / w)
+        Vn_1, Vn = cap.A[3][:M], cap.A[3][M:]
+        return sp.bmat([[sp.diags(Vn_1) + G.T @ Wi @ G, -(sp.diags(Vn_1) - sp.diags(Vn)) + G.T @ Wi @ H],
+                        [1.3 * (H.T @ Wi @ G), 1.3 * (H.T @ Wi @ H) + 0.7 * sp.diags(lay.G)]], format="csr")
+
+    xy, xyz = blocks((0, 1)), blocks((0, 1, 2))
+    assert abs(A - xy).max() <= 1e-13 * abs(xy).max()
+    assert abs(A - xyz).max() > 1e-2 * abs(xyz).max()
