@@ -255,6 +255,12 @@ int32_t pg_solver_create_moving_mono(pg_capacity* c, pg_diffops* o, const pg_bc_
                                      const pg_border_desc* borders, int32_t nborders, const double* Dcoef,
                                      const double* source_n, const double* source_np1, const double* T_prev,
                                      int32_t scheme, pg_solver** out);
+/* the same, with the state of the previous slab's solver (solved, same mesh) as T_prev -- device to device: the time loop
+   then moves no state over PCIe unless the caller asks for one (pg_solver_get_state) */
+int32_t pg_solver_create_moving_mono_next(pg_capacity* c, pg_diffops* o, const pg_bc_desc* bc_interface,
+                                          const pg_border_desc* borders, int32_t nborders, const double* Dcoef,
+                                          const double* source_n, const double* source_np1, pg_solver* previous,
+                                          int32_t scheme, pg_solver** out);
 int32_t pg_solver_destroy(pg_solver* s);
 
 /* per-step data for time-dependent closures; the host evaluates them at the reference's points and

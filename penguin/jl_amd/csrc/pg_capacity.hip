@@ -317,109 +317,146 @@ struct MotionView {
   double sgn, t0, t1;
   const MotionNode* q;
   MotionNode end[2];
+  // the body at mid time and how far any of the bodies the rule sees (nodes and both faces) is from it: |c - c_mid| + |r - r_mid|
+  // at most `reach` -- a cell FULL for the mid body shrunk by `reach` (EMPTY for it grown by `reach`) is so at every node
+  MotionNode mid;
+  double reach;
+  // the body at node k (k < nq) and at the two time faces (nq, nq + 1), built by the host: every lane of a wave reads the
+  // same one (scalar loads) -- a BallSet per lane would live in scratch
+  const BallSet* bodies;
 };
 
-__device__ inline void body_at(const MotionView& mv, const MotionNode& q, BallSet& bs) {
-  if (mv.kind == BODY_HALFSPACE) bs.pos = q.c[0];
-  else {
-    for (int d = 0; d < 3; ++d) bs.c[0][d] = q.c[d];
-    bs.r = q.r;
+// Work is split as in the static kernels: a cheap pass over all cells finishes the ones that need no quadrature and
+// lists the others; a second kernel gives every listed item one WAVE whose lanes take the time nodes (a box / section
+// measure is a few thousand fp64 instructions with square roots and arc tangents: 64 of them in one lane, for the few
+// cells near the interface, left the whole grid waiting -- 6.4 ms per slab at 1024², 0.3 ms this way).
+__device__ inline double wave_add(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+struct StOut {
+  double *V, *G, *ct, *Cw[3], *Cg[3], *Vt0, *Vt1, *Ctw, *Ctg;
+};
+
+__device__ inline void st_store_plain(const GeoView& g, const MotionView& mv, const StOut& o, i64 lc, const double* lo, const double* hi,
+                                      bool real, bool fluid) {
+  double cw[3] = {0.0, 0.0, 0.0};
+  double v = 0.0, v01 = 0.0, t = 0.0, tw = 0.0;
+  if (real) {
+    for (int d = 0; d < g.N; ++d) cw[d] = 0.5 * (lo[d] + hi[d]);
+    tw = 0.5 * (mv.t0 + mv.t1);
+    if (fluid) { v = full_measure(g, -1) * (mv.t1 - mv.t0); v01 = full_measure(g, -1); t = (double)PG_FULL; }
+  }
+  o.V[lc] = v; o.G[lc] = 0.0; o.ct[lc] = t; o.Vt0[lc] = v01; o.Vt1[lc] = v01; o.Ctw[lc] = tw; o.Ctg[lc] = 0.0;
+  for (int d = 0; d < g.N; ++d) {
+    o.Cw[d][lc] = cw[d];
+    if (o.Cg[d]) o.Cg[d][lc] = 0.0;
   }
 }
 
-__device__ inline BallSet body_init(const MotionView& mv, int N) {
-  BallSet bs;
-  bs.N = N; bs.nballs = 1; bs.complement = mv.complement; bs.kind = mv.kind; bs.axis = mv.axis; bs.sgn = mv.sgn;
-  bs.r = 1.0; bs.pos = 0.0;
-  for (int d = 0; d < 3; ++d) { bs.c[0][d] = 0.0; bs.ax[d] = 1.0; }
-  return bs;
-}
-
-__global__ void k_st_cells(GeoView g, MotionView mv, i64 Mloc, double* V, double* G, double* ct, double* Cw0, double* Cw1,
-                           double* Cw2, double* Cg0, double* Cg1, double* Cg2, double* Vt0, double* Vt1, double* Ctw,
-                           double* Ctg) {
-  double* Cw[3] = {Cw0, Cw1, Cw2};
-  double* Cg[3] = {Cg0, Cg1, Cg2};
-  const double dt = mv.t1 - mv.t0;
+// pass 1 of V, C_ω, Γ, C_γ, type, V(t0), V(t1): cells far from the interface during the whole slab are finished here
+__global__ void k_st_classify(GeoView g, MotionView mv, i64 Mloc, StOut o, int* list, int* count) {
   for (i64 lc = blockIdx.x * (i64)blockDim.x + threadIdx.x; lc < Mloc; lc += (i64)gridDim.x * blockDim.x) {
     i64 idx[3];
     decode_cell(g.N, g.ext, g.plane, g.s0, lc, idx);
-    double v = 0.0, gam = 0.0, t = 0.0, v0 = 0.0, v1 = 0.0, tw = 0.0, tg = 0.0;
-    double cw[3] = {0.0, 0.0, 0.0}, cg[3] = {0.0, 0.0, 0.0};
-    if (is_real_cell(g, idx)) {
-      double lo[3], hi[3];
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    const bool real = is_real_cell(g, idx);
+    int far = -1;   // 1: inside every body the rule sees, -1: outside every one, 0: near
+    if (real) {
       cell_box(g, idx, lo, hi);
-      BallSet bs = body_init(mv, g.N);
-      bool all_full = true, all_empty = true;
-      for (int e = 0; e < 2; ++e) {
-        body_at(mv, mv.end[e], bs);
-        const BoxMeasure m = box_measure(bs, lo, hi, false, c_gl);
-        (e == 0 ? v0 : v1) = m.vol;
-        all_full = all_full && m.type == PG_FULL;
-        all_empty = all_empty && m.type == PG_EMPTY;
-      }
-      double mom[3] = {0.0, 0.0, 0.0}, gm[3] = {0.0, 0.0, 0.0}, momt = 0.0, gmt = 0.0;
-      for (int k = 0; k < mv.nq; ++k) {
-        const MotionNode q = mv.q[k];
-        body_at(mv, q, bs);
-        const BoxMeasure m = box_measure(bs, lo, hi, true, c_gl);
-        all_full = all_full && m.type == PG_FULL;
-        all_empty = all_empty && m.type == PG_EMPTY;
-        const double wv = q.w * m.vol;
-        v += wv;
-        momt += wv * q.tau;
-        for (int d = 0; d < g.N; ++d) mom[d] += wv * m.cen[d];
-        if (m.gamma > 0.0) {
-          double vn;
-          if (mv.kind == BODY_HALFSPACE) vn = q.dc[0];
-          else {
-            double nn = 0.0, dot = 0.0;
-            for (int d = 0; d < g.N; ++d) {
-              const double e = m.cg[d] - q.c[d];
-              nn += e * e;
-              dot += e * q.dc[d];
-            }
-            vn = q.dr + (nn > 0.0 ? dot / sqrt(nn) : 0.0);
-          }
-          const double ws = q.w * m.gamma * sqrt(1.0 + vn * vn);
-          gam += ws;
-          gmt += ws * q.tau;
-          for (int d = 0; d < g.N; ++d) gm[d] += ws * m.cg[d];
-        }
-      }
-      for (int d = 0; d < g.N; ++d) cw[d] = 0.5 * (lo[d] + hi[d]);
-      tw = 0.5 * (mv.t0 + mv.t1);
-      if (all_full) {                       // same bits in every full cell (see full_measure)
-        v = full_measure(g, -1) * dt;
-        v0 = v1 = full_measure(g, -1);
-        t = (double)PG_FULL;
-      } else if (all_empty) {
-        v = 0.0;
-        t = (double)PG_EMPTY;
+      far = 0;
+      if (mv.kind == BODY_HALFSPACE) {
+        const double pl = mv.mid.c[0] - mv.reach, ph = mv.mid.c[0] + mv.reach;
+        if (hi[mv.axis] <= pl) far = mv.sgn > 0.0 ? 1 : -1;
+        else if (lo[mv.axis] >= ph) far = mv.sgn > 0.0 ? -1 : 1;
       } else {
-        t = (double)PG_CUT;
-        if (v > 0.0) {
-          for (int d = 0; d < g.N; ++d) cw[d] = mom[d] / v;
-          tw = momt / v;
-        }
-        if (gam > 0.0) {
-          for (int d = 0; d < g.N; ++d) cg[d] = gm[d] / gam;
-          tg = gmt / gam;
-        }
+        if (mv.mid.r - mv.reach > 0.0 && ball_box_type(mv.mid.c, mv.mid.r - mv.reach, lo, hi, g.N) == PG_FULL) far = 1;
+        else if (ball_box_type(mv.mid.c, mv.mid.r + mv.reach, lo, hi, g.N) == PG_EMPTY) far = -1;
       }
     }
-    V[lc] = v; G[lc] = gam; ct[lc] = t; Vt0[lc] = v0; Vt1[lc] = v1; Ctw[lc] = tw; Ctg[lc] = tg;
-    for (int d = 0; d < g.N; ++d) {
-      Cw[d][lc] = cw[d];
-      if (Cg[d]) Cg[d][lc] = cg[d];
-    }
+    if (far != 0) st_store_plain(g, mv, o, lc, lo, hi, real, (far == 1) != (mv.complement != 0));
+    else list[atomicAdd(count, 1)] = (int)lc;
   }
 }
 
-// A_d, B_d: the conventions of k_sections, integrated over the slab
-__global__ void k_st_sections(GeoView g, MotionView mv, i64 Mloc, const double* ct, const double* Cw0, const double* Cw1,
-                              const double* Cw2, double* A0, double* A1, double* A2, double* B0, double* B1, double* B2) {
-  const double* Cw[3] = {Cw0, Cw1, Cw2};
+// pass 2: one wave per listed cell, lanes over the time nodes (+ lanes 0 / 1: the two time faces)
+__global__ void k_st_cells(GeoView g, MotionView mv, const int* __restrict__ list, int nlist, StOut o) {
+  const int lane = threadIdx.x & 63;
+  const i64 item = (blockIdx.x * (i64)blockDim.x + threadIdx.x) >> 6;
+  if (item >= nlist) return;
+  const i64 lc = list[item];
+  i64 idx[3];
+  decode_cell(g.N, g.ext, g.plane, g.s0, lc, idx);
+  double lo[3], hi[3];
+  cell_box(g, idx, lo, hi);
+  double v = 0.0, gam = 0.0, momt = 0.0, gmt = 0.0, vend = 0.0;
+  double mom[3] = {0.0, 0.0, 0.0}, gm[3] = {0.0, 0.0, 0.0};
+  bool full = true, empty = true;
+  if (lane < 2) {
+    const BoxMeasure m = box_measure(mv.bodies[mv.nq + lane], lo, hi, false, c_gl);
+    vend = m.vol;
+    full = m.type == PG_FULL;
+    empty = m.type == PG_EMPTY;
+  }
+  for (int k = lane; k < mv.nq; k += 64) {
+    const MotionNode q = mv.q[k];
+    const BoxMeasure m = box_measure(mv.bodies[k], lo, hi, true, c_gl);
+    full = full && m.type == PG_FULL;
+    empty = empty && m.type == PG_EMPTY;
+    const double wv = q.w * m.vol;
+    v += wv;
+    momt += wv * q.tau;
+    for (int d = 0; d < g.N; ++d) mom[d] += wv * m.cen[d];
+    if (m.gamma > 0.0) {
+      double vn;
+      if (mv.kind == BODY_HALFSPACE) vn = q.dc[0];
+      else {
+        double nn = 0.0, dot = 0.0;
+        for (int d = 0; d < g.N; ++d) {
+          const double e = m.cg[d] - q.c[d];
+          nn += e * e;
+          dot += e * q.dc[d];
+        }
+        vn = q.dr + (nn > 0.0 ? dot / sqrt(nn) : 0.0);
+      }
+      const double ws = q.w * m.gamma * sqrt(1.0 + vn * vn);
+      gam += ws;
+      gmt += ws * q.tau;
+      for (int d = 0; d < g.N; ++d) gm[d] += ws * m.cg[d];
+    }
+  }
+  const bool all_full = __all(full), all_empty = __all(empty);
+  v = wave_add(v); gam = wave_add(gam); momt = wave_add(momt); gmt = wave_add(gmt);
+  for (int d = 0; d < g.N; ++d) { mom[d] = wave_add(mom[d]); gm[d] = wave_add(gm[d]); }
+  const double v0 = __shfl(vend, 0, 64), v1 = __shfl(vend, 1, 64);
+  if (lane != 0) return;
+  if (all_full || all_empty) {
+    st_store_plain(g, mv, o, lc, lo, hi, true, all_full);
+    return;
+  }
+  double cw[3], cg[3] = {0.0, 0.0, 0.0}, tw = 0.5 * (mv.t0 + mv.t1), tg = 0.0;
+  for (int d = 0; d < g.N; ++d) cw[d] = 0.5 * (lo[d] + hi[d]);
+  if (v > 0.0) {
+    for (int d = 0; d < g.N; ++d) cw[d] = mom[d] / v;
+    tw = momt / v;
+  }
+  if (gam > 0.0) {
+    for (int d = 0; d < g.N; ++d) cg[d] = gm[d] / gam;
+    tg = gmt / gam;
+  }
+  o.V[lc] = v; o.G[lc] = gam; o.ct[lc] = (double)PG_CUT; o.Vt0[lc] = v0; o.Vt1[lc] = v1; o.Ctw[lc] = tw; o.Ctg[lc] = tg;
+  for (int d = 0; d < g.N; ++d) {
+    o.Cw[d][lc] = cw[d];
+    if (o.Cg[d]) o.Cg[d][lc] = cg[d];
+  }
+}
+
+// A_d, B_d: the conventions of k_sections, integrated over the slab.  Pass 1 writes the faces that need no quadrature and
+// lists (cell, d) for the others; pass 2: one wave per item.
+__global__ void k_st_sections(GeoView g, MotionView mv, i64 Mloc, const double* ct, double* A0, double* A1, double* A2, double* B0,
+                              double* B1, double* B2, int* list, int* count, int cap) {
   double* A[3] = {A0, A1, A2};
   double* B[3] = {B0, B1, B2};
   const double dt = mv.t1 - mv.t0;
@@ -427,35 +464,21 @@ __global__ void k_st_sections(GeoView g, MotionView mv, i64 Mloc, const double* 
     i64 idx[3];
     decode_cell(g.N, g.ext, g.plane, g.s0, lc, idx);
     const bool real = is_real_cell(g, idx);
-    BallSet bs = body_init(mv, g.N);
     for (int d = 0; d < g.N; ++d) {
       bool others_real = true;
       for (int k = 0; k < g.N; ++k)
         if (k != d && idx[k] >= g.n[k]) others_real = false;
       double a = 0.0, b = 0.0;
       if (others_real) {
-        double lo[3], hi[3];
-        for (int k = 0; k < g.N; ++k) {
-          const i64 ik = idx[k] < g.n[k] ? idx[k] : g.n[k] - 1;
-          lo[k] = g.nodes[k][ik];
-          hi[k] = g.nodes[k][ik + 1];
-        }
         double t = (double)PG_CUT;
         if (real) t = ct[lc];
         else if (idx[d] >= g.n[d] && lc - g.stride[d] >= 0) t = ct[lc - g.stride[d]];
         if (g.N > 1 && t == (double)PG_FULL) {
           a = full_measure(g, d) * dt;
           b = real ? a : 0.0;
-        } else if (g.N > 1 && t == (double)PG_EMPTY) {
-          a = 0.0;
-          b = 0.0;
-        } else {
-          for (int k = 0; k < mv.nq; ++k) {
-            const MotionNode q = mv.q[k];
-            body_at(mv, q, bs);
-            a += q.w * section_measure(bs, d, g.nodes[d][idx[d]], lo, hi, full_measure(g, d));
-            if (real) b += q.w * section_measure(bs, d, Cw[d][lc], lo, hi, full_measure(g, d));
-          }
+        } else if (!(g.N > 1 && t == (double)PG_EMPTY)) {
+          const int slot = atomicAdd(count, 1);
+          if (slot < cap) { list[2 * slot] = (int)lc; list[2 * slot + 1] = d; }
         }
       }
       A[d][lc] = a;
@@ -464,16 +487,46 @@ __global__ void k_st_sections(GeoView g, MotionView mv, i64 Mloc, const double* 
   }
 }
 
-// W_d: the conventions of k_stagger, integrated over the slab
+__global__ void k_st_sections_cut(GeoView g, MotionView mv, const int* __restrict__ list, int nlist, const double* Cw0,
+                                  const double* Cw1, const double* Cw2, double* A0, double* A1, double* A2, double* B0,
+                                  double* B1, double* B2) {
+  const double* Cw[3] = {Cw0, Cw1, Cw2};
+  double* A[3] = {A0, A1, A2};
+  double* B[3] = {B0, B1, B2};
+  const int lane = threadIdx.x & 63;
+  const i64 item = (blockIdx.x * (i64)blockDim.x + threadIdx.x) >> 6;
+  if (item >= nlist) return;
+  const i64 lc = list[2 * item];
+  const int d = list[2 * item + 1];
+  i64 idx[3];
+  decode_cell(g.N, g.ext, g.plane, g.s0, lc, idx);
+  const bool real = is_real_cell(g, idx);
+  double lo[3], hi[3];
+  for (int k = 0; k < g.N; ++k) {
+    const i64 ik = idx[k] < g.n[k] ? idx[k] : g.n[k] - 1;
+    lo[k] = g.nodes[k][ik];
+    hi[k] = g.nodes[k][ik + 1];
+  }
+  double a = 0.0, b = 0.0;
+  for (int k = lane; k < mv.nq; k += 64) {
+    const double wq = mv.q[k].w;
+    a += wq * section_measure(mv.bodies[k], d, g.nodes[d][idx[d]], lo, hi, full_measure(g, d));
+    if (real) b += wq * section_measure(mv.bodies[k], d, Cw[d][lc], lo, hi, full_measure(g, d));
+  }
+  a = wave_add(a);
+  b = wave_add(b);
+  if (lane == 0) { A[d][lc] = a; B[d][lc] = b; }
+}
+
+// W_d: the conventions of k_stagger, integrated over the slab; same two passes
 __global__ void k_st_stagger(GeoView g, MotionView mv, i64 Mloc, const double* ct, const double* Cw0, const double* Cw1,
-                             const double* Cw2, double* W0, double* W1, double* W2) {
+                             const double* Cw2, double* W0, double* W1, double* W2, int* list, int* count, int cap) {
   const double* Cw[3] = {Cw0, Cw1, Cw2};
   double* W[3] = {W0, W1, W2};
   const double dt = mv.t1 - mv.t0;
   for (i64 lc = blockIdx.x * (i64)blockDim.x + threadIdx.x; lc < Mloc; lc += (i64)gridDim.x * blockDim.x) {
     i64 idx[3];
     decode_cell(g.N, g.ext, g.plane, g.s0, lc, idx);
-    BallSet bs = body_init(mv, g.N);
     for (int d = 0; d < g.N; ++d) {
       double w = 0.0;
       bool others_real = true;
@@ -487,31 +540,50 @@ __global__ void k_st_stagger(GeoView g, MotionView mv, i64 Mloc, const double* c
       if (others_real && have && ip != in) {
         const double tp = ct[lp], tn = ct[ln];
         if (!(tp == 0.0 && tn == 0.0)) {
-          double lo[3], hi[3];
-          for (int k = 0; k < g.N; ++k) {
-            if (k == d) continue;
-            lo[k] = g.nodes[k][idx[k]];
-            hi[k] = g.nodes[k][idx[k] + 1];
-          }
-          lo[d] = Cw[d][lp];
-          hi[d] = Cw[d][ln];
-          bool degenerate = false;
+          bool degenerate = !(Cw[d][ln] - Cw[d][lp] > 0.0);
           for (int k = 0; k < g.N; ++k)
-            if (!(hi[k] - lo[k] > 0.0)) degenerate = true;
+            if (k != d && !(g.nodes[k][idx[k] + 1] - g.nodes[k][idx[k]] > 0.0)) degenerate = true;
           if (!degenerate) {
             if (tp == 1.0 && tn == 1.0) w = full_measure(g, -1) * dt;
-            else
-              for (int k = 0; k < mv.nq; ++k) {
-                const MotionNode q = mv.q[k];
-                body_at(mv, q, bs);
-                w += q.w * box_measure(bs, lo, hi, false, c_gl).vol;
-              }
+            else {
+              const int slot = atomicAdd(count, 1);
+              if (slot < cap) { list[2 * slot] = (int)lc; list[2 * slot + 1] = d; }
+            }
           }
         }
       }
       W[d][lc] = w;
     }
   }
+}
+
+__global__ void k_st_stagger_cut(GeoView g, MotionView mv, const int* __restrict__ list, int nlist, const double* Cw0,
+                                 const double* Cw1, const double* Cw2, double* W0, double* W1, double* W2) {
+  const double* Cw[3] = {Cw0, Cw1, Cw2};
+  double* W[3] = {W0, W1, W2};
+  const int lane = threadIdx.x & 63;
+  const i64 item = (blockIdx.x * (i64)blockDim.x + threadIdx.x) >> 6;
+  if (item >= nlist) return;
+  const i64 lc = list[2 * item];
+  const int d = list[2 * item + 1];
+  i64 idx[3];
+  decode_cell(g.N, g.ext, g.plane, g.s0, lc, idx);
+  const i64 ip = idx[d] - 1 < 0 ? 0 : idx[d] - 1;
+  const i64 in = idx[d] < g.n[d] - 1 ? idx[d] : g.n[d] - 1;
+  const i64 lp = lc + (ip - idx[d]) * g.stride[d];
+  const i64 ln = lc + (in - idx[d]) * g.stride[d];
+  double lo[3], hi[3];
+  for (int k = 0; k < g.N; ++k) {
+    if (k == d) continue;
+    lo[k] = g.nodes[k][idx[k]];
+    hi[k] = g.nodes[k][idx[k] + 1];
+  }
+  lo[d] = Cw[d][lp];
+  hi[d] = Cw[d][ln];
+  double w = 0.0;
+  for (int k = lane; k < mv.nq; k += 64) w += mv.q[k].w * box_measure(mv.bodies[k], lo, hi, false, c_gl).vol;
+  w = wave_add(w);
+  if (lane == 0) W[d][lc] = w;
 }
 
 GeoView geo_view(pg_mesh* m, const Slab& s) {
@@ -749,6 +821,7 @@ int32_t pg_capacity_create_spacetime(pg_mesh* m, const pg_motion_desc* mo, pg_ca
   PG_API_BEGIN
   require_init();
   PG_REQUIRE(m && mo && out && mo->nodes, "pg_capacity_create_spacetime: NULL argument");
+  AsyncAllocScope pool;   // one capacity per time slab: the stream-ordered allocator (pg_common.h)
   PG_REQUIRE(ctx().nranks == 1 && !ctx().comm, "pg_capacity_create_spacetime: single rank only");
   const int N = m->N;
   PG_REQUIRE(N == 1 || N == 2, "space-time capacities: 1-D+t and 2-D+t (the reference's 3-D+t blocks drop the z direction)");
@@ -789,6 +862,36 @@ int32_t pg_capacity_create_spacetime(pg_mesh* m, const pg_motion_desc* mo, pg_ca
   DevBuf<MotionNode> dq(mo->nq);
   dq.upload(hq.data(), mo->nq);
   mv.q = dq.p;
+  {
+    const double tm = 0.5 * (mo->t0 + mo->t1);
+    int km = 0;
+    for (int k = 1; k < mo->nq; ++k)
+      if (fabs(hq[k].tau - tm) < fabs(hq[km].tau - tm)) km = k;
+    mv.mid = hq[km];
+    double reach = 0.0;
+    auto dist = [&](const MotionNode& q) {
+      double dc = 0.0;
+      if (mv.kind == BODY_HALFSPACE) return fabs(q.c[0] - mv.mid.c[0]);
+      for (int d = 0; d < N; ++d) dc += (q.c[d] - mv.mid.c[d]) * (q.c[d] - mv.mid.c[d]);
+      return std::sqrt(dc) + fabs(q.r - mv.mid.r);
+    };
+    for (int k = 0; k < mo->nq; ++k) reach = std::max(reach, dist(hq[k]));
+    reach = std::max(reach, std::max(dist(mv.end[0]), dist(mv.end[1])));
+    mv.reach = reach * (1.0 + 1e-12) + 1e-300;
+  }
+  std::vector<BallSet> hb(mo->nq + 2);
+  for (int k = 0; k < mo->nq + 2; ++k) {
+    const MotionNode& q = k < mo->nq ? hq[k] : mv.end[k - mo->nq];
+    BallSet& b = hb[k];
+    std::memset(&b, 0, sizeof(b));
+    b.N = N; b.nballs = 1; b.complement = mv.complement; b.kind = mv.kind; b.axis = mv.axis; b.sgn = mv.sgn;
+    b.r = mv.kind == BODY_HALFSPACE ? 1.0 : q.r;
+    b.pos = mv.kind == BODY_HALFSPACE ? q.c[0] : 0.0;
+    for (int d = 0; d < 3; ++d) { b.c[0][d] = mv.kind == BODY_HALFSPACE ? 0.0 : q.c[d]; b.ax[d] = 1.0; }
+  }
+  DevBuf<BallSet> dbodies(mo->nq + 2);
+  dbodies.upload(hb.data(), mo->nq + 2);
+  mv.bodies = dbodies.p;
 
   auto* c = new pg_capacity();
   std::unique_ptr<pg_capacity> guard(c);
@@ -808,16 +911,46 @@ int32_t pg_capacity_create_spacetime(pg_mesh* m, const pg_motion_desc* mo, pg_ca
   GeoView g = geo_view(m, c->slab);
   EventPair ev;
   PG_HIP(hipEventRecord(ev.e0, st));
-  const int gr = grid_for(Ml, 64, 256 * 16);
-  hipLaunchKernelGGL(k_st_cells, dim3(gr), dim3(64), 0, st, g, mv, Ml, c->V.p, c->G.p, c->ct.p, c->Cw[0].p, c->Cw[1].p,
-                     c->Cw[2].p, c->Cg[0].p, c->Cg[1].p, c->Cg[2].p, c->Vt[0].p, c->Vt[1].p, c->Ctw.p, c->Ctg.p);
+  const int gr = grid_for(Ml, 256, 256 * 16);
+  StOut so;
+  so.V = c->V.p; so.G = c->G.p; so.ct = c->ct.p; so.Vt0 = c->Vt[0].p; so.Vt1 = c->Vt[1].p; so.Ctw = c->Ctw.p; so.Ctg = c->Ctg.p;
+  for (int d = 0; d < 3; ++d) { so.Cw[d] = c->Cw[d].p; so.Cg[d] = c->Cg[d].p; }
+  DevBuf<int> near_list(Ml), counters(3);
+  counters.zero();
+  hipLaunchKernelGGL(k_st_classify, dim3(gr), dim3(256), 0, st, g, mv, Ml, so, near_list.p, counters.p);
   PG_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_st_sections, dim3(gr), dim3(64), 0, st, g, mv, Ml, c->ct.p, c->Cw[0].p, c->Cw[1].p, c->Cw[2].p,
-                     c->A[0].p, c->A[1].p, c->A[2].p, c->B[0].p, c->B[1].p, c->B[2].p);
+  int hc[3];
+  counters.download(hc, 3);
+  const int nnear = hc[0];
+  c->n_cut_local = nnear;
+  auto waves = [](i64 items) { return dim3((unsigned)((items * 64 + 255) / 256)); };
+  if (nnear > 0) {
+    hipLaunchKernelGGL(k_st_cells, waves(nnear), dim3(256), 0, st, g, mv, near_list.p, nnear, so);
+    PG_HIP(hipGetLastError());
+  }
+  // at most N faces / staggered volumes per near cell and per neighbour of one (1-D: every face is evaluated)
+  const i64 cap = std::min<i64>((i64)N * Ml, (N == 1 ? (i64)Ml : (i64)6 * N * (i64)nnear) + 1024);
+  DevBuf<int> list2(2 * cap);
+  hipLaunchKernelGGL(k_st_sections, dim3(gr), dim3(256), 0, st, g, mv, Ml, c->ct.p, c->A[0].p, c->A[1].p, c->A[2].p, c->B[0].p,
+                     c->B[1].p, c->B[2].p, list2.p, counters.p + 1, (int)cap);
   PG_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_st_stagger, dim3(gr), dim3(64), 0, st, g, mv, Ml, c->ct.p, c->Cw[0].p, c->Cw[1].p, c->Cw[2].p,
-                     c->W[0].p, c->W[1].p, c->W[2].p);
+  counters.download(hc, 3);
+  PG_REQUIRE(hc[1] <= cap, "internal: space-time section work list overflow");
+  if (hc[1] > 0) {
+    hipLaunchKernelGGL(k_st_sections_cut, waves(hc[1]), dim3(256), 0, st, g, mv, list2.p, hc[1], c->Cw[0].p, c->Cw[1].p, c->Cw[2].p,
+                       c->A[0].p, c->A[1].p, c->A[2].p, c->B[0].p, c->B[1].p, c->B[2].p);
+    PG_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_st_stagger, dim3(gr), dim3(256), 0, st, g, mv, Ml, c->ct.p, c->Cw[0].p, c->Cw[1].p, c->Cw[2].p, c->W[0].p,
+                     c->W[1].p, c->W[2].p, list2.p, counters.p + 2, (int)cap);
   PG_HIP(hipGetLastError());
+  counters.download(hc, 3);
+  PG_REQUIRE(hc[2] <= cap, "internal: space-time staggered-volume work list overflow");
+  if (hc[2] > 0) {
+    hipLaunchKernelGGL(k_st_stagger_cut, waves(hc[2]), dim3(256), 0, st, g, mv, list2.p, hc[2], c->Cw[0].p, c->Cw[1].p, c->Cw[2].p,
+                       c->W[0].p, c->W[1].p, c->W[2].p);
+    PG_HIP(hipGetLastError());
+  }
   PG_HIP(hipEventRecord(ev.e1, st));
   PG_HIP(hipEventSynchronize(ev.e1));
   float ms = 0.f;

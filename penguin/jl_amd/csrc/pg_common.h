@@ -86,6 +86,18 @@ void comm_allreduce_max_f64(double* dev, int count, hipStream_t st);
 void comm_allreduce_sum_u64(unsigned long long* dev, i64 count, hipStream_t st);
 
 // ---- device buffer -------------------------------------------------------------------------
+// Allocation: hipMalloc / hipFree, or the stream-ordered allocator on the compute stream (a pool that is never trimmed).
+// hipMalloc / hipFree synchronise the device, and a caller that rebuilds capacities and systems every time step -- the
+// moving-body solver: ~60 buffers per slab -- pays that ~120 times per step (17 -> 5 ms per slab at 1024²).  The pool serves
+// the allocations made inside an AsyncAllocScope (the moving path's entry points) or all of them with PG_ASYNC_ALLOC=1 (opt-in:
+// one 512^3 test run aborted inside the runtime with it); pointers remember where they came from.
+void* dev_alloc(size_t bytes);   // pg_context.hip
+void dev_free(void* p);
+struct AsyncAllocScope {
+  AsyncAllocScope();
+  ~AsyncAllocScope();
+};
+
 template <class T>
 struct DevBuf {
   T* p = nullptr;
@@ -101,14 +113,14 @@ struct DevBuf {
   }
   ~DevBuf() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) dev_free(p);
     p = nullptr; n = 0;
   }
   void alloc(i64 n_) {
     release();
     n = n_;
     // 64 bytes of slack: 16-byte loads that start at the last element (SpMV pair loads) stay inside the allocation
-    if (n > 0) PG_HIP(hipMalloc(reinterpret_cast<void**>(&p), sizeof(T) * static_cast<size_t>(n) + 64));
+    if (n > 0) p = static_cast<T*>(dev_alloc(sizeof(T) * static_cast<size_t>(n) + 64));
   }
   void zero() {
     if (n > 0) PG_HIP(hipMemsetAsync(p, 0, sizeof(T) * static_cast<size_t>(n), ctx().stream));

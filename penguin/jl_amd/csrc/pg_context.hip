@@ -1,5 +1,8 @@
 // pg_context.hip -- device / stream / RCCL communicator lifetime, error channel, Mesh.
 #include "pg_common.h"
+
+#include <mutex>
+#include <unordered_set>
 #include "pg_host_algos.h"
 
 #include <algorithm>
@@ -43,6 +46,60 @@ static void init_device(int device_id) {
 }  // namespace pg
 
 using namespace pg;
+
+namespace pg {
+namespace {
+thread_local int t_async_scope = 0;
+std::mutex g_pool_mutex;
+std::unordered_set<void*> g_pool_ptrs;
+bool async_everywhere() {
+  static const bool on = getenv("PG_ASYNC_ALLOC") ? atoi(getenv("PG_ASYNC_ALLOC")) != 0 : false;
+  return on;
+}
+}  // namespace
+AsyncAllocScope::AsyncAllocScope() { ++t_async_scope; }
+AsyncAllocScope::~AsyncAllocScope() { --t_async_scope; }
+
+void* dev_alloc(size_t bytes) {
+  void* p = nullptr;
+  Context& c = ctx();
+  if ((t_async_scope > 0 || async_everywhere()) && c.inited && c.stream && !c.local) {
+    static bool pool_set = false;
+    if (!pool_set) {
+      hipMemPool_t pool;
+      if (hipDeviceGetDefaultMemPool(&pool, c.device) == hipSuccess) {
+        uint64_t keep = ~0ull;     // never hand memory back at synchronisation points
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+      }
+      pool_set = true;
+    }
+    if (hipMallocAsync(&p, bytes, c.stream) == hipSuccess && p) {
+      std::lock_guard<std::mutex> lk(g_pool_mutex);
+      g_pool_ptrs.insert(p);
+      return p;
+    }
+    (void)hipGetLastError();
+    p = nullptr;
+  }
+  PG_HIP(hipMalloc(&p, bytes));
+  return p;
+}
+
+void dev_free(void* p) {
+  bool pooled = false;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    pooled = g_pool_ptrs.erase(p) > 0;
+  }
+  if (pooled) {
+    Context* c = thread_context();
+    Context& cc = c ? *c : ctx();
+    if (cc.inited && cc.stream && hipFreeAsync(p, cc.stream) == hipSuccess) return;
+    (void)hipGetLastError();
+  }
+  (void)hipFree(p);
+}
+}  // namespace pg
 
 extern "C" {
 

@@ -66,6 +66,7 @@ struct pg_solver {
   // moving body (pg_solver_create_moving_mono): one space-time step; Ψn1 = psip.(Vn, Vn_1), Ψn = psim.(Vn, Vn_1)
   bool moving = false;
   DevBuf<double> psi_p, psi_m;
+  pg_solver* init_from = nullptr;   // constructor only: the previous slab's solver whose state is this one's initial state
 };
 
 namespace {
@@ -484,6 +485,8 @@ void build_first_rhs(pg_solver* s) {
   PG_HIP(hipStreamSynchronize(st));
 }
 
+void materialize_x(pg_solver* s);
+
 void setup_common(pg_solver* s, const pg_border_desc* borders, int nborders, const double* T0) {
   hipStream_t st = ctx().stream;
   const Slab& slab = s->slab;
@@ -515,6 +518,16 @@ void setup_common(pg_solver* s, const pg_border_desc* borders, int nborders, con
   s->T0pad.zero();   // T0 == NULL: zeros(2M) without a host array (multi-GPU sizes)
   if (T0)
     for (int k = 0; k < s->K; ++k) s->T0pad.upload(T0 + (i64)k * s->M + slab.first_cell(), s->Mloc, (i64)k * s->Mloc);
+  if (s->init_from) {     // the previous slab's state, device to device (zeros at its eliminated unknowns, solver.jl:186-187)
+    pg_solver* p = s->init_from;
+    PG_REQUIRE(p->K == s->K && p->Mloc == s->Mloc && p->M == s->M, "previous solver lives on another mesh");
+    materialize_x(p);
+    if (p->nb.n_own > 0)
+      hipLaunchKernelGGL(k_scatter_active, dim3(grid_for(p->nb.n_own, BLOCK)), dim3(BLOCK), 0, st, make_segs(p->nb), p->nb.n_own,
+                         p->Mloc, p->nb.row_cell.p, p->x.p, s->T0pad.p);
+    PG_HIP(hipGetLastError());
+    s->init_from = nullptr;
+  }
 
   // K10 once, K7/K9 for the constructor scheme
   const SysParams P = make_params(s, s->scheme_ctor);
@@ -632,7 +645,18 @@ pg_krylov_opts default_opts() {
 void do_initial(pg_solver* s, const pg_krylov_opts* opts, SolveStats& st) {
   const pg_krylov_opts o = opts ? *opts : default_opts();
   // solve_system!(s) with the constructor's A and b (diffusion.jl:275)
-  krylov_solve(s->A_ctor, s->nb, s->slab, s->b.p, s->ysol.p, s->work, o, st);
+  const i64 n = s->nb.n_own;
+  if (s->moving && o.warm_start != 0 && o.method == PG_METHOD_BICGSTAB && n > 0) {
+    // a slab of the moving solver: start from the previous state on this slab's active set (s->x, written by k_rhs_first;
+    // fresh cells start from the 0 their eliminated unknown held) -- a time step, as pg_solver_step's warm start
+    hipStream_t stream = ctx().stream;
+    hipLaunchKernelGGL(k_scale_state, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, stream, n, s->A_ctor.ds.p, s->x.p, s->z.p, 1);
+    spmv_halo(s->A_ctor, s->nb, s->slab, s->z.p, s->y.p, stream);
+    PG_HIP(hipGetLastError());
+    krylov_solve(s->A_ctor, s->nb, s->slab, s->b.p, s->ysol.p, s->work, o, st, s->z.p, s->y.p, false);
+  } else {
+    krylov_solve(s->A_ctor, s->nb, s->slab, s->b.p, s->ysol.p, s->work, o, st);
+  }
   std::swap(s->z.p, s->ysol.p);   // the scaled solution becomes the state (same-size buffers trade roles)
   s->z_matrix = &s->A_ctor;
   s->x_valid = false;
@@ -742,12 +766,35 @@ int32_t pg_solver_create_unsteady_mono(pg_capacity* c, pg_diffops* o, const pg_b
   PG_API_END
 }
 
+static int32_t create_moving(pg_capacity* c, pg_diffops* o, const pg_bc_desc* bc_interface, const pg_border_desc* borders,
+                             int32_t nborders, const double* Dcoef, const double* source_n, const double* source_np1,
+                             const double* T_prev, pg_solver* prev, int32_t scheme, pg_solver** out);
+
 int32_t pg_solver_create_moving_mono(pg_capacity* c, pg_diffops* o, const pg_bc_desc* bc_interface,
                                      const pg_border_desc* borders, int32_t nborders, const double* Dcoef,
                                      const double* source_n, const double* source_np1, const double* T_prev,
                                      int32_t scheme, pg_solver** out) {
+  return create_moving(c, o, bc_interface, borders, nborders, Dcoef, source_n, source_np1, T_prev, nullptr, scheme, out);
+}
+
+int32_t pg_solver_create_moving_mono_next(pg_capacity* c, pg_diffops* o, const pg_bc_desc* bc_interface,
+                                          const pg_border_desc* borders, int32_t nborders, const double* Dcoef,
+                                          const double* source_n, const double* source_np1, pg_solver* previous,
+                                          int32_t scheme, pg_solver** out) {
+  if (!previous) {
+    pg::set_last_error("pg_solver_create_moving_mono_next: NULL previous solver");
+    return 1;
+  }
+  return create_moving(c, o, bc_interface, borders, nborders, Dcoef, source_n, source_np1, nullptr, previous, scheme, out);
+}
+
+static int32_t create_moving(pg_capacity* c, pg_diffops* o, const pg_bc_desc* bc_interface, const pg_border_desc* borders,
+                             int32_t nborders, const double* Dcoef, const double* source_n, const double* source_np1,
+                             const double* T_prev, pg_solver* prev, int32_t scheme, pg_solver** out) {
   PG_API_BEGIN
   require_init();
+  if (prev) PG_REQUIRE(prev->initial_done, "pg_solver_create_moving_mono_next: the previous slab has not been solved");
+  AsyncAllocScope pool;   // one solver per time slab: the stream-ordered allocator (pg_common.h)
   PG_REQUIRE(scheme == PG_SCHEME_BE || scheme == PG_SCHEME_CN, "scheme must be BE or CN");
   PG_REQUIRE(c && o && bc_interface && out, "solver constructor: NULL argument");
   PG_REQUIRE(o->cap == c, "operators were built from a different capacity");
@@ -778,6 +825,7 @@ int32_t pg_solver_create_moving_mono(pg_capacity* c, pg_diffops* o, const pg_bc_
     upload_local(s->g_n, bc_interface->value_array, s->slab);
   }
   s->bc_i.value_array = nullptr;
+  s->init_from = prev;
   setup_common(s, borders, nborders, T_prev);
   *out = guard.release();
   PG_API_END
@@ -903,6 +951,7 @@ int32_t pg_solver_initial_solve(pg_solver* s, const pg_krylov_opts* opts, pg_ste
   require_init();
   PG_REQUIRE(s, "Solver is not initialized. Call a solver constructor first.");
   SolveStats st;
+  std::unique_ptr<AsyncAllocScope> pool(s->moving ? new AsyncAllocScope() : nullptr);   // (work vectors allocated on first use)
   do_initial(s, opts, st);
   fill_info(s, st, info);
   PG_API_END

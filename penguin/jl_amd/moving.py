@@ -213,7 +213,7 @@ api.Capacity.__new__ = staticmethod(_capacity_new)
 
 
 def _create_step(s: api.Solver, phase: api.Phase, bc_b, bc_i, Î”t: float, Táµ¢: Optional[np.ndarray], mesh: api.Mesh, scheme: str,
-                 t: float):
+                 t: float, from_previous: bool = False):
     """A_/b_mono_unstead_diff_moving + BC_border_mono!(A, b, bc_b, mesh; t) of one slab (diffusion.jl:29-33, 254-258)."""
     cap = phase.capacity
     if not isinstance(cap, SpaceTimeCapacity):
@@ -229,13 +229,17 @@ def _create_step(s: api.Solver, phase: api.Phase, bc_b, bc_i, Î”t: float, Táµ¢: 
     if sch == "CN" and f1 is not None and f0 is None:
         f0 = np.zeros(M)
     borders, nb, bvals = api._border_descs(bc_b, mesh, float(t))
-    if s._h:
-        L.check(L.lib().pg_solver_destroy(s._h))
-        s._h = C.c_void_p()
-    L.check(L.lib().pg_solver_create_moving_mono(
-        cap._h, phase.operator._h, C.byref(desc), borders, C.c_int32(nb), L.dptr(D_arr) if D_arr is not None else None,
-        L.dptr(f0) if f0 is not None else None, L.dptr(f1) if f1 is not None else None,
-        L.dptr(Táµ¢) if Táµ¢ is not None else None, C.c_int32(L.PG_SCHEME[sch]), C.byref(s._h)))
+    old, new = s._h, C.c_void_p()
+    common = (cap._h, phase.operator._h, C.byref(desc), borders, C.c_int32(nb), L.dptr(D_arr) if D_arr is not None else None,
+              L.dptr(f0) if f0 is not None else None, L.dptr(f1) if f1 is not None else None)
+    if from_previous:      # the previous slab's state stays on the device (pg_solver_create_moving_mono_next)
+        L.check(L.lib().pg_solver_create_moving_mono_next(*common, old, C.c_int32(L.PG_SCHEME[sch]), C.byref(new)))
+    else:
+        L.check(L.lib().pg_solver_create_moving_mono(*common, L.dptr(Táµ¢) if Táµ¢ is not None else None,
+                                                     C.c_int32(L.PG_SCHEME[sch]), C.byref(new)))
+    s._h = new
+    if old:
+        L.check(L.lib().pg_solver_destroy(old))
     if bvals is not None:
         L.check(L.lib().pg_solver_set_border_values(s._h, L.dptr(bvals)))
     s._keep = (cap, phase.operator)      # the device solver reads the capacity: keep it alive as long as the handle
@@ -262,10 +266,12 @@ def MovingDiffusionUnsteadyMono(phase: api.Phase, bc_b, bc_i, Î”t: float, Táµ¢: 
 def solve_MovingDiffusionUnsteadyMono_b(s: api.Solver, phase: api.Phase, body, Î”t: float, Tâ‚›: float, Tâ‚‘: float, bc_b, bc,
                                         mesh: api.Mesh, scheme: str, method="gmres", algorithm=None, geometry_method="VOFI",
                                         verbose: bool = False, max_steps: Optional[int] = None, time_panels: int = 16,
-                                        time_order: int = 4, **kwargs):
+                                        time_order: int = 4, save_states: bool = True, **kwargs):
     """solve_MovingDiffusionUnsteadyMono!(s, phase, body, Î”t, Tâ‚›, Tâ‚‘, bc_b, bc, mesh, scheme; method, ...) --
     prescribedmotionsolver/diffusion.jl:227-268: the constructor's system first (states[1]); then `while t < Tâ‚‘`:
-    t += Î”t, the capacity of the slab [t, t+Î”t], new blocks and border rows at t, solve, push."""
+    t += Î”t, the capacity of the slab [t, t+Î”t], new blocks and border rows at t, solve, push.
+    `save_states=False` (not in the reference): the state is handed from slab to slab on the device and only the last one is
+    fetched (`s.x`, `s.states[-1]`); the reference's `push!(s.states, s.x)` costs a device-to-host copy of 2M doubles per slab."""
     if s is None or not s._h:
         raise PenguinHipError("Solver is not initialized. Call a solver constructor first.")
     opts = api._krylov_opts(method, kwargs)
@@ -276,11 +282,12 @@ def solve_MovingDiffusionUnsteadyMono_b(s: api.Solver, phase: api.Phase, body, Î
         L.check(L.lib().pg_solver_initial_solve(s._h, C.byref(opts), C.byref(info)))
         api._step_info_check(s, info, what)
         s._initial_done = True
-        s.x = s._fetch_state(-1)
-        s.states.append(s.x)
         s.ch.append(info)
+        if save_states:
+            s.x = s._fetch_state(-1)
+            s.states.append(s.x)
         if verbose:
-            print("Solver Extremum : ", float(np.max(np.abs(s.x))))
+            print("Solver Extremum : ", float(info.extremum))
 
     t = float(Tâ‚›)
     if verbose:
@@ -297,8 +304,11 @@ def solve_MovingDiffusionUnsteadyMono_b(s: api.Solver, phase: api.Phase, body, Î
         cap = api.Capacity(body, SpaceTimeMesh(mesh, [t, t + Î”t]), time_panels=time_panels, time_order=time_order,
                            compute_centroids=True, method=geometry_method)
         ph = api.Phase(cap, api.DiffusionOps(cap), phase.source, phase.Diffusion_coeff)
-        _create_step(s, ph, bc_b, bc, float(Î”t), Táµ¢, mesh, sch, t)
+        _create_step(s, ph, bc_b, bc, float(Î”t), Táµ¢, mesh, sch, t, from_previous=not save_states)
         solve_current(f"the solve of the slab starting at t = {t}")
         Táµ¢ = s.x
         steps += 1
+    if not save_states:
+        s.x = s._fetch_state(-1)
+        s.states.append(s.x)
     return s

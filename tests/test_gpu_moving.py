@@ -151,7 +151,7 @@ def test_moving_steps_match_oracle(pj, name, scheme, bc_kind):
         assert np.array_equal(np.flatnonzero(x != 0.0), np.flatnonzero(xo != 0.0)), f"active set of state {k}"
         tol = max(TOL_T, 50.0 * max(sens[: k + 1]))
         if bc_kind == "dirichlet":
-            assert tol == TOL_T, f"state {k}: a Dirichlet system this sensitive ({max(sens):.1e}) is not expected"
+            assert max(sens[: k + 1]) < 1e-10, f"state {k}: a Dirichlet system this sensitive ({max(sens):.1e}) is not expected"
         assert rel_l2(x, xo) <= tol, f"state {k}: {rel_l2(x, xo):.2e} (bar {tol:.1e})"
         nact.add(int(np.count_nonzero(xo)))
     assert len(nact) > 1          # the active set did change from slab to slab (fresh / dead cells were exercised)
@@ -215,3 +215,23 @@ def test_moving_interface_similarity_solution(pj, scheme):
         assert errs[0] < 2.5e-3 and errs[1] < 0.4 * errs[0], errs
     else:       # an order below BE at these sizes; the error then stalls near the interface (fresh cells restart from 0)
         assert errs[0] < 3e-4 and errs[1] < 3e-4, errs
+
+
+def test_moving_states_handed_over_on_the_device(pj):
+    """save_states=False: pg_solver_create_moving_mono_next takes the previous slab's state on the device; the last state is the
+    one the host-state loop ends with, bit for bit (same systems, same start vectors)."""
+    mesh, omesh, (body, obody), dt = _cases(pj)["2d"]
+    M = int(np.prod(omesh.ext))
+    f = lambda x, y, z, t: 0.3 + 0.2 * x + 0.5 * t
+    bc = pj.Dirichlet(lambda x, y, z=0.0: 1.0 + 0.2 * x)
+    bcb = pj.BorderConditions({k: pj.Dirichlet(0.2) for k in ("left", "right", "top", "bottom")})
+    T0 = np.random.default_rng(9).random(2 * M)
+    out = []
+    for keep in (True, False):
+        cap0 = pj.Capacity(body, pj.SpaceTimeMesh(mesh, [0.0, dt]))
+        ph = pj.Phase(cap0, pj.DiffusionOps(cap0), f, 1.0)
+        s = pj.MovingDiffusionUnsteadyMono(ph, bcb, bc, dt, T0, mesh, "CN")
+        pj.solve_MovingDiffusionUnsteadyMono_b(s, ph, body, dt, 0.0, 3.5 * dt, bcb, bc, mesh, "CN", method="bicgstab", save_states=keep)
+        assert s.unconverged == 0 and len(s.states) == (5 if keep else 1)
+        out.append(s.states[-1])
+    assert np.array_equal(out[0], out[1])
