@@ -826,6 +826,7 @@ static int32_t create_moving(pg_capacity* c, pg_diffops* o, const pg_bc_desc* bc
   }
   s->bc_i.value_array = nullptr;
   s->init_from = prev;
+  s->A_ctor.want_units = false;
   setup_common(s, borders, nborders, T_prev);
   *out = guard.release();
   PG_API_END

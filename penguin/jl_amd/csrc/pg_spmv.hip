@@ -1015,7 +1015,8 @@ void build_slices(CsrMatrix& A, const int* rp) {
     std::vector<MRun> runs;     // U runs of 2-D / 3-D stencil rows: candidates for marching units
     i64 rows_u = 0, rows_p = 0, nnz_p = 0;
   };
-  static const bool march_on = getenv("PG_SPMV_MARCH") ? atoi(getenv("PG_SPMV_MARCH")) != 0 : true;
+  static const bool march_env = getenv("PG_SPMV_MARCH") ? atoi(getenv("PG_SPMV_MARCH")) != 0 : true;
+  const bool march_on = march_env && A.want_units;
   auto classify = [&](i64 lo, i64 hi, Part& out) {
     auto emit = [&](int type, i64 a, i64 b, int cnt) {
       if (march_on && type == SL_U && (cnt == 5 || cnt == 7)) {

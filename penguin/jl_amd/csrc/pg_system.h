@@ -62,6 +62,7 @@ struct CsrMatrix {
   // stencil rows; these rows are in no slice
   DevBuf<int> mrec;
   i64 nunits = 0, rows_m = 0;
+  bool want_units = true;   // false: a system solved once (a slab of the moving solver): planning the units costs more than they save
   i64 nslices = 0;
   i64 nslices_int = 0;   // slices [0, nslices_int) reference no ghost column (computable before the halo of x has landed)
   DevBuf<unsigned char> rowflags;   // k_row_same flags the slices were cut from (structure reuse, assemble_csr_like)
