@@ -63,7 +63,9 @@ AsyncAllocScope::~AsyncAllocScope() { --t_async_scope; }
 void* dev_alloc(size_t bytes) {
   void* p = nullptr;
   Context& c = ctx();
-  if ((t_async_scope > 0 || async_everywhere()) && c.inited && c.stream && !c.local) {
+  // (buffers of a GiB and more go the ordinary way: a 512^3 run with every allocation in the pool aborted inside the runtime
+  //  at its first > 2 GiB request)
+  if ((t_async_scope > 0 || async_everywhere()) && c.inited && c.stream && !c.local && bytes < (size_t(1) << 30)) {
     static bool pool_set = false;
     if (!pool_set) {
       hipMemPool_t pool;
