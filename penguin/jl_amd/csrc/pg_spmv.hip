@@ -499,7 +499,8 @@ __device__ __forceinline__ double march_plane(const double (&c)[CNT], int rng, i
     d2u_t out;
     out.x = s1; out.y = s2;
     // y leaves with the stream hint: fewer dirty lines for the end-of-kernel write-back, which sits between every two
-    // dependent launches of the loop (55.3 -> 52.6 µs per back-to-back launch at 512^3; dbg bit 2048: plain stores)
+    // dependent launches of the loop (55.3 -> 52.6 µs per back-to-back launch at 512^3 on one box, within the noise on another; system-scope write-through
+    // stores, `sc0 sc1`, double the launch; dbg bit 2048: plain stores)
     if (!(dbg & 2048)) __builtin_nontemporal_store(out, reinterpret_cast<d2u_t*>(yrow));
     else *reinterpret_cast<d2u_t*>(yrow) = out;
   } else if (v1) {
