@@ -57,3 +57,21 @@ def test_heat2d_disc_order_of_convergence(pj, tmp_path):
     assert all(p > 0.9 for p in res["pair_order_all"][1:])                   # BE with Δt ∝ h²: first order in time = second in h
     assert res["err_vals"][-1] < res["err_vals"][0] / 4.0
     _check_csvs(res, ["nx", "ny"])
+
+
+def test_moving_disc_convergence_benchmark(pj, tmp_path):
+    """benchmark/Heat_2d_moving.jl through the HIP moving path (oscillating disc, manufactured solution, BE, Δt = ½h², meshes
+    8 .. 64): literally -- initial state sampled at the NODES, error at Tend although the loop overshoots it -- the fitted orders
+    stay above 1 (the benchmark's own O(h) artefacts dominate as h falls); with the state sampled where the unknowns live and
+    the error taken at the time reached, the space-time capacities and the moving blocks are second-order accurate."""
+    import csv
+    from penguin.jl_amd import convergence as cv
+
+    lit = cv.run_mesh_convergence_moving([8, 16, 32, 64], output_dir=str(tmp_path))
+    assert lit["orders"]["all"] > 1.0 and lit["orders"]["cut"] > 1.5
+    rows = list(csv.DictReader(open(tmp_path / lit["run_dir"].split("/")[-1] / "summary.csv")))
+    assert [int(r["nx"]) for r in rows] == [8, 16, 32, 64] and set(rows[0]) >= {"mesh_size", "dt", "global_error", "cut_error"}
+    rates = {r["parameter"]: float(r["value"]) for r in csv.DictReader(open(tmp_path / lit["run_dir"].split("/")[-1] / "convergence_rates.csv"))}
+    assert rates["p_global"] == round(lit["orders"]["all"], 2)
+    fixed = cv.run_mesh_convergence_moving([16, 32, 64, 128], literal=False)
+    assert fixed["orders"]["all"] > 1.8 and fixed["err_vals"][-1] < 1.5e-3
