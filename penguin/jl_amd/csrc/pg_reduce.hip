@@ -140,7 +140,9 @@ void build_gamma_elim(const CsrMatrix& A, const Numbering& nb, GammaElim& E) {
   if (!enabled || nb.K != 2 || A.n <= 0 || !A.rowptr.p) return;
   const i64 n = A.n, n_w = nb.cnt_own[0];
   if (n_w <= 0 || n_w >= n) return;
-  if ((cx.nranks > 1 || cx.comm) && A.halo_needed) return;      // ω rows may reference ghosts: prefixes would not do
+  // several ranks that exchange a halo: ω rows reference ghosts, prefixes would not do -- and the decision has to be the same
+  // on every rank (A.halo_needed is collective); one rank never has ghosts, with or without a communicator
+  if (cx.nranks > 1 && A.halo_needed) return;
   DevBuf<unsigned long long> bad(2);
   bad.zero();
   E.gdiag.alloc(n - n_w);
