@@ -1200,7 +1200,14 @@ int32_t pg_solver_time_spmv(pg_solver* s, int32_t which, int32_t reps, double* a
   const int sel = which & 1, mode = (which >> 4) & 7;   // bits 4-6: mode of the launch (0 plain, 1, 2, 3 fused dots, 4: 2x - Ax)
   PG_REQUIRE(mode <= 4, "pg_solver_time_spmv: unknown launch mode");
   if (sel == 1) PG_REQUIRE(s->have_run, "run matrix not assembled yet");
-  const CsrMatrix& A = sel == 0 ? s->A_ctor : run_matrix(s);
+  const CsrMatrix& Afull = sel == 0 ? s->A_ctor : run_matrix(s);
+  // bit 9: the matrix the warm loop iterates on (without the Dirichlet interface rows, pg_reduce.hip), built here if need be
+  GammaElim& E = (&Afull == &s->A_ctor) ? s->elim_ctor : s->elim_run;
+  if ((which & 512) && !E.tried) build_gamma_elim(Afull, s->nb, E);
+  const CsrMatrix& A = ((which & 512) && E.active) ? E.A : Afull;
+  // bit 10: chained launches, each reading what the one before wrote (two vectors in turn): the access pattern of a chain
+  // of lean launches in the loop
+  const bool chained = (which & 1024) != 0;
   hipStream_t st = ctx().stream;
   EventPair ev;
   KrylovWork& w = s->work;
@@ -1220,8 +1227,8 @@ int32_t pg_solver_time_spmv(pg_solver* s, int32_t which, int32_t reps, double* a
   }
   int it = 0;
   auto one = [&]() {
-    const double* xin = cold ? ring[it % RING].p : s->z.p;
-    double* yout = cold ? ring[(it + 3) % RING].p : s->y.p;
+    const double* xin = cold ? ring[it % RING].p : (chained && (it & 1) ? s->y.p : s->z.p);
+    double* yout = cold ? ring[(it + 3) % RING].p : (chained && (it & 1) ? s->z.p : s->y.p);
     const double* ax = cold ? ring[(it + 5) % RING].p : w.rhat.p;
     ++it;
     if (mode == 0) spmv(A, xin, yout, st);

@@ -47,6 +47,10 @@ for mode in modes:
     warm = ms.value
     L.check(lib.pg_solver_time_spmv(s._h, sel | (mode << 4) | 256, reps, C.byref(ms)))
     out.append(f"m{mode} warm {warm * 1e3:5.1f} cold {ms.value * 1e3:5.1f} us ({(info.spmv_bytes + extra) / ms.value / 1e6:5.0f} GB/s)")
+    if mode == 4:      # the loop's own matrix (Dirichlet interface rows left out), launches chained as in a polynomial chain
+        L.check(lib.pg_solver_time_spmv(s._h, sel | (mode << 4) | 512 | 1024, reps, C.byref(ms)))
+        li = s.system_info(6 + sel)
+        out.append(f"loop-matrix chained {ms.value * 1e3:5.1f} us ({li.spmv_bytes / 1e6:.1f} MB)")
 if not broken:
     L.check(lib.pg_set_profiling(1))
     L.check(lib.pg_solver_run(s._h, C.c_double(1e9), C.c_int32(1), C.byref(opts), 0, C.c_int64(10), 0, C.byref(run)))
