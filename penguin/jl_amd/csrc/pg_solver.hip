@@ -589,6 +589,7 @@ void ensure_run_matrix(pg_solver* s, int scheme) {
     return;
   }
   const SysParams P = make_params(s, scheme);
+  s->elim_run = GammaElim();        // (belongs to the matrix that is about to be replaced)
   assemble_csr_like(P, s->slab, s->nb, s->A_ctor, s->A_run);
   s->A_run.scheme = scheme;
   s->scheme_run = scheme;
