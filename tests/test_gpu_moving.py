@@ -235,3 +235,51 @@ def test_moving_states_handed_over_on_the_device(pj):
         assert s.unconverged == 0 and len(s.states) == (5 if keep else 1)
         out.append(s.states[-1])
     assert np.array_equal(out[0], out[1])
+
+
+@pytest.mark.parametrize("variant", ["hs_minus", "hs_complement", "ball_1d", "sqrt_from_zero", "on_nodes"])
+def test_spacetime_capacity_variants(pj, variant):
+    """Half space with the fluid on the other side / as a complement, a moving interval (1-D ball), the reference's own motion
+    `xf + c sqrt(t)` started at t = 0 (infinite interface speed at the slab's lower face: Γ only, everything else exact), and
+    an interface that sits exactly on mesh nodes at both time faces."""
+    import math
+    n, L = 40, 1.0
+    mesh, omesh = pj.Mesh((n,), (L,), (0.0,)), po.Mesh((n,), (L,), (0.0,))
+    h, t0, dt = L / n, 0.0, 0.01
+    if variant == "hs_minus":
+        pos, dpos = (lambda t: 0.62 - 0.8 * t), (lambda t: -0.8)
+        body, obody = pj.MovingHalfSpace(0, pos, -1.0, dposition=dpos), ost.MovingHalfSpace(0, pos, -1.0, dposition=dpos)
+    elif variant == "hs_complement":
+        pos, dpos = (lambda t: 0.33 + 0.5 * t), (lambda t: 0.5)
+        body = pj.MovingHalfSpace(0, pos, 1.0, complement=True, dposition=dpos)
+        obody = ost.MovingHalfSpace(0, pos, 1.0, complement=True, dposition=dpos)
+    elif variant == "ball_1d":
+        cen, rad = (lambda t: (0.48 + 0.6 * t,)), (lambda t: 0.2 + 0.3 * t)
+        body = pj.MovingSphere(cen, rad, dcenter=lambda t: (0.6,), dradius=lambda t: 0.3)
+        obody = ost.MovingBall(cen, rad, dcenter=lambda t: (0.6,), dradius=lambda t: 0.3)
+    elif variant == "sqrt_from_zero":
+        pos = lambda t: 0.01 + 1.0 * math.sqrt(t)                       # examples/1D/SolidMoving/MovingHeat.jl:16-18
+        dpos = lambda t: 0.5 / math.sqrt(t)
+        body, obody = pj.MovingHalfSpace(0, pos, 1.0, dposition=dpos), ost.MovingHalfSpace(0, pos, 1.0, dposition=dpos)
+    else:
+        x_a, x_b = float(omesh.nodes[0][12]), float(omesh.nodes[0][13])  # on a node at t0, on the next one at t0 + dt
+        pos, dpos = (lambda t: x_a + (x_b - x_a) * (t - t0) / dt), (lambda t: (x_b - x_a) / dt)
+        body, obody = pj.MovingHalfSpace(0, pos, 1.0, dposition=dpos), ost.MovingHalfSpace(0, pos, 1.0, dposition=dpos)
+    cap = pj.Capacity(body, pj.SpaceTimeMesh(mesh, [t0, t0 + dt]), time_panels=8, time_order=4)
+    same = ost.make_spacetime_capacity(obody, omesh, t0, t0 + dt, panels=8, order=4)
+    lay = ost.spatial_layer(same, omesh)
+    M = n + 1
+    assert np.array_equal(cap.cell_types, lay.cell_types)
+    assert np.max(np.abs(cap.V - lay.V)) <= 1e-13 * h * dt
+    assert np.max(np.abs(cap.Vn_1 - same.A[1][:M])) <= 1e-14 * h and np.max(np.abs(cap.Vn - same.A[1][M:])) <= 1e-14 * h
+    assert np.max(np.abs(cap.A[0] - lay.A[0])) <= 1e-13 * dt and np.max(np.abs(cap.B[0] - lay.B[0])) <= 1e-13 * dt
+    assert np.max(np.abs(cap.W[0] - lay.W[0])) <= 1e-8 * h * dt
+    assert np.max(np.abs(cap.Γ - lay.G)) <= 1e-12 * max(lay.G.max(), dt)
+    # total fluid measure of the slab: the time integral of the fluid length (closed form where the motion is linear)
+    if variant in ("hs_minus", "hs_complement", "on_nodes"):
+        lo_d, hi_d = float(omesh.nodes[0][0]), float(omesh.nodes[0][-1])
+        p0, p1 = pos(t0), pos(t0 + dt)
+        mean_pos = 0.5 * (p0 + p1)
+        fluid_right = (variant == "hs_minus") or (variant == "hs_complement")
+        exact = (hi_d - mean_pos) * dt if fluid_right else (mean_pos - lo_d) * dt
+        assert abs(cap.V.sum() - exact) <= 1e-14

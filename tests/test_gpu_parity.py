@@ -1196,3 +1196,23 @@ def test_dirichlet_interface_rows_are_solved_before_the_iteration(pj, kind):
     else:
         assert loop.nnz < full.nnz - full.n_gamma and loop.rows_irregular <= full.rows_irregular   # γ rows AND γ columns gone
         assert loop.spmv_bytes < full.spmv_bytes
+
+
+@pytest.mark.parametrize("N", [2, 3])
+def test_ellipsoid_degenerate_placements(pj, N):
+    """centre on a mesh node, semi-axes multiples of the spacing: the surface passes through nodes, touches cell faces and
+    runs through cell corners -- classification still bit for bit (compare-only on the scaled box), measures to rounding."""
+    from oracle.geometry import Ellipsoid
+    n, L = (16, 4.0) if N == 2 else (8, 2.0)
+    h = L / n
+    mesh, omesh = pj.Mesh((n,) * N, (L,) * N, (0.0,) * N), po.Mesh((n,) * N, (L,) * N, (0.0,) * N)
+    node = float(omesh.nodes[0][n // 2])
+    c = (node,) * N
+    ax = (4 * h, 2 * h, 3 * h)[:N]
+    for comp in (False, True):
+        cap = pj.Capacity(pj.Ellipsoid(c, ax, complement=comp), mesh)
+        ocap = po.make_capacity(Ellipsoid(c, ax, comp), omesh)
+        _caps_close(cap, ocap, N, h)
+    cap = pj.Capacity(pj.Ellipsoid(c, ax), mesh)
+    vol = np.pi * ax[0] * ax[1] if N == 2 else 4.0 / 3.0 * np.pi * ax[0] * ax[1] * ax[2]
+    assert abs(cap.V.sum() - vol) <= 1e-11 * vol
