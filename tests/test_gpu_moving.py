@@ -283,3 +283,93 @@ def test_spacetime_capacity_variants(pj, variant):
         fluid_right = (variant == "hs_minus") or (variant == "hs_complement")
         exact = (hi_d - mean_pos) * dt if fluid_right else (mean_pos - lo_d) * dt
         assert abs(cap.V.sum() - exact) <= 1e-14
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_moving_random_problems(pj, seed):
+    """seeded random moving problems (1-D half lines and intervals, 2-D discs inside / outside; BE / CN; Dirichlet / Robin
+    interface data; random border sets): 1 + 3 slabs against the literal oracle fed with the HIP capacities."""
+    import scipy.sparse.linalg as spla
+    rng = np.random.default_rng(2000 + seed)
+    N = 1 if seed % 3 == 0 else 2
+    n = int(rng.integers(14, 26)) if N == 1 else int(rng.integers(10, 18))
+    L, x0 = float(rng.uniform(1.0, 3.0)), float(rng.uniform(-1.0, 0.5))
+    mesh, omesh = pj.Mesh((n,) * N, (L,) * N, (x0,) * N), po.Mesh((n,) * N, (L,) * N, (x0,) * N)
+    h = L / n
+    dt = float(rng.uniform(0.3, 1.5)) * h * h
+    speed = float(rng.uniform(0.2, 0.9)) * h / dt                   # crosses most of a cell per slab: fresh / dead cells
+    comp = bool(rng.integers(0, 2))
+    if N == 1 and seed % 2 == 0:
+        p0, sgn = x0 + L * float(rng.uniform(0.3, 0.7)), float(rng.choice([-1.0, 1.0]))
+        v = speed * float(rng.choice([-1.0, 1.0]))
+        pos, dpos = (lambda t: p0 + v * t), (lambda t: v)
+        body, obody = pj.MovingHalfSpace(0, pos, sgn, complement=comp, dposition=dpos), ost.MovingHalfSpace(0, pos, sgn, comp, dposition=dpos)
+    else:
+        c0 = x0 + L * rng.uniform(0.4, 0.6, N)
+        vel = rng.uniform(-1, 1, N)
+        vel = vel / np.linalg.norm(vel) * speed * 0.5
+        r0, dr = L * float(rng.uniform(0.18, 0.28)), speed * 0.5 * float(rng.choice([-1.0, 1.0]))
+        cen, rad = (lambda t: tuple(c0 + vel * t)), (lambda t: r0 + dr * t)
+        body = pj.MovingSphere(cen, rad, comp, dcenter=lambda t: tuple(vel), dradius=lambda t: dr)
+        obody = ost.MovingBall(cen, rad, comp, dcenter=lambda t: tuple(vel), dradius=lambda t: dr)
+    scheme = "CN" if rng.integers(0, 2) else "BE"
+    kind = int(rng.integers(0, 3))
+    a, b, c = rng.uniform(0.2, 1.0, 3)
+    g = lambda x, y, z=0.0: a + b * x + c * y
+    if kind == 0:
+        bc, obc = pj.Dirichlet(g), po.Dirichlet(g)
+    elif kind == 1:
+        bc, obc = pj.Robin(1.0, 0.3, g), po.Robin(1.0, 0.3, g)
+    else:      # (pure Neumann data on the tiny fresh cells of a slab make the reference's system singular to working precision)
+        bc, obc = pj.Robin(0.6, 1.0, g), po.Robin(0.6, 1.0, g)
+    keys = [k for k in (("bottom", "top") if N == 1 else ("left", "right", "top", "bottom")) if rng.random() < 0.7]
+    bval = lambda *p: 0.3 + 0.2 * p[-1]
+    bcb, obcb = pj.BorderConditions({k: pj.Dirichlet(bval) for k in keys}), po.BorderConditions({k: po.Dirichlet(bval) for k in keys})
+    f = lambda x, y, z, t: 0.1 + 0.3 * x + t
+    D = lambda x, y, z: 1.0 + 0.2 * x * x
+    M = int(np.prod(omesh.ext))
+    T0 = rng.random(2 * M)
+    cap0 = pj.Capacity(body, pj.SpaceTimeMesh(mesh, [0.0, dt]))
+    ph = pj.Phase(cap0, pj.DiffusionOps(cap0), f, D)
+    s = pj.MovingDiffusionUnsteadyMono(ph, bcb, bc, dt, T0, mesh, scheme)
+    pj.solve_MovingDiffusionUnsteadyMono_b(s, ph, body, dt, 0.0, 2.5 * dt, bcb, bc, mesh, scheme, method="bicgstab", reltol=1e-14)
+    assert s.unconverged == 0 and len(s.states) == 4
+    ocap0 = _oracle_cap(cap0, omesh, 0.0, dt, obody)
+    so = ost.MovingDiffusionUnsteadyMono(po.Phase(ocap0, po.make_diffusion_ops(ocap0), f, D), obcb, obc, dt, T0, omesh, scheme)
+    t, sens = 0.0, []
+
+    systems = []
+
+    def solve_and_probe():
+        po.solve_system(so)
+        so.states.append(so.x)
+        A, bb = so.last_A_reduced, so.last_b_reduced
+        systems.append((A, bb, so.last_idx))
+        Ap = A.copy()
+        Ap.data = Ap.data * (1.0 + 2.2e-16 * np.random.default_rng(1).standard_normal(len(Ap.data)))
+        sens.append(rel_l2(spla.spsolve(Ap.tocsc(), bb), spla.spsolve(A.tocsc(), bb)))
+
+    solve_and_probe()
+    while t < 2.5 * dt:
+        t += dt
+        ocap = _oracle_cap(pj.Capacity(body, pj.SpaceTimeMesh(mesh, [t, t + dt])), omesh, t, t + dt, obody)
+        oop = po.make_diffusion_ops(ocap)
+        so.A = ost.A_mono_unstead_diff_moving(oop, ocap, D, obc, scheme)
+        so.b = ost.b_mono_unstead_diff_moving(oop, ocap, D, f, obc, so.states[-1], dt, t, scheme)
+        so.A, so.b = po.BC_border_mono(so.A, so.b, obcb, omesh, t=t)
+        solve_and_probe()
+    for k, (x, xo) in enumerate(zip(s.states, so.states)):
+        assert np.array_equal(np.flatnonzero(x != 0.0), np.flatnonzero(xo != 0.0)), f"active set of state {k}"
+        tol = max(TOL_T, 50.0 * max(sens[: k + 1]))
+        if tol < 1e-7:
+            assert rel_l2(x, xo) <= tol, f"state {k}: {rel_l2(x, xo):.2e} (bar {tol:.1e})"
+        else:
+            # an isolated sliver cell with Robin data (all its faces closed) leaves the reference's system singular to working
+            # precision: its own direct solution is not determined; the HIP state must still SOLVE that system -- componentwise
+            # backward error of the oracle's matrix and right-hand side (built from the previous ORACLE state, which is why this
+            # ends the comparison of the run)
+            A, bb, idx = systems[k]
+            xr = x[idx]
+            berr = np.abs(A @ xr - bb) / (abs(A) @ np.abs(xr) + np.abs(bb) + 1e-300)
+            assert berr.max() <= 1e-9, f"state {k}: backward error {berr.max():.2e}"
+            break
