@@ -101,10 +101,15 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_s(i64 n, const double* __restric
 }
 
 // the half step accepted (PH_BICG_S): x += αp, r = s stands, the iteration counts, done
-__global__ __launch_bounds__(BLOCK) void k_bicg_half(i64 n, double* sc, const double* __restrict__ p, double* __restrict__ x) {
+// fresh != 0: x is the accumulated solution of the preconditioned system, which starts at zero and has not been written yet
+// in the first iteration -- assigned instead of read (its memset and its first read are saved)
+__global__ __launch_bounds__(BLOCK) void k_bicg_half(i64 n, double* sc, const double* __restrict__ p, double* __restrict__ x,
+                                                     int fresh) {
   if (sc[S_DONE] != 0.0 || sc[S_HALF] == 0.0) return;
   const double alpha = sc[S_ALPHA];
-  for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) x[i] += alpha * p[i];
+  const bool first = fresh != 0 && sc[S_ITERS] == 0.0;
+  for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK)
+    x[i] = (first ? 0.0 : x[i]) + alpha * p[i];
 }
 // (separate launch: every block of k_bicg_half must have read the flags before they change)
 __global__ void k_bicg_half_done(double* sc) {
@@ -125,15 +130,16 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_xrp(i64 n, double* sc, const dou
                                                     const double* __restrict__ v, double* __restrict__ x,
                                                     double* __restrict__ r, double* __restrict__ p,
                                                     double* __restrict__ rhat, double* __restrict__ partials,
-                                                    const double* __restrict__ ds) {
+                                                    const double* __restrict__ ds, int fresh) {
   __shared__ double s_red[BLOCK / 64];
   if (sc[S_DONE] != 0.0) return;
   const double alpha = sc[S_ALPHA], omega = sc[S_OMEGA], beta = sc[S_BETA];
   const bool restart = sc[S_RESTART] != 0.0;
+  const bool first = fresh != 0 && sc[S_ITERS] == 0.0;   // (see k_bicg_half)
   double a0 = 0.0, aw = 0.0;
   for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) {
     const double si = r[i], pi = p[i];
-    const double xi = (NTV ? __builtin_nontemporal_load(x + i) : x[i]) + alpha * pi + omega * si;
+    const double xi = (first ? 0.0 : (NTV ? __builtin_nontemporal_load(x + i) : x[i])) + alpha * pi + omega * si;
     if (NTV) __builtin_nontemporal_store(xi, x + i); else x[i] = xi;
     const double ri = si - omega * (NTV ? __builtin_nontemporal_load(t + i) : t[i]);
     r[i] = ri;
@@ -420,7 +426,7 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
       w.ya.alloc(nvec); w.wa.alloc(nvec); w.wb.alloc(nvec);
       w.ya.zero(); w.wa.zero(); w.wb.zero();
     }
-    PG_HIP(hipMemsetAsync(w.ya.p, 0, sizeof(double) * (size_t)nvec, st));   // y0 = 0: x = x0 + q(Â) y
+    // y0 = 0 (x = x0 + q(Â) y): not written here -- the first update of y assigns (k_bicg_half / k_bicg_xrp, `fresh`)
   }
   double* const xit = poly ? w.ya.p : x;   // what the iteration updates
   // convergence is also tested after the first half of an iteration when a half costs several products (the test itself
@@ -489,14 +495,14 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_s<false>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p, (const double*)A.ds.p);
         if (half_test) {   // does s already meet the tolerance?  then x += αp and stop: the second half is 1 + m launches
           finalize(PH_BICG_S, 1, w, st, true, 4);
-          hipLaunchKernelGGL(k_bicg_half, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, (const double*)w.p.p, xit);
+          hipLaunchKernelGGL(k_bicg_half, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, (const double*)w.p.p, xit, poly ? 1 : 0);
           hipLaunchKernelGGL(k_bicg_half_done, dim3(1), dim3(1), 0, st, w.sc.p);
         }
         apply(w.r.p, w.t.p, PH_BICG_2, 5);     // t = C s (r holds s), (t,s), (t,t), (r̂,t); then ω, ρ, β / restart
         if (ntv) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_xrp<true>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.t.p, w.v.p, xit, w.r.p,
-                                    w.p.p, w.rhat.p, w.partials.p, (const double*)A.ds.p);
+                                    w.p.p, w.rhat.p, w.partials.p, (const double*)A.ds.p, poly ? 1 : 0);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_xrp<false>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.t.p, w.v.p, xit, w.r.p,
-                                w.p.p, w.rhat.p, w.partials.p, (const double*)A.ds.p);
+                                w.p.p, w.rhat.p, w.partials.p, (const double*)A.ds.p, poly ? 1 : 0);
       } else {
         timer.begin(st, launched + it);
         spmv_with_halo(2, A, nb, slab, w.p.p, w.v.p, nullptr, w.partials.p, w.sc.p, G, st);   // v = A p ; (v.p), (v.v)
@@ -518,7 +524,7 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
     // from the iterate reached (the matrix keeps the verdict)
     if (!done && poly && launched >= poly_give_up) { poly_failed = true; done = true; }
   }
-  if (poly) {
+  if (poly && w.h_sc[S_ITERS] > 0.0) {      // (no iteration: the start already met the tolerance, y was never written)
     // x = x0 + q(Â) y,  q(Â) y = Σ_k τ_k w_k,  w_0 = y, w_(k+1) = (I - τ_k Â) w_k  -- evaluated by Horner's rule from the inside,
     //   u_(m-1) = τ_(m-1) y,   u_k = τ_k y + (I - τ_k Â) u_(k+1),   q(Â) y = u_0,
     // in the scaled variable ũ_k = u_k / τ_k so that a launch needs no scaled copy of y:
