@@ -89,8 +89,9 @@ void comm_allreduce_sum_u64(unsigned long long* dev, i64 count, hipStream_t st);
 // Allocation: hipMalloc / hipFree, or the stream-ordered allocator on the compute stream (a pool that is never trimmed).
 // hipMalloc / hipFree synchronise the device, and a caller that rebuilds capacities and systems every time step -- the
 // moving-body solver: ~60 buffers per slab -- pays that ~120 times per step (17 -> 5 ms per slab at 1024²).  The pool serves
-// the allocations made inside an AsyncAllocScope (the moving path's entry points) or all of them with PG_ASYNC_ALLOC=1 (opt-in:
-// one 512^3 test run aborted inside the runtime with it); pointers remember where they came from.
+// the allocations below 64 MB made inside an AsyncAllocScope (the moving path's entry points), or everywhere with
+// PG_ASYNC_ALLOC=1 (opt-in); larger blocks misbehave in this runtime's pool (pg_context.hip, pool_limit); pointers remember
+// where they came from.
 void* dev_alloc(size_t bytes);   // pg_context.hip
 void dev_free(void* p);
 struct AsyncAllocScope {

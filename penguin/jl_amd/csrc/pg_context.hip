@@ -52,9 +52,18 @@ namespace {
 thread_local int t_async_scope = 0;
 std::mutex g_pool_mutex;
 std::unordered_set<void*> g_pool_ptrs;
-bool async_everywhere() {
-  static const bool on = getenv("PG_ASYNC_ALLOC") ? atoi(getenv("PG_ASYNC_ALLOC")) != 0 : false;
-  return on;
+int async_mode() {      // PG_ASYNC_ALLOC: 1 every allocation from the pool, -1 none (not even inside an AsyncAllocScope)
+  static const int m = getenv("PG_ASYNC_ALLOC") ? atoi(getenv("PG_ASYNC_ALLOC")) : 0;
+  return m;
+}
+bool async_everywhere() { return async_mode() > 0; }
+// Requests of this size and more go the ordinary way (PG_POOL_LIMIT_MB, default 64).  Measured on this runtime: with blocks of
+// 370 MB in the pool (a 3072² slab) buffers came back with stale zeros in them and slabs took 100+ ms, with > 2 GiB requests
+// the process aborted; up to 165 MB (2048²) everything was fine.  The gain is in the dozens of SMALL buffers a slab creates
+// and frees (lists, counters, per-row flags): 64 MB keeps all of it (1024²: 5.5 ms per slab against 17 without the pool).
+size_t pool_limit() {
+  static const size_t lim = (size_t)(getenv("PG_POOL_LIMIT_MB") ? atoi(getenv("PG_POOL_LIMIT_MB")) : 64) << 20;
+  return lim;
 }
 }  // namespace
 AsyncAllocScope::AsyncAllocScope() { ++t_async_scope; }
@@ -63,9 +72,7 @@ AsyncAllocScope::~AsyncAllocScope() { --t_async_scope; }
 void* dev_alloc(size_t bytes) {
   void* p = nullptr;
   Context& c = ctx();
-  // (buffers of a GiB and more go the ordinary way: a 512^3 run with every allocation in the pool aborted inside the runtime
-  //  at its first > 2 GiB request)
-  if ((t_async_scope > 0 || async_everywhere()) && c.inited && c.stream && !c.local && bytes < (size_t(1) << 30)) {
+  if ((t_async_scope > 0 || async_everywhere()) && async_mode() >= 0 && c.inited && c.stream && !c.local && bytes < pool_limit()) {
     static bool pool_set = false;
     if (!pool_set) {
       hipMemPool_t pool;

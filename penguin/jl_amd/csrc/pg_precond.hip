@@ -484,6 +484,22 @@ void decide_poly(CsrMatrix& A) {
   worst.download(&h, 1);
   A.gersh = h;
   A.poly_ok = h < 0.95;
+  if (getenv("PG_DEBUG") && !(h < 1e300) && A.n > 0) {   // developer aid: the first rows whose disc is not finite
+    std::vector<int> rp(A.n + 1), cl(A.nnz);
+    std::vector<double> vl(A.nnz), dsv(A.ds.n);
+    A.rowptr.download(rp.data(), A.n + 1); A.col.download(cl.data(), A.nnz); A.val.download(vl.data(), A.nnz);
+    A.ds.download(dsv.data(), A.ds.n);
+    int shown = 0;
+    for (i64 r = 0; r < A.n && shown < 4; ++r) {
+      bool bad = !(dsv[r] > 0.0) || !(dsv[r] < 1e300);
+      for (int k = rp[r]; k < rp[r + 1]; ++k) bad = bad || !(std::fabs(vl[k]) < 1e300);
+      if (!bad) continue;
+      ++shown;
+      fprintf(stderr, "[pg_precond] row %lld: ds %.3e entries", (long long)r, dsv[r]);
+      for (int k = rp[r]; k < rp[r + 1]; ++k) fprintf(stderr, " (%d: %.3e, ds %.3e)", cl[k], vl[k], dsv[cl[k]]);
+      fprintf(stderr, "\n");
+    }
+  }
   if (getenv("PG_DEBUG"))
     fprintf(stderr, "[pg_precond] rank %d: largest Gershgorin radius %.4f => Neumann preconditioner %s\n", ctx().rank, h,
             A.poly_ok ? "admissible" : "not used");
