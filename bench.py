@@ -189,7 +189,7 @@ def main() -> None:
     n_full = n_rows
     reduced = sliced and int(loopinfo.spmv_bytes) != int(sysinfo.spmv_bytes)
     if reduced:
-        n_rows = int(sysinfo.n_omega)
+        n_rows = int(loopinfo.rows_matrix)
     b_fmt = int(loopinfo.spmv_bytes) if sliced else b_csr
     m = int(run.poly_degree)                           # products per application of the preconditioned operator (0: plain)
     # launches timed in the loop: LEAN (a factor of the preconditioner polynomial: x in, y out, the matrix) and CLOSING
@@ -278,7 +278,7 @@ def main() -> None:
             "rows_uniform": int(loopinfo.rows_uniform), "rows_pattern": int(loopinfo.rows_pattern),
             "rows_irregular": int(loopinfo.rows_irregular), "slices": int(loopinfo.spmv_slices),
             "rows_in_the_iteration": n_rows, "nnz_in_the_iteration": int(loopinfo.nnz),
-            "dirichlet_interface_rows_solved_before_the_iteration": n_full - n_rows,
+            "rows_alone_on_their_diagonal_solved_before_the_iteration": n_full - n_rows,
             "full_matrix": {"rows": n_full, "nnz": nnz, "bytes_per_launch": b_fmt_full, "rows_irregular": int(sysinfo.rows_irregular)},
         },
     }

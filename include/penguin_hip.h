@@ -138,6 +138,8 @@ typedef struct {
   double gershgorin;      /* the largest Gershgorin radius that decision rests on (all ranks)     */
   int64_t spmv_units;     /* marching units (DESIGN.md "SpMV"): <= 11 planes x 126 uniform stencil rows each      */
   int64_t rows_marched;   /* rows covered by them (counted in rows_uniform too; they are in no slice)             */
+  int64_t rows_matrix;    /* rows of the matrix the other SpMV figures describe: n_own, or fewer for which = 6 / 7 (the
+                             warm loop's matrix without the rows that are alone on their diagonal)                   */
 } pg_system_info;
 
 /* ---- library / device -------------------------------------------------------------------- */

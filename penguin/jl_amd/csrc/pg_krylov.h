@@ -17,6 +17,9 @@ struct KrylovWork {
   // adapt_m products per application, adapt_h applications expected
   const void* adapt_matrix = nullptr;
   int adapt_m = 0, adapt_h = 0;
+  // set by the caller around one krylov_solve: the system is a compact image of the caller's (pg_reduce.hip, DiagElim) and
+  // x is the caller's FULL vector -- the solution update x += q(Â)y lands at x[scatter[i]].  Needs the polynomial path.
+  const int* scatter = nullptr;
   // polynomial right preconditioner (pg_krylov.hip), n_vec each, on first use: the accumulated solution of the
   // preconditioned system (x = x0 + q(Â) ya) and the two work vectors the chain of products alternates between
   DevBuf<double> ya, wa, wb;
@@ -57,6 +60,9 @@ void spmv_halo(const CsrMatrix& A, const Numbering& nb, const Slab& slab, double
 void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, const double* b, double* x,
                   KrylovWork& w, const pg_krylov_opts& opts, SolveStats& stats, const double* x0 = nullptr,
                   const double* Ax0 = nullptr, bool preinit = false);
+
+// will krylov_solve(A, ..., opts) run BiCGStab right-preconditioned with the polynomial (the y-space iteration)?
+bool krylov_uses_polynomial(const CsrMatrix& A, const pg_krylov_opts& opts);
 
 // restarted GMRES (pg_gmres.hip): zero initial guess, x (n_vec, overwritten) = A^{-1} b
 void gmres_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, const double* b, double* x, KrylovWork& w,

@@ -211,6 +211,11 @@ __global__ __launch_bounds__(BLOCK) void k_cg_p(i64 n, const double* __restrict_
 }
 
 // x += a w  (last term of x = x0 + q(Â) y)
+__global__ __launch_bounds__(BLOCK) void k_axpy_scatter(i64 n, double a, const double* __restrict__ w, double* __restrict__ x,
+                                                        const int* __restrict__ map) {
+  for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) x[map[i]] += a * w[i];
+}
+
 __global__ __launch_bounds__(BLOCK) void k_axpy(i64 n, double a, const double* __restrict__ w, double* __restrict__ x) {
   for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) x[i] += a * w[i];
 }
@@ -374,6 +379,14 @@ void spmv(const CsrMatrix& A, const double* x, double* y, hipStream_t st) {
   PG_HIP(hipGetLastError());
 }
 
+bool krylov_uses_polynomial(const CsrMatrix& A, const pg_krylov_opts& opts) {
+  static const bool poly_env = getenv("PG_POLY") ? atoi(getenv("PG_POLY")) != 0 : true;
+  static const int degree_env = getenv("PG_POLY_DEGREE") ? atoi(getenv("PG_POLY_DEGREE")) : 6;
+  if (!(poly_env && opts.precond >= 0 && opts.method == PG_METHOD_BICGSTAB && A.poly_ok && spmv_supports_preconditioner_product() && A.n > 0))
+    return false;
+  return (opts.precond > 0 ? opts.precond : degree_env) >= 2;
+}
+
 void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, const double* b, double* x, KrylovWork& w,
                   const pg_krylov_opts& opts, SolveStats& stats, const double* x0, const double* Ax0, bool preinit) {
   Context& cx = ctx();
@@ -415,6 +428,7 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
   if (m < 2) m = 0;
   const bool poly = m > 0;
   stats.poly_degree = m;
+  PG_REQUIRE(!w.scatter || (poly && preinit), "a compact system needs the polynomial path and a prepared start");
   double tau[16];
   if (poly) {
     // 1 / Chebyshev nodes of [1 - g, 1 + g], the largest and the smallest remaining root in turn
@@ -532,7 +546,8 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
     // m - 1 launches of three vector streams each (the accumulating form, mode 7, read and wrote x as a fourth in every
     // launch); the factors are applied in the reverse of the chain's order, which alternates between the two ends of the
     // spectrum either way.  (No done flag here: it is set.)
-    static const bool horner = getenv("PG_RECOVERY_HORNER") ? atoi(getenv("PG_RECOVERY_HORNER")) != 0 : true;
+    static const bool horner_env = getenv("PG_RECOVERY_HORNER") ? atoi(getenv("PG_RECOVERY_HORNER")) != 0 : true;
+    const bool horner = horner_env || w.scatter != nullptr;
     double* src = w.ya.p;
     if (horner) {
       for (int k = m - 2; k >= 0; --k) {
@@ -543,7 +558,8 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
         spmv_with_halo(8, A, nb, slab, src, dst, nullptr, nullptr, nullptr, G, st, &f);
         src = dst;
       }
-      hipLaunchKernelGGL(k_axpy, dim3(G), dim3(BLOCK), 0, st, n, tau[0], (const double*)src, x);
+      if (w.scatter) hipLaunchKernelGGL(k_axpy_scatter, dim3(G), dim3(BLOCK), 0, st, n, tau[0], (const double*)src, x, w.scatter);
+      else hipLaunchKernelGGL(k_axpy, dim3(G), dim3(BLOCK), 0, st, n, tau[0], (const double*)src, x);
     } else {
       for (int k = 0; k + 1 < m; ++k) {
         double* dst = (k & 1) ? w.wb.p : w.wa.p;
@@ -555,6 +571,14 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
       hipLaunchKernelGGL(k_axpy, dim3(G), dim3(BLOCK), 0, st, n, tau[m - 1], (const double*)src, x);
     }
     PG_HIP(hipGetLastError());
+    if (poly_failed && w.scatter) {      // (the caller solves again on its full system, which has a right-hand side vector)
+      const_cast<CsrMatrix&>(A).poly_ok = false;
+      stats.iters = launched;
+      stats.converged = 0;
+      stats.poly_degree = -1;
+      timer.collect(stats, launched, false);
+      return;
+    }
     if (poly_failed) {
       if (getenv("PG_DEBUG")) fprintf(stderr, "[pg_krylov] polynomial preconditioner (m = %d) stagnated after %d iterations: plain iteration\n", m, launched);
       const_cast<CsrMatrix&>(A).poly_ok = false;

@@ -129,6 +129,106 @@ __global__ __launch_bounds__(BLOCK) void k_renorm(i64 n_w, const int* __restrict
   if (threadIdx.x == 0) partials[2 * (size_t)gridDim.x + blockIdx.x] = tw;
 }
 
+
+// ---- compact variant: every row that is alone on its diagonal ------------------------------------------------------
+__global__ void k_diag_rows(i64 n, const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val,
+                            int* __restrict__ is_e, int* __restrict__ is_r) {
+  for (i64 r = blockIdx.x * (i64)blockDim.x + threadIdx.x; r < n; r += (i64)gridDim.x * blockDim.x) {
+    const int a = rowptr[r], b = rowptr[r + 1];
+    const int e = (b - a == 1 && col[a] == (int)r && fabs(val[a] - 1.0) <= 1e-12) ? 1 : 0;
+    is_e[r] = e;
+    is_r[r] = 1 - e;
+  }
+}
+
+__global__ void k_maps(i64 n, const int* __restrict__ is_e, const int* __restrict__ pos_e, const int* __restrict__ pos_r,
+                       const int* __restrict__ rowptr, const double* __restrict__ val, const double* __restrict__ ds, int* cmap,
+                       int* rlist, int* elist, double* gdiag, double* ds_c) {
+  for (i64 r = blockIdx.x * (i64)blockDim.x + threadIdx.x; r < n; r += (i64)gridDim.x * blockDim.x) {
+    if (is_e[r]) {
+      cmap[r] = -1;
+      elist[pos_e[r]] = (int)r;
+      gdiag[pos_e[r]] = val[rowptr[r]];
+    } else {
+      cmap[r] = pos_r[r];
+      rlist[pos_r[r]] = (int)r;
+      ds_c[pos_r[r]] = ds[r];
+    }
+  }
+}
+
+// per remaining row: entries kept, entries of the coupling block, ghost references
+__global__ void k_c_count(i64 n_c, i64 n, const int* __restrict__ rlist, const int* __restrict__ cmap, const int* __restrict__ rowptr,
+                          const int* __restrict__ col, int* cnt_c, int* has_g, int* cnt_g, unsigned long long* ghosts) {
+  unsigned long long gh = 0;
+  for (i64 c = blockIdx.x * (i64)blockDim.x + threadIdx.x; c < n_c; c += (i64)gridDim.x * blockDim.x) {
+    const int r = rlist[c];
+    int cw = 0, cg = 0;
+    for (int e = rowptr[r]; e < rowptr[r + 1]; ++e) {
+      const int j = col[e];
+      if (j >= n) ++gh;
+      else if (cmap[j] >= 0) ++cw;
+      else ++cg;
+    }
+    cnt_c[c] = cw; cnt_g[c] = cg; has_g[c] = cg > 0 ? 1 : 0;
+  }
+  if (gh) atomicAdd(ghosts, gh);
+}
+
+__global__ void k_c_fill(i64 n_c, const int* __restrict__ rlist, const int* __restrict__ cmap, const int* __restrict__ rowptr,
+                         const int* __restrict__ col, const double* __restrict__ val, const int* __restrict__ rp_c, int* col_c,
+                         double* val_c, const int* __restrict__ has_g, const int* __restrict__ pos_g, const int* __restrict__ cnt_g,
+                         int* wg_rows, int* wg_cnt) {
+  for (i64 c = blockIdx.x * (i64)blockDim.x + threadIdx.x; c < n_c; c += (i64)gridDim.x * blockDim.x) {
+    const int r = rlist[c];
+    int at = rp_c[c];
+    for (int e = rowptr[r]; e < rowptr[r + 1]; ++e) {
+      const int j = cmap[col[e]];
+      if (j >= 0) { col_c[at] = j; val_c[at] = val[e]; ++at; }
+    }
+    if (has_g[c]) { wg_rows[pos_g[c]] = r; wg_cnt[pos_g[c]] = cnt_g[c]; }
+  }
+}
+
+__global__ void k_c_coupling(i64 n_wg, const int* __restrict__ wg_rows, const int* __restrict__ wg_ptr, const int* __restrict__ cmap,
+                             const int* __restrict__ pos_e, const int* __restrict__ rowptr, const int* __restrict__ col,
+                             const double* __restrict__ val, int* wg_col, double* wg_val) {
+  for (i64 q = blockIdx.x * (i64)blockDim.x + threadIdx.x; q < n_wg; q += (i64)gridDim.x * blockDim.x) {
+    const int r = wg_rows[q];
+    int at = wg_ptr[q];
+    for (int e = rowptr[r]; e < rowptr[r + 1]; ++e)
+      if (cmap[col[e]] < 0) { wg_col[at] = pos_e[col[e]]; wg_val[at] = val[e]; ++at; }
+  }
+}
+
+__global__ void k_e_snap(i64 n_e, const int* __restrict__ elist, const double* __restrict__ gdiag, double* __restrict__ x,
+                         const double* __restrict__ r_full, double* __restrict__ delta, int* flag) {
+  int f = 0;
+  for (i64 e = blockIdx.x * (i64)blockDim.x + threadIdx.x; e < n_e; e += (i64)gridDim.x * blockDim.x) {
+    const int i = elist[e];
+    const double d = r_full[i] / gdiag[e], xo = x[i];
+    delta[e] = d;
+    x[i] = xo + d;
+    if (fabs(d) > 1e-12 * fabs(xo)) f = 1;
+  }
+  if (f) atomicOr(flag, 1);
+}
+
+// coupled remaining rows (compact index cmap[wg_rows[q]]): r -= Â_RE δ, r̂ and p alike
+__global__ void k_c_couple(i64 n_wg, const int* __restrict__ wg_rows, const int* __restrict__ wg_ptr, const int* __restrict__ wg_col,
+                           const double* __restrict__ wg_val, const double* __restrict__ delta, const int* __restrict__ cmap,
+                           double* __restrict__ r, double* __restrict__ rhat, double* __restrict__ p) {
+  for (i64 q = blockIdx.x * (i64)blockDim.x + threadIdx.x; q < n_wg; q += (i64)gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int e = wg_ptr[q]; e < wg_ptr[q + 1]; ++e) s += wg_val[e] * delta[wg_col[e]];
+    if (s != 0.0) {
+      const int c = cmap[wg_rows[q]];
+      const double v = r[c] - s;
+      r[c] = v; rhat[c] = v; p[c] = v;
+    }
+  }
+}
+
 }  // namespace
 
 void build_gamma_elim(const CsrMatrix& A, const Numbering& nb, GammaElim& E) {
@@ -224,6 +324,100 @@ void gamma_fix(const GammaElim& E, double* x, double* r, double* rhat, double* p
     hipLaunchKernelGGL(k_gamma_couple, dim3(grid_for(E.n_wg, 256)), dim3(256), 0, st, E.n_wg, E.wg_rows.p, E.wg_ptr.p, E.wg_col.p,
                        E.wg_val.p, E.delta.p, r, rhat, p);
   hipLaunchKernelGGL(k_renorm, dim3(grid), dim3(BLOCK), 0, st, E.n_w, E.flag.p, r, E.A.ds.p, partials);
+  PG_HIP(hipGetLastError());
+}
+
+
+void build_diag_elim(const CsrMatrix& A, const Numbering& nb, DiagElim& E) {
+  E.tried = true;
+  E.active = false;
+  Context& cx = ctx();
+  hipStream_t st = cx.stream;
+  static const bool enabled = getenv("PG_DIAG_ELIM") ? atoi(getenv("PG_DIAG_ELIM")) != 0 : true;
+  if (!enabled || A.n <= 0 || !A.rowptr.p || !A.poly_ok) return;
+  if (cx.nranks > 1 && A.halo_needed) return;
+  const i64 n = A.n;
+  DevBuf<int> is_e(n + 1), is_r(n + 1), pos_e(n + 1), pos_r(n + 1), tot(2);
+  hipLaunchKernelGGL(k_diag_rows, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, n, A.rowptr.p, A.col.p, A.val.p, is_e.p, is_r.p);
+  scan_exclusive<int>(is_e.p, pos_e.p, n, tot.p, st);
+  scan_exclusive<int>(is_r.p, pos_r.p, n, tot.p + 1, st);
+  int ht[2];
+  tot.download(ht, 2);
+  const i64 n_e = ht[0], n_c = ht[1];
+  if (n_e * 50 < n || n_c <= 0) return;             // fewer than 2 % of the rows: not worth a second matrix
+  E.n = n; E.n_c = n_c; E.n_e = n_e;
+  E.cmap.alloc(n); E.rlist.alloc(n_c); E.elist.alloc(n_e); E.gdiag.alloc(n_e); E.delta.alloc(n_e); E.flag.alloc(1);
+  CsrMatrix& R = E.A;
+  R.n = n_c;
+  R.scheme = A.scheme;
+  R.ds.alloc(n_c);
+  hipLaunchKernelGGL(k_maps, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, n, is_e.p, pos_e.p, pos_r.p, A.rowptr.p, A.val.p, A.ds.p,
+                     E.cmap.p, E.rlist.p, E.elist.p, E.gdiag.p, R.ds.p);
+  DevBuf<int> cnt_c(n_c + 1), has_g(n_c + 1), cnt_g(n_c), pos_g(n_c + 1);
+  DevBuf<unsigned long long> ghosts(1);
+  ghosts.zero();
+  hipLaunchKernelGGL(k_c_count, dim3(grid_for(n_c, 256, 256 * 16)), dim3(256), 0, st, n_c, n, E.rlist.p, E.cmap.p, A.rowptr.p, A.col.p,
+                     cnt_c.p, has_g.p, cnt_g.p, ghosts.p);
+  PG_HIP(hipGetLastError());
+  unsigned long long hg = 0;
+  ghosts.download(&hg, 1);
+  if (hg != 0) return;
+  R.rowptr.alloc(n_c + 1);
+  scan_exclusive<int>(cnt_c.p, R.rowptr.p, n_c, R.rowptr.p + n_c, st);
+  scan_exclusive<int>(has_g.p, pos_g.p, n_c, tot.p, st);
+  int nnz = 0, n_wg = 0;
+  R.rowptr.download(&nnz, 1, n_c);
+  tot.download(&n_wg, 1);
+  R.nnz = nnz;
+  R.col.alloc(nnz + 8); R.val.alloc(nnz + 8);
+  R.col.zero(); R.val.zero();
+  E.n_wg = n_wg;
+  E.wg_rows.alloc(n_wg + 1);
+  DevBuf<int> wg_cnt(n_wg + 1);
+  hipLaunchKernelGGL(k_c_fill, dim3(grid_for(n_c, 256, 256 * 16)), dim3(256), 0, st, n_c, E.rlist.p, E.cmap.p, A.rowptr.p, A.col.p, A.val.p,
+                     R.rowptr.p, R.col.p, R.val.p, has_g.p, pos_g.p, cnt_g.p, E.wg_rows.p, wg_cnt.p);
+  PG_HIP(hipGetLastError());
+  E.wg_ptr.alloc(n_wg + 1);
+  int nnz_g = 0;
+  if (n_wg > 0) {
+    scan_exclusive<int>(wg_cnt.p, E.wg_ptr.p, n_wg, E.wg_ptr.p + n_wg, st);
+    E.wg_ptr.download(&nnz_g, 1, n_wg);
+  } else {
+    E.wg_ptr.zero();
+  }
+  E.wg_col.alloc(nnz_g + 1); E.wg_val.alloc(nnz_g + 1);
+  if (n_wg > 0)
+    hipLaunchKernelGGL(k_c_coupling, dim3(grid_for(n_wg, 256)), dim3(256), 0, st, (i64)n_wg, E.wg_rows.p, E.wg_ptr.p, E.cmap.p, pos_e.p,
+                       A.rowptr.p, A.col.p, A.val.p, E.wg_col.p, E.wg_val.p);
+  PG_HIP(hipGetLastError());
+  PG_HIP(hipStreamSynchronize(st));
+  R.halo_needed = false;
+  R.poly_ok = A.poly_ok;
+  R.gersh = A.gersh;
+  R.nnz_raw = nnz;
+  build_spmv_chunks(R);
+  E.nb = Numbering();
+  E.nb.K = 1;
+  E.nb.Mloc = nb.Mloc;
+  E.nb.n_own = n_c;
+  E.nb.n_ghost = 0;
+  E.nb.cnt_own[0] = n_c;
+  E.active = true;
+  if (getenv("PG_DEBUG"))
+    fprintf(stderr, "[pg_reduce] rows alone on their diagonal left out of the iteration: %lld of %lld rows (compact vectors), %lld of %lld entries; "
+            "coupling block %d rows, %d entries; irregular rows %lld -> %lld\n", (long long)n_e, (long long)n, (long long)(A.nnz - nnz),
+            (long long)A.nnz, n_wg, nnz_g, (long long)A.rows_g, (long long)R.rows_g);
+}
+
+void diag_fix(const DiagElim& E, double* x, double* r_full, double* r, double* rhat, double* p, double* partials, int grid,
+              hipStream_t st) {
+  PG_HIP(hipMemsetAsync(E.flag.p, 0, sizeof(int), st));
+  hipLaunchKernelGGL(k_e_snap, dim3(grid_for(E.n_e, 256)), dim3(256), 0, st, E.n_e, E.elist.p, E.gdiag.p, x, (const double*)r_full,
+                     E.delta.p, E.flag.p);
+  if (E.n_wg > 0)
+    hipLaunchKernelGGL(k_c_couple, dim3(grid_for(E.n_wg, 256)), dim3(256), 0, st, E.n_wg, E.wg_rows.p, E.wg_ptr.p, E.wg_col.p, E.wg_val.p,
+                       E.delta.p, E.cmap.p, r, rhat, p);
+  hipLaunchKernelGGL(k_renorm, dim3(grid), dim3(BLOCK), 0, st, E.n_c, E.flag.p, (const double*)r, E.A.ds.p, partials);
   PG_HIP(hipGetLastError());
 }
 

@@ -42,6 +42,7 @@ struct pg_solver {
   Numbering nb;
   CsrMatrix A_ctor, A_run;
   GammaElim elim_ctor, elim_run;   // the same matrices without the Dirichlet interface unknowns (pg_reduce.hip), on first use
+  DiagElim diag_ctor, diag_run;    // ... without any row that is alone on its diagonal, compact vectors (PG_DIAG_ELIM=1)
   bool have_run = false;
   int scheme_run = -1;
   // per-row data
@@ -279,6 +280,44 @@ __global__ __launch_bounds__(BLOCK) void k_rhs_init(i64 n, i64 nvec, int scheme,
           p[k] = 0.0;
         }
       }
+    }
+  }
+  const double t = block_sum(acc, s_red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+  const double tb = block_sum(accb, s_red);
+  if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = tb;
+  const double tw = block_sum(accw, s_red);
+  if (threadIdx.x == 0) partials[2 * (size_t)gridDim.x + blockIdx.x] = tw;
+}
+
+// k_rhs_init for a COMPACT loop system (pg_reduce.hip, DiagElim): cmap[i] >= 0: the row stays, r = r̂ = p go to that index of
+// the compact vectors and count in the start sums; cmap[i] < 0: the row is alone on its diagonal, its residual is kept at
+// r_e[i] (the snap needs it) and is left out of the sums.  b̂ is written for every row, (b̂,b̂)_W sums over all of them.
+__global__ __launch_bounds__(BLOCK) void k_rhs_init_c(i64 n, int scheme, const double* __restrict__ z,
+                                                      const double* __restrict__ yhat, const double* __restrict__ ds,
+                                                      const double* __restrict__ mass, const double* __restrict__ bconst,
+                                                      const unsigned char* __restrict__ fixed,
+                                                      const unsigned char* __restrict__ isblk, const int* __restrict__ cmap,
+                                                      double* __restrict__ b, double* __restrict__ r_e, double* __restrict__ r,
+                                                      double* __restrict__ rhat, double* __restrict__ p,
+                                                      double* __restrict__ partials) {
+  __shared__ double s_red[BLOCK / 64];
+  double acc = 0.0, accb = 0.0, accw = 0.0;
+  for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) {
+    const double d = __builtin_nontemporal_load(ds + i);
+    const bool blk = isblk[i] != 0;
+    double bi, ri;
+    rhs_init_one(scheme, z[i], __builtin_nontemporal_load(yhat + i), d, __builtin_nontemporal_load(mass + i),
+                 __builtin_nontemporal_load(bconst + i), fixed[i] != 0, blk, blk ? b[i] : 0.0, bi, ri);
+    __builtin_nontemporal_store(bi, b + i);
+    accb += (d * bi) * (d * bi);
+    const int c = cmap[i];
+    if (c >= 0) {
+      r[c] = ri; rhat[c] = ri; p[c] = ri;
+      acc += ri * ri;
+      accw += (d * ri) * (d * ri);
+    } else {
+      r_e[i] = ri;
     }
   }
   const double t = block_sum(acc, s_red);
@@ -590,6 +629,7 @@ void ensure_run_matrix(pg_solver* s, int scheme) {
   }
   const SysParams P = make_params(s, scheme);
   s->elim_run = GammaElim();        // (belongs to the matrix that is about to be replaced)
+  s->diag_run = DiagElim();
   assemble_csr_like(P, s->slab, s->nb, s->A_ctor, s->A_run);
   s->A_run.scheme = scheme;
   s->scheme_run = scheme;
@@ -688,6 +728,40 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
                          A.blk_idx.p, A.blk_coef.p, A.blk_cn.p, s->z.p, A.ds.p, s->y.p, s->mass.p, s->bconst.p, s->fixed.p,
                          s->b.p);
     KrylovWork& w = s->work;
+    // rows alone on their diagonal (interface AND border identity rows) left out, compact vectors (pg_reduce.hip, DiagElim)
+    DiagElim& DE = (&A == &s->A_ctor) ? s->diag_ctor : s->diag_run;
+    if (!DE.tried) build_diag_elim(A, s->nb, DE);
+    bool solved = false;
+    if (DE.active && krylov_uses_polynomial(DE.A, o)) {
+      // r = r̂ = p of the remaining rows go straight to the compact vectors, the residuals of the others to scratch (t)
+      hipLaunchKernelGGL(k_rhs_init_c, dim3(w.grid), dim3(BLOCK), 0, stream, n, scheme, s->z.p, s->y.p, A.ds.p, s->mass.p, s->bconst.p,
+                         s->fixed.p, A.isblk.p, DE.cmap.p, s->b.p, w.t.p, w.r.p, w.rhat.p, w.p.p, w.partials.p);
+      PG_HIP(hipGetLastError());
+      diag_fix(DE, s->z.p, w.t.p, w.r.p, w.rhat.p, w.p.p, w.partials.p, w.grid, stream);
+      w.scatter = DE.rlist.p;
+      try {
+        krylov_solve(DE.A, DE.nb, s->slab, nullptr, s->z.p, w, o, st, nullptr, nullptr, true);
+      } catch (...) {
+        w.scatter = nullptr;
+        throw;
+      }
+      w.scatter = nullptr;
+      solved = st.poly_degree >= 0;            // -1: the polynomial stagnated on the compact system -> the full path below
+      if (!solved) {        // z's rows were already set to their solution: ŷ and b̂ have to see that
+        DE.active = false;
+        st = SolveStats();
+        spmv_halo(A, s->nb, s->slab, s->z.p, s->y.p, stream);
+        if (A.n_blk > 0)
+          hipLaunchKernelGGL(k_rhs_block, dim3(grid_for(A.n_blk, BLOCK)), dim3(BLOCK), 0, stream, A.n_blk, scheme, A.blk_rows.p,
+                             A.blk_idx.p, A.blk_coef.p, A.blk_cn.p, s->z.p, A.ds.p, s->y.p, s->mass.p, s->bconst.p, s->fixed.p,
+                             s->b.p);
+      }
+    }
+    if (solved) {
+      s->x_valid = false;
+      s->steps_done += 1;
+      return;
+    }
     hipLaunchKernelGGL(k_rhs_init, dim3(w.grid), dim3(BLOCK), 0, stream, n, s->nb.n_vec(), scheme, s->z.p, s->y.p, A.ds.p,
                        s->mass.p, s->bconst.p, s->fixed.p, A.isblk.p, s->b.p, w.r.p, w.rhat.p, w.p.p, w.partials.p);
     PG_HIP(hipGetLastError());
@@ -1066,7 +1140,8 @@ int32_t pg_solver_system_info(const pg_solver* s, int32_t which, pg_system_info*
   // which & 4: the matrix the warm time loop iterates on -- Â without the Dirichlet interface unknowns when that reduction
   // is active for this system (pg_reduce.hip), else Â itself; n_own / n_omega / n_gamma always describe the full system
   const GammaElim& E = (&Af == &s->A_ctor) ? s->elim_ctor : s->elim_run;
-  const CsrMatrix& A = ((which & 4) && E.active) ? E.A : Af;
+  const DiagElim& DE = (&Af == &s->A_ctor) ? s->diag_ctor : s->diag_run;
+  const CsrMatrix& A = ((which & 4) && DE.active) ? DE.A : (((which & 4) && E.active) ? E.A : Af);
   out->n_own = s->nb.n_own;
   out->nnz = (which & 6) ? A.nnz : A.nnz_raw;
   out->n_ghost = s->nb.n_ghost;
@@ -1084,6 +1159,7 @@ int32_t pg_solver_system_info(const pg_solver* s, int32_t which, pg_system_info*
   out->gershgorin = A.gersh;
   out->spmv_units = A.nunits;
   out->rows_marched = A.rows_m;
+  out->rows_matrix = A.n;
   PG_API_END
 }
 
