@@ -303,21 +303,44 @@ __global__ __launch_bounds__(BLOCK) void k_rhs_init_c(i64 n, int scheme, const d
                                                       double* __restrict__ partials) {
   __shared__ double s_red[BLOCK / 64];
   double acc = 0.0, accb = 0.0, accw = 0.0;
-  for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) {
-    const double d = __builtin_nontemporal_load(ds + i);
-    const bool blk = isblk[i] != 0;
-    double bi, ri;
-    rhs_init_one(scheme, z[i], __builtin_nontemporal_load(yhat + i), d, __builtin_nontemporal_load(mass + i),
-                 __builtin_nontemporal_load(bconst + i), fixed[i] != 0, blk, blk ? b[i] : 0.0, bi, ri);
-    __builtin_nontemporal_store(bi, b + i);
+  auto one = [&](i64 i, double zi, double yh, double d, double ms, double bc, bool fx, bool blk, double bold, int c, double& bi) {
+    double ri;
+    rhs_init_one(scheme, zi, yh, d, ms, bc, fx, blk, bold, bi, ri);
     accb += (d * bi) * (d * bi);
-    const int c = cmap[i];
     if (c >= 0) {
       r[c] = ri; rhat[c] = ri; p[c] = ri;
       acc += ri * ri;
       accw += (d * ri) * (d * ri);
     } else {
       r_e[i] = ri;
+    }
+  };
+  // two rows per lane, 16-byte loads of the seven input streams (as k_rhs_init); the compact stores are 8-byte
+  const i64 npair = (n + 1) / 2;
+  for (i64 q = blockIdx.x * (i64)BLOCK + threadIdx.x; q < npair; q += (i64)gridDim.x * BLOCK) {
+    const i64 i = 2 * q;
+    if (i + 1 < n) {
+      const rd2_t yh = __builtin_nontemporal_load(reinterpret_cast<const rd2_t*>(yhat + i));
+      const rd2_t d = __builtin_nontemporal_load(reinterpret_cast<const rd2_t*>(ds + i));
+      const rd2_t bc = __builtin_nontemporal_load(reinterpret_cast<const rd2_t*>(bconst + i));
+      const rd2_t ms = __builtin_nontemporal_load(reinterpret_cast<const rd2_t*>(mass + i));
+      const rd2_t zz = *reinterpret_cast<const rd2_t*>(z + i);
+      const ruc2_t fx = *reinterpret_cast<const ruc2_t*>(fixed + i);
+      const ruc2_t bk = *reinterpret_cast<const ruc2_t*>(isblk + i);
+      const int c0 = cmap[i], c1 = cmap[i + 1];
+      rd2_t bold;
+      bold.x = 0.0; bold.y = 0.0;
+      if (bk.x | bk.y) bold = *reinterpret_cast<const rd2_t*>(b + i);
+      rd2_t bi;
+      double b0, b1;
+      one(i, zz.x, yh.x, d.x, ms.x, bc.x, fx.x != 0, bk.x != 0, bold.x, c0, b0);
+      one(i + 1, zz.y, yh.y, d.y, ms.y, bc.y, fx.y != 0, bk.y != 0, bold.y, c1, b1);
+      bi.x = b0; bi.y = b1;
+      __builtin_nontemporal_store(bi, reinterpret_cast<rd2_t*>(b + i));
+    } else if (i < n) {
+      double b0;
+      one(i, z[i], yhat[i], ds[i], mass[i], bconst[i], fixed[i] != 0, isblk[i] != 0, isblk[i] ? b[i] : 0.0, cmap[i], b0);
+      b[i] = b0;
     }
   }
   const double t = block_sum(acc, s_red);
