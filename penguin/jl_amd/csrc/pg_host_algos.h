@@ -40,17 +40,32 @@ struct MarchGeometry {
   int W;              // rows computed per window (the window holds W + 2 elements of every line)
   int INFO;           // dwords per run descriptor: 8 offsets, 8 values (lo, hi)
   int kmax;           // planes per unit actually used (<= K)
+  // optional grid geometry (3-D units only): dword 24 of a run descriptor is then the grid cell of the run's first row,
+  // cell = (plane * lines + line) * ext0 + i, and the units are ordered strip by strip (see below)
+  int64_t ext0 = 0, lines = 0;
+  int strip = 0;      // lateral lines per strip (0: order by first row)
 };
+
+// place of a grid cell in the order of the work items: strip of lateral lines, then plane; ties by row number
+inline int64_t march_order(int64_t cell, int64_t ext0, int64_t lines, int strip) {
+  const int64_t line = (cell / ext0) % lines, plane = cell / (ext0 * lines);
+  return (line / strip) * ((int64_t)1 << 20) + plane;
+}
 
 // Chains of runs that face each other across the slowest stencil direction (entry cnt-3 / cnt-2 of a row lead to the row of
 // the same lateral position one plane up / down), cut into windows of W computed rows and units of <= kmax planes
 // (pg_spmv.hip "marching units" has the record layout).  info: INFO dwords per run -- the col - row offsets (8) and the
 // values (8 doubles as lo / hi dwords) of the run's first row, in the entry order of the assembled rows:
 // +1, -1, [+Y, -Y,] +Z, -Z, 0.  n = rows of the matrix (= guaranteed length of every vector the kernel reads).
-// mrec: the unit records, sorted by first row; fallback: rows that cannot march (another entry order, windows that would read
+// mrec: the unit records, sorted by first row -- or, when the grid geometry is known, 3-D units strip by strip: all planes
+// of `strip` neighbouring lateral lines before the next strip.  A unit reads the line below its first and above its last
+// plane (6 lines of the chain for 4 computed ones); in first-row order a plane of units lies between a unit and the unit
+// above it in the chain, which is more than an XCD's L2 holds at 512^3 (PMC: x crossed the fabric 1.54 times per launch),
+// in strip order it is strip x windows units.  fallback: rows that cannot march (another entry order, windows that would read
 // outside the vector); rows_m: rows covered by units.
 inline void plan_march_units(int64_t n, const std::vector<MRun>& runs, const std::vector<int>& info, const MarchGeometry& geo,
-                             std::vector<int>& mrec, std::vector<RowRange>& fallback, int64_t& rows_m) {
+                             std::vector<int>& mrec, std::vector<RowRange>& fallback, int64_t& rows_m,
+                             std::vector<int64_t>* okeys = nullptr) {
   typedef int64_t i64;
   rows_m = 0;
   const i64 nr = (i64)runs.size();
@@ -92,7 +107,7 @@ inline void plan_march_units(int64_t n, const std::vector<MRun>& runs, const std
     }
     if (best >= 0) { succ[i] = (int)best; pred[best] = (int)i; }
   }
-  struct Unit { int key; std::vector<int> rec; };
+  struct Unit { int key; int64_t order; std::vector<int> rec; };
   std::vector<Unit> units;
   // every load of a unit reads elements idx0 .. idx0 + 129 of a vector of >= n elements (+ 8 of slack, DevBuf)
   auto safe = [&](i64 idx0) { return idx0 >= 0 && idx0 + 130 <= n + 8; };
@@ -147,6 +162,13 @@ inline void plan_march_units(int64_t n, const std::vector<MRun>& runs, const std
         u.rec.assign(geo.REC, 0);
         range(k, lo, hi);
         u.key = (int)(B[k] + lo);
+        u.order = 0;
+        if (Y && geo.strip > 0 && geo.ext0 > 0 && geo.lines > 0 && RI > 24) {
+          const i64 cell = info[RI * chain[k] + 24];
+          if (cell >= 0) {
+            u.order = march_order(cell, geo.ext0, geo.lines, geo.strip);
+          }
+        }
         const int Kp = K <= geo.KS ? geo.KS : geo.K;   // the kernel's two unit sizes: shorter units end with empty planes
         u.rec[0] = Kp | (cnt << 8);   // | active lanes << 16, below
         u.rec[1] = u.key;
@@ -179,9 +201,39 @@ inline void plan_march_units(int64_t n, const std::vector<MRun>& runs, const std
       }
     }
   }
-  std::sort(units.begin(), units.end(), [](const Unit& a, const Unit& b) { return a.key < b.key; });
+  std::sort(units.begin(), units.end(), [](const Unit& a, const Unit& b) { return a.order != b.order ? a.order < b.order : a.key < b.key; });
   mrec.reserve(units.size() * geo.REC);
   for (auto& u : units) mrec.insert(mrec.end(), u.rec.begin(), u.rec.end());
+  if (okeys) {   // the order as one number per unit (build_tiles lines the slices up with it)
+    okeys->clear();
+    okeys->reserve(units.size());
+    for (auto& u : units) okeys->push_back(u.order * ((i64)1 << 32) + u.key);
+  }
+}
+
+// Tile table of the slice kernel (pg_spmv.hip k_spmv_s): the units (sorted by ukey) and the slices that need no halo
+// (sorted by skey, the same order) are both split into 8 equal parts -- one per XCD, as the kernel without tiles does --
+// and every part into `T` tiles: equal numbers of units, and the slices whose keys lie between the tile's first unit and
+// the next tile's.  tab[(q (T + 1) + t) 2 + {0, 1}] = first unit / first slice of tile t of XCD q (t = T: the ends).
+inline void plan_tiles(const std::vector<int64_t>& ukey, const std::vector<int64_t>& skey, int T, std::vector<int>& tab) {
+  typedef int64_t i64;
+  const i64 nu = (i64)ukey.size(), ns = (i64)skey.size();
+  tab.assign((size_t)8 * (T + 1) * 2, 0);
+  for (int q = 0; q < 8; ++q) {
+    const i64 u0 = nu * q / 8, u1 = nu * (q + 1) / 8, s0 = ns * q / 8, s1 = ns * (q + 1) / 8;
+    i64 sprev = s0;
+    for (int t = 0; t <= T; ++t) {
+      const i64 u = u0 + (u1 - u0) * t / T;
+      i64 sl;
+      if (t == 0) sl = s0;
+      else if (t == T || u >= nu) sl = s1;
+      else sl = std::lower_bound(skey.begin(), skey.end(), ukey[u]) - skey.begin();
+      sl = std::min(std::max(sl, sprev), s1);
+      sprev = sl;
+      tab[((size_t)q * (T + 1) + t) * 2] = (int)u;
+      tab[((size_t)q * (T + 1) + t) * 2 + 1] = (int)sl;
+    }
+  }
 }
 
 }  // namespace pghost

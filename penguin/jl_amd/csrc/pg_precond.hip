@@ -303,6 +303,14 @@ __global__ void k_point_scale(SysParams P, int K, i64 Mloc, const int* red, doub
 
 namespace pg {
 
+// grid position of the rows for the order of the marching units (3-D only: pg_host_algos.h plan_march_units)
+static void set_geo(CsrMatrix& A, const Slab& slab, const Numbering& nb) {
+  A.geo_cell = nb.row_cell.p;
+  A.geo_map = nullptr;
+  A.geo_ext0 = slab.N == 3 ? slab.ext[0] : 0;
+  A.geo_lines = slab.N == 3 ? slab.ext[1] : 0;
+}
+
 void assemble_csr_preconditioned(const SysParams& P, const Slab& s, const Numbering& nb, CsrMatrix& A,
                                  const bool* inherit_halo) {
   hipStream_t st = ctx().stream;
@@ -390,6 +398,7 @@ void assemble_csr_preconditioned(const SysParams& P, const Slab& s, const Number
               A.halo_needed ? "exchanged" : "skipped");
   }
   laps.lap("  asm: count/fill/table kernels");
+  set_geo(A, s, nb);
   build_spmv_chunks(A);
   laps.lap("  asm: SpMV chunks + slices");
   decide_poly(A);
@@ -465,6 +474,7 @@ void assemble_csr_like(const SysParams& P, const Slab& s, const Numbering& nb, c
     PG_HIP(hipStreamSynchronize(st));
   }
   laps.lap("  asm-like: values on the ctor matrix' pattern");
+  set_geo(A, s, nb);
   if (!build_slices_like(T, A)) build_spmv_chunks(A);
   laps.lap("  asm-like: slices");
   decide_poly(A);

@@ -298,6 +298,7 @@ void build_gamma_elim(const CsrMatrix& A, const Numbering& nb, GammaElim& E) {
   R.poly_ok = A.poly_ok;        // Gershgorin already left the identity rows' columns out (decide_poly)
   R.gersh = A.gersh;
   R.nnz_raw = nnz;
+  R.geo_cell = A.geo_cell; R.geo_map = nullptr; R.geo_ext0 = A.geo_ext0; R.geo_lines = A.geo_lines;   // rows [0, n_w) keep their numbers
   build_spmv_chunks(R);
   E.nb = Numbering();
   E.nb.K = 1;
@@ -395,6 +396,7 @@ void build_diag_elim(const CsrMatrix& A, const Numbering& nb, DiagElim& E) {
   R.poly_ok = A.poly_ok;
   R.gersh = A.gersh;
   R.nnz_raw = nnz;
+  R.geo_cell = A.geo_cell; R.geo_map = E.rlist.p; R.geo_ext0 = A.geo_ext0; R.geo_lines = A.geo_lines;
   build_spmv_chunks(R);
   E.nb = Numbering();
   E.nb.K = 1;

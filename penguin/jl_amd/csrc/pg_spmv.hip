@@ -600,7 +600,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_spmv_s(i64 nslices, const int* __r
                                                   double* __restrict__ y, const double* __restrict__ aux,
                                                   double* __restrict__ partials, const double* __restrict__ sc, int xcd,
                                                   FinArgs fin, int pstride, int accum, const int* __restrict__ mrec,
-                                                  i64 nunits) {
+                                                  i64 nunits, const int* __restrict__ tiles, int tpx) {
   __shared__ __attribute__((aligned(16))) double s_val[BLOCK / 64][512];
   __shared__ __attribute__((aligned(16))) double s_x[BLOCK / 64][512];   // G chunks: x[col] of every entry of the chunk
   __shared__ double s_red[BLOCK / 64];
@@ -628,19 +628,36 @@ __global__ __launch_bounds__(BLOCK, 4) void k_spmv_s(i64 nslices, const int* __r
   // that the latency-bound irregular chunks of some waves overlap the streaming of others, measured no faster, and one
   // merged loop costs registers: the live ranges of both bodies add up -- 144 VGPRs, a wave per SIMD less.)
   xcd &= 1;
+  // Work of this wave: every (BLOCK / 64 x blocks)-th unit and slice of its XCD's eighth of both lists (XCD-aware: the
+  // blocks of an XCD share one L2) -- in TILES when the image has a tile table (build_tiles): tile t of XCD q = units
+  // [tb[2t], tb[2t+2]) and the slices [tb[2t+1], tb[2t+3]) that lie next to them in the grid, units first.  The irregular
+  // rows of a tile then gather x from lines the tile's units have just pulled into this XCD's L2; with all units before
+  // all slices those lines crossed the fabric twice (PMC, 512^3: 28 MB of 234 per launch).  The round robin over the
+  // waves runs on across the tiles (a tile holds about one unit per wave).
+  const bool xsplit = xcd && gridDim.x >= 8;
+  const int xid = xsplit ? (blockIdx.x & 7) : 0;
+  const int woff = xsplit ? (int)(blockIdx.x >> 3) * (BLOCK / 64) + wave : (int)blockIdx.x * (BLOCK / 64) + wave;
+  const int wstr = xsplit ? (int)(((i64)gridDim.x + 7 - xid) >> 3) * (BLOCK / 64) : (int)gridDim.x * (BLOCK / 64);
+  const int* __restrict__ tb = tiles ? tiles + 2 * (tpx + 1) * xid : nullptr;
+  const int ntile = tiles ? tpx : 1;
+  const int l31 = lane & 31;
+  for (int tile = 0; tile < ntile; ++tile) {
+  i64 ulo, uhi, slo, shi, ubase, sbase;
+  if (tiles) {
+    ubase = tb[0]; sbase = tb[1];
+    ulo = tb[2 * tile]; slo = tb[2 * tile + 1]; uhi = tb[2 * tile + 2]; shi = tb[2 * tile + 3];
+  } else if (xsplit) {
+    ubase = ulo = nunits * xid / 8; uhi = nunits * (xid + 1) / 8;
+    sbase = slo = nslices * xid / 8; shi = nslices * (xid + 1) / 8;
+  } else {
+    ubase = ulo = 0; uhi = nunits;
+    sbase = slo = 0; shi = nslices;
+  }
   if (nunits > 0) {
-    i64 ucur, ustride, uhi;
-    if (xcd && gridDim.x >= 8) {
-      const int xid = blockIdx.x & 7;
-      const i64 nbx = ((i64)gridDim.x + 7 - xid) >> 3;
-      uhi = nunits * (xid + 1) / 8;
-      ucur = nunits * xid / 8 + (i64)(blockIdx.x >> 3) * (BLOCK / 64) + wave;
-      ustride = nbx * (BLOCK / 64);
-    } else {
-      ucur = (i64)blockIdx.x * (BLOCK / 64) + wave;
-      ustride = (i64)gridDim.x * (BLOCK / 64);
-      uhi = nunits;
-    }
+    int d = (woff - (int)(ulo - ubase)) % wstr;
+    d = d < 0 ? d + wstr : d;
+    i64 ucur = ulo + d;
+    const i64 ustride = wstr;
     int urec = ucur < uhi ? mrec[MARCH_REC * ucur + lane] : 0;
     for (; ucur < uhi; ucur += ustride) {
       const i64 un = ucur + ustride;
@@ -654,21 +671,10 @@ __global__ __launch_bounds__(BLOCK, 4) void k_spmv_s(i64 nslices, const int* __r
       urec = urec_n;
     }
   }
-  i64 first, wstride, hi;
-  if (xcd && gridDim.x >= 8) {
-    const int xid = blockIdx.x & 7;
-    const i64 nbx = ((i64)gridDim.x + 7 - xid) >> 3;          // blocks resident on this XCD
-    const i64 lo = nslices * xid / 8;
-    hi = nslices * (xid + 1) / 8;
-    first = lo + (i64)(blockIdx.x >> 3) * (BLOCK / 64) + wave;
-    wstride = nbx * (BLOCK / 64);
-  } else {
-    first = (i64)blockIdx.x * (BLOCK / 64) + wave;
-    wstride = (i64)gridDim.x * (BLOCK / 64);
-    hi = nslices;
-  }
+  int ds_ = (woff - (int)(slo - sbase)) % wstr;
+  ds_ = ds_ < 0 ? ds_ + wstr : ds_;
+  const i64 first = slo + ds_, wstride = wstr, hi = shi;
   const i64 lastc = hi - 1;
-  const int l31 = lane & 31;
   // the record of a slice is fetched with ONE vector load TWO slices ahead (lane l reads dword l & 31) and its
   // wave-uniform fields are broadcast with v_readlane
   int rec = first < hi ? srec[SL_REC * first + l31] : 0;
@@ -750,6 +756,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_spmv_s(i64 nslices, const int* __r
     rec = rec_n;
     rec_n = rec_nn;
   }
+  }   // tiles
   // (write-through stores: the last block of this launch may read them, see fold_scalar_phase)
   // pstride = blocks per partial slot (the grid the Krylov workspace was sized for; >= gridDim.x).  accum: this launch
   // covers the rows left out by an earlier launch of the same product (spmv_with_halo: the rows that had to wait for
@@ -863,14 +870,17 @@ bool launch_slices(int v, const CsrMatrix& A, i64 s0, i64 ns, const double* x, d
   if (fin && MODE >= 1) fa = *fin;
   const int* rec = A.srec.p + SL_REC * s0;
   const i64 nu = units ? A.nunits : 0;   // the marching units ride with the launch that covers the interior slices
+  const bool tiled = units && A.tiles_per_xcd > 0 && s0 == 0 && ns == A.tile_ns && (xcd_map() & 1) && grid >= 8;
+  const int* tiles = tiled ? (const int*)A.tiles.p : nullptr;
+  const int tpx = tiled ? A.tiles_per_xcd : 0;
   if (v & 4)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_s<MODE, true>), dim3(grid), dim3(BLOCK), 0, st, ns, rec, A.pval.p,
                        A.g_rowid.p, A.g_rowptr.p, A.g_col.p, A.g_val.p, x, y, aux, partials, sc, xcd_map(), fa, pstride, accum,
-                       (const int*)A.mrec.p, nu);
+                       (const int*)A.mrec.p, nu, tiles, tpx);
   else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_s<MODE, false>), dim3(grid), dim3(BLOCK), 0, st, ns, rec, A.pval.p,
                        A.g_rowid.p, A.g_rowptr.p, A.g_col.p, A.g_val.p, x, y, aux, partials, sc, xcd_map(), fa, pstride, accum,
-                       (const int*)A.mrec.p, nu);
+                       (const int*)A.mrec.p, nu, tiles, tpx);
   return fa.ticket != nullptr;
 }
 
@@ -900,17 +910,20 @@ struct Slice {
   int r0, meta, base, aux;
   int key;   // first matrix row (sort key)
   int bnd;   // 1: some row references a ghost column (the slice waits for the halo exchange)
+  i64 okey = 0;   // place in the order of the work items (march_order of the first row's cell, then the row)
 };
 
 using pghost::MRun;   // rows [r0, r0 + len) with one stencil (offsets and values), cnt = 5 / 7 entries
 
-constexpr int RUN_INFO = 24;   // dwords per run: 8 offsets, 8 values (lo, hi)
+constexpr int RUN_INFO = 25;   // dwords per run: 8 offsets, 8 values (lo, hi), grid cell of the first row (-1: unknown)
 
 // col - row offsets and values of the first row of every run
 __global__ void k_run_info(i64 nruns, const int* __restrict__ run_r0, const int* __restrict__ rowptr,
-                           const int* __restrict__ col, const double* __restrict__ val, int* __restrict__ out) {
+                           const int* __restrict__ col, const double* __restrict__ val, const int* __restrict__ cell,
+                           const int* __restrict__ map, int* __restrict__ out) {
   for (i64 q = blockIdx.x * (i64)blockDim.x + threadIdx.x; q < nruns; q += (i64)gridDim.x * blockDim.x) {
     const int r = run_r0[q], a = rowptr[r], len = rowptr[r + 1] - a;
+    out[RUN_INFO * q + 24] = cell ? cell[map ? map[r] : r] : -1;
     for (int k = 0; k < 8; ++k) {
       out[RUN_INFO * q + k] = k < len ? col[a + k] - r : 0;
       const double v = k < len ? val[a + k] : 0.0;
@@ -961,6 +974,35 @@ __global__ void k_units_invalid(i64 nunits, const int* __restrict__ mrec, const 
   if (c) atomicAdd(out, c);
 }
 
+__global__ void k_row_cells(i64 nrows, const int* __restrict__ rows, const int* __restrict__ cell, const int* __restrict__ map,
+                            int* __restrict__ out) {
+  for (i64 q = blockIdx.x * (i64)blockDim.x + threadIdx.x; q < nrows; q += (i64)gridDim.x * blockDim.x) {
+    const int r = rows[q];
+    out[q] = cell[map ? map[r] : r];
+  }
+}
+
+int march_strip() {
+  static const int strip = getenv("PG_SPMV_STRIP") ? atoi(getenv("PG_SPMV_STRIP")) : 16;
+  return strip;
+}
+bool has_geo(const CsrMatrix& A) { return A.geo_cell && A.geo_ext0 > 0 && A.geo_lines > 0 && march_strip() > 0; }
+
+// march_order of the given rows (0 for all without grid geometry)
+std::vector<i64> row_orders(const CsrMatrix& A, const std::vector<int>& rows) {
+  std::vector<i64> ord(rows.size(), 0);
+  if (!has_geo(A) || rows.empty()) return ord;
+  const i64 nr = (i64)rows.size();
+  DevBuf<int> d_rows(nr), d_cells(nr);
+  d_rows.upload(rows.data(), nr);
+  hipLaunchKernelGGL(k_row_cells, dim3(grid_for(nr, 256)), dim3(256), 0, ctx().stream, nr, d_rows.p, A.geo_cell, A.geo_map, d_cells.p);
+  PG_HIP(hipGetLastError());
+  std::vector<int> cells(rows.size());
+  d_cells.download(cells.data(), nr);
+  for (i64 q = 0; q < nr; ++q) ord[q] = pghost::march_order(cells[q], A.geo_ext0, A.geo_lines, march_strip());
+  return ord;
+}
+
 void emit_u_rows(std::vector<Slice>& up, i64 a, i64 b, int cnt) {
   for (i64 r = a; r < b; r += SL_MAXROWS_U) {
     const int rows = (int)std::min<i64>(SL_MAXROWS_U, b - r);
@@ -971,7 +1013,8 @@ void emit_u_rows(std::vector<Slice>& up, i64 a, i64 b, int cnt) {
 // Chains of runs -> unit records: the planning itself is plain host code (pg_host_algos.h: also compiled, with
 // AddressSanitizer / UBSan, into the CPU test-suite); here: the run descriptors come from the device and the result goes
 // back.  Rows that cannot march are appended to `up` as U slices.
-void build_march_units(CsrMatrix& A, const std::vector<MRun>& runs, std::vector<int>& mrec, std::vector<Slice>& up) {
+void build_march_units(CsrMatrix& A, const std::vector<MRun>& runs, std::vector<int>& mrec, std::vector<Slice>& up,
+                       std::vector<i64>& ukeys) {
   A.rows_m = 0;
   const i64 nr = (i64)runs.size();
   if (nr == 0) return;
@@ -982,15 +1025,16 @@ void build_march_units(CsrMatrix& A, const std::vector<MRun>& runs, std::vector<
     for (i64 i = 0; i < nr; ++i) r0s[i] = runs[i].r0;
     DevBuf<int> d_r0(nr), d_info(RUN_INFO * nr);
     d_r0.upload(r0s.data(), nr);
-    hipLaunchKernelGGL(k_run_info, dim3(grid_for(nr, 256)), dim3(256), 0, st, nr, d_r0.p, A.rowptr.p, A.col.p, A.val.p, d_info.p);
+    hipLaunchKernelGGL(k_run_info, dim3(grid_for(nr, 256)), dim3(256), 0, st, nr, d_r0.p, A.rowptr.p, A.col.p, A.val.p,
+                       A.geo_cell, A.geo_map, d_info.p);
     PG_HIP(hipGetLastError());
     d_info.download(info.data(), RUN_INFO * nr);
   }
   static const int kmax = getenv("PG_SPMV_MARCH_K") ? std::max(1, std::min(MARCH_K, atoi(getenv("PG_SPMV_MARCH_K")))) : MARCH_K;
-  pghost::MarchGeometry geo{MARCH_K, MARCH_KS, MARCH_REC, MARCH_W, RUN_INFO, kmax};
+  pghost::MarchGeometry geo{MARCH_K, MARCH_KS, MARCH_REC, MARCH_W, RUN_INFO, kmax, A.geo_ext0, A.geo_lines, march_strip()};
   std::vector<pghost::RowRange> fallback;
   i64 rows_m = 0;
-  pghost::plan_march_units(A.n, runs, info, geo, mrec, fallback, rows_m);
+  pghost::plan_march_units(A.n, runs, info, geo, mrec, fallback, rows_m, &ukeys);
   A.rows_m = rows_m;
   for (const auto& f : fallback) emit_u_rows(up, f.a, f.b, f.cnt);
 }
@@ -1107,7 +1151,8 @@ void build_slices(CsrMatrix& A, const int* rp) {
   laps.lap("    slices: host classification");
   // marching units out of the stencil runs; what cannot march comes back as U slices
   std::vector<int> mrec;
-  build_march_units(A, runs, mrec, up);
+  std::vector<i64> ukeys;
+  build_march_units(A, runs, mrec, up, ukeys);
   A.nunits = (i64)mrec.size() / MARCH_REC;
   A.mrec.alloc(std::max<i64>((i64)mrec.size(), 1));
   if (!mrec.empty()) A.mrec.upload(mrec.data(), (i64)mrec.size());
@@ -1126,7 +1171,36 @@ void build_slices(CsrMatrix& A, const int* rp) {
   A.pval.alloc(A.nnz_p + 8);
   // packed CSR of the irregular rows + its chunks: the rows that reference a ghost column go last, so that no chunk
   // mixes rows that can be multiplied before the halo has landed with rows that cannot
-  std::stable_partition(grows.begin(), grows.end(), [&](int r) { return (fl[r] & 4) == 0; });
+  // ... in the order of the work items (strip of lines, plane, row: the chunks of a tile gather x where the tile's units
+  // have just read it) -- a counting sort, the rows arrive in ascending order
+  std::vector<i64> g_ord = row_orders(A, grows);
+  if (has_geo(A) && !grows.empty()) {
+    std::vector<i64> uniq(g_ord);
+    std::sort(uniq.begin(), uniq.end());
+    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+    std::vector<i64> start(uniq.size() + 1, 0);
+    std::vector<int> bucket(grows.size());
+    for (size_t q = 0; q < grows.size(); ++q) {
+      bucket[q] = (int)(std::lower_bound(uniq.begin(), uniq.end(), g_ord[q]) - uniq.begin());
+      ++start[bucket[q] + 1];
+    }
+    for (size_t b = 0; b < uniq.size(); ++b) start[b + 1] += start[b];
+    std::vector<int> sorted(grows.size());
+    std::vector<i64> sorted_ord(grows.size());
+    for (size_t q = 0; q < grows.size(); ++q) {
+      const i64 pos = start[bucket[q]]++;
+      sorted[pos] = grows[q];
+      sorted_ord[pos] = g_ord[q];
+    }
+    grows.swap(sorted);
+    g_ord.swap(sorted_ord);
+  }
+  {   // (the order keys travel with the rows through the partition)
+    std::vector<std::pair<int, i64>> both(grows.size());
+    for (size_t q = 0; q < grows.size(); ++q) both[q] = {grows[q], g_ord[q]};
+    std::stable_partition(both.begin(), both.end(), [&](const std::pair<int, i64>& e) { return (fl[e.first] & 4) == 0; });
+    for (size_t q = 0; q < grows.size(); ++q) { grows[q] = both[q].first; g_ord[q] = both[q].second; }
+  }
   const i64 ng = (i64)grows.size();
   i64 ng_int = 0;
   while (ng_int < ng && (fl[grows[ng_int]] & 4) == 0) ++ng_int;
@@ -1141,6 +1215,12 @@ void build_slices(CsrMatrix& A, const int* rp) {
   A.g_col.zero();
   A.g_val.zero();
   A.g_rowptr.upload(grp.data(), ng + 1);
+  {
+    std::vector<int> firsts(up.size());
+    for (size_t q = 0; q < up.size(); ++q) firsts[q] = up[q].key;
+    const std::vector<i64> ord = row_orders(A, firsts);
+    for (size_t q = 0; q < up.size(); ++q) up[q].okey = ord[q] * ((i64)1 << 32) + up[q].key;
+  }
   std::vector<Slice> all(up);
   if (ng > 0) {
     A.g_rowid.upload(grows.data(), ng);
@@ -1153,15 +1233,36 @@ void build_slices(CsrMatrix& A, const int* rp) {
       PG_REQUIRE(grp[e] - grp[q] <= SPMV_CHUNK_ENTRIES, "CSR row longer than an SpMV chunk");
       const i64 stop = q < ng_int ? ng_int : ng;   // chunks end at the interior / boundary seam
       while (e < stop && e - q < 64 && grp[e + 1] - grp[q] <= SPMV_CHUNK_ENTRIES) ++e;
-      all.push_back(Slice{(int)q, (int)(e - q) | (SL_G << 8), grp[q], grp[e], grows[q], q >= ng_int ? 1 : 0});
+      all.push_back(Slice{(int)q, (int)(e - q) | (SL_G << 8), grp[q], grp[e], grows[q], q >= ng_int ? 1 : 0,
+                          g_ord[q] * ((i64)1 << 32) + grows[q]});
       q = e;
     }
   }
   // by first row within each group; the slices that wait for the halo form the tail [nslices_int, nslices)
-  std::stable_sort(all.begin(), all.end(), [](const Slice& a, const Slice& b) { return a.bnd != b.bnd ? a.bnd < b.bnd : a.key < b.key; });
+  std::stable_sort(all.begin(), all.end(), [](const Slice& a, const Slice& b) { return a.bnd != b.bnd ? a.bnd < b.bnd : a.okey < b.okey; });
   A.nslices = (i64)all.size();
   A.nslices_int = 0;
   while (A.nslices_int < A.nslices && !all[A.nslices_int].bnd) ++A.nslices_int;
+  // tiles (PG_SPMV_TILE_UNITS = units per tile, e.g. 512 = one per resident wave of an XCD; default off): measured at
+  // 512^3, tiles of 512 units take 5 MB off the 159 MB a lean launch reads but cost 6 us of its 45 -- a wave then has one
+  // unit and about one slice per tile and nothing to prefetch the next record behind
+  {
+    static const int tile_units = getenv("PG_SPMV_TILE_UNITS") ? atoi(getenv("PG_SPMV_TILE_UNITS")) : 0;
+    const i64 T = tile_units > 0 ? std::min<i64>(256, (A.nunits / 8 + tile_units / 2) / tile_units) : 0;
+    A.tiles_per_xcd = 0;
+    A.tile_ns = 0;
+    A.tiles.release();
+    if (T >= 2 && A.nslices_int > 0 && (i64)ukeys.size() == A.nunits) {
+      std::vector<i64> skeys((size_t)A.nslices_int);
+      for (i64 q = 0; q < A.nslices_int; ++q) skeys[q] = all[q].okey;
+      std::vector<int> tab;
+      pghost::plan_tiles(ukeys, skeys, (int)T, tab);
+      A.tiles.alloc((i64)tab.size());
+      A.tiles.upload(tab.data(), (i64)tab.size());
+      A.tiles_per_xcd = (int)T;
+      A.tile_ns = A.nslices_int;
+    }
+  }
   std::vector<int> sd(SL_REC * (A.nslices + 1), 0);
   for (i64 q = 0; q < A.nslices; ++q) {
     int* rec = sd.data() + SL_REC * q;
@@ -1276,6 +1377,9 @@ bool build_slices_like(const CsrMatrix& T, CsrMatrix& A) {
   A.rows_u = T.rows_u; A.rows_p = T.rows_p; A.rows_g = T.rows_g; A.nnz_p = T.nnz_p; A.nnz_g = T.nnz_g;
   A.spmv_bytes = T.spmv_bytes;
   A.nunits = T.nunits; A.rows_m = T.rows_m;
+  A.tiles_per_xcd = T.tiles_per_xcd; A.tile_ns = T.tile_ns;
+  if (T.tiles_per_xcd > 0) clone_buf(A.tiles, T.tiles, st);
+  else A.tiles.release();
   clone_buf(A.mrec, T.mrec, st);
   if (A.nunits > 0)
     hipLaunchKernelGGL(k_fill_units, dim3(grid_for(A.nunits, 256)), dim3(256), 0, st, A.nunits, A.mrec.p, A.rowptr.p, A.val.p);

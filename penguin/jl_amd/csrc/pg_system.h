@@ -62,6 +62,16 @@ struct CsrMatrix {
   // stencil rows; these rows are in no slice
   DevBuf<int> mrec;
   i64 nunits = 0, rows_m = 0;
+  // tile table of the slice kernel (pg_host_algos.h plan_tiles): 8 x (tiles_per_xcd + 1) x {first unit, first slice}; covers
+  // the units and the slices [0, tile_ns) = [0, nslices_int)
+  DevBuf<int> tiles;
+  int tiles_per_xcd = 0;
+  i64 tile_ns = 0;
+  // grid position of the rows, for the order of the units only (non-owning, read while the units are planned): local cell
+  // of row geo_map[r] (or r), cells per grid line, lines per plane
+  const int* geo_cell = nullptr;
+  const int* geo_map = nullptr;
+  i64 geo_ext0 = 0, geo_lines = 0;
   bool want_units = true;   // false: a system solved once (a slab of the moving solver): planning the units costs more than they save
   i64 nslices = 0;
   i64 nslices_int = 0;   // slices [0, nslices_int) reference no ghost column (computable before the halo of x has landed)

@@ -134,6 +134,28 @@ static void test_march(std::mt19937_64& rng) {
     pghost::plan_march_units(s.nrows, s.runs, s.info, geo, mrec, fb, rows_m);
     const int64_t nunits = (int64_t)mrec.size() / geo.REC;
     CHECK(nunits > 0 && rows_m > 0, "no units planned (n = %d, runs = %zu)", n, s.runs.size());
+    {   // the tile table over the units' keys and some slices' keys: 8 parts x T tiles, monotone, ends on the part's ends
+      std::vector<int> mrec2;
+      std::vector<pghost::RowRange> fb2;
+      std::vector<int64_t> uk, sk;
+      int64_t rm2 = 0;
+      pghost::plan_march_units(s.nrows, s.runs, s.info, geo, mrec2, fb2, rm2, &uk);
+      CHECK((int64_t)uk.size() == nunits && std::is_sorted(uk.begin(), uk.end()), "unit keys: %zu of %lld", uk.size(), (long long)nunits);
+      for (int q = 0, m = (int)(rng() % 4000); q < m; ++q) sk.push_back((int64_t)(rng() % (uint64_t)(s.nrows + 1)));
+      std::sort(sk.begin(), sk.end());
+      const int T = 1 + (int)(rng() % 7);
+      std::vector<int> tab;
+      pghost::plan_tiles(uk, sk, T, tab);
+      CHECK((int)tab.size() == 8 * (T + 1) * 2, "tile table size %zu", tab.size());
+      const int64_t nu = nunits, ns = (int64_t)sk.size();
+      for (int q = 0; q < 8; ++q) {
+        const int* tb = tab.data() + (size_t)q * (T + 1) * 2;
+        CHECK(tb[0] == nu * q / 8 && tb[2 * T] == nu * (q + 1) / 8 && tb[1] == ns * q / 8 && tb[2 * T + 1] == ns * (q + 1) / 8,
+              "tile table: part %d does not end on the part's ends", q);
+        for (int t = 0; t < T; ++t)
+          CHECK(tb[2 * t] <= tb[2 * t + 2] && tb[2 * t + 1] <= tb[2 * t + 3], "tile table: part %d tile %d not monotone", q, t);
+      }
+    }
     // execute the records as the kernel does (lane l holds elements 2l, 2l+1 of a 128-element window of every line) on a
     // vector with 8 elements of slack, and compare with the stencil applied row by row
     std::vector<double> x(s.nrows + 8), y(s.nrows, 0.0), yref(s.nrows, 0.0);

@@ -4,6 +4,9 @@ Bars (BASELINE.json north_star): bit-exact cut-cell classification and indices; 
 the temperature field.  Per-cell capacities agree to quadrature / cancellation accuracy (oracle/geometry.py).
 """
 import math
+import os
+import pathlib
+import sys
 
 import numpy as np
 import pytest
@@ -753,6 +756,20 @@ def test_spmv_stencil_slices_bitwise_equal_csr_kernels(pj, case):
         diff, mx = _spmv_compare(pj, s, 0, 70, other)
         assert mx > 0.0
         assert diff == 0.0, (case, other, diff, mx)
+
+
+@pytest.mark.parametrize("env", [{"PG_SPMV_TILE_UNITS": "8"}, {"PG_SPMV_STRIP": "0"}, {"PG_SPMV_STRIP": "5", "PG_SPMV_TILE_UNITS": "3"}])
+def test_spmv_work_item_orders_bitwise_equal_csr_kernels(env):
+    """The order of the slice kernel's work items (strips of grid lines; optional tiles of units + neighbouring slices) is read
+    from the environment once per process: the bitwise comparison above, in a child process per setting."""
+    import subprocess
+    root = pathlib.Path(__file__).resolve().parents[1]
+    code = ("import sys; sys.path.insert(0, '.'); import penguin.jl_amd as pj; pj.init(0); import tests.test_gpu_parity as t\n"
+            "for c in ('mono3d_march', 'mono3d_march_offcentre', 'mono3d_march_two_balls', 'mono2d_march'):\n"
+            "    t.test_spmv_stencil_slices_bitwise_equal_csr_kernels(pj, c)\n"
+            "print('orders ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "orders ok" in r.stdout, (env, r.stdout[-2000:], r.stderr[-4000:])
 
 
 # ------------------------------------------------------------------------------------ steady diffusion (SURVEY §8f.1)
