@@ -77,9 +77,10 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_init(i64 n, i64 nvec, const doub
 // slot 4 = (s,s)_W, the weighted norm of the half-step convergence test (PH_BICG_S; the second product overwrites the slot
 // afterwards)
 template <bool NTV>
-__global__ __launch_bounds__(BLOCK) void k_bicg_s(i64 n, const double* __restrict__ sc, const double* __restrict__ v,
+__global__ __launch_bounds__(BLOCK) void k_bicg_s(i64 n, double* __restrict__ sc, const double* __restrict__ v,
                                                   const double* __restrict__ rhat, double* __restrict__ r,
-                                                  double* __restrict__ partials, const double* __restrict__ ds) {
+                                                  double* __restrict__ partials, const double* __restrict__ ds,
+                                                  unsigned* __restrict__ ticket) {
   __shared__ double s_red[BLOCK / 64];
   if (sc[S_DONE] != 0.0) return;
   const double alpha = sc[S_ALPHA];
@@ -97,27 +98,34 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_s(i64 n, const double* __restric
   const double t1 = block_sum(a1, s_red);
   if (threadIdx.x == 0) partials[3 * (size_t)gridDim.x + blockIdx.x] = t1;
   const double tw = block_sum(aw, s_red);
-  if (threadIdx.x == 0) partials[4 * (size_t)gridDim.x + blockIdx.x] = tw;
+  if (!ticket) {
+    if (threadIdx.x == 0) partials[4 * (size_t)gridDim.x + blockIdx.x] = tw;
+    return;
+  }
+  // the half-step test (PH_BICG_S) inside this launch: the last block to arrive sums slot 4 in k_finalize's order and
+  // derives (one rank: no all-reduce in between) -- a scalar kernel and its gap less per half step
+  double* slot4 = partials + 4 * (size_t)gridDim.x;
+  if (threadIdx.x == 0) store_partial(slot4 + blockIdx.x, tw);
+  if (!last_block_arrives(ticket, gridDim.x, s_red)) return;
+  double a = 0.0;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += BLOCK) a += load_partial(slot4 + i);
+  const double t = block_sum(a, s_red);
+  if (threadIdx.x == 0) {
+    sc[S_RED0 + 4] = t;
+    derive(PH_BICG_S, sc);
+  }
 }
 
-// the half step accepted (PH_BICG_S): x += αp, r = s stands, the iteration counts, done
+// the half step accepted (PH_BICG_S: derive has set S_DONE and S_HALF = this iteration's number): x += αp; r = s stands
 // fresh != 0: x is the accumulated solution of the preconditioned system, which starts at zero and has not been written yet
 // in the first iteration -- assigned instead of read (its memset and its first read are saved)
-__global__ __launch_bounds__(BLOCK) void k_bicg_half(i64 n, double* sc, const double* __restrict__ p, double* __restrict__ x,
-                                                     int fresh) {
-  if (sc[S_DONE] != 0.0 || sc[S_HALF] == 0.0) return;
+__global__ __launch_bounds__(BLOCK) void k_bicg_half(i64 n, const double* __restrict__ sc, const double* __restrict__ p,
+                                                     double* __restrict__ x, int fresh, int iteration) {
+  if (sc[S_HALF] != (double)iteration) return;
   const double alpha = sc[S_ALPHA];
-  const bool first = fresh != 0 && sc[S_ITERS] == 0.0;
+  const bool first = fresh != 0 && iteration == 1;
   for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK)
     x[i] = (first ? 0.0 : x[i]) + alpha * p[i];
-}
-// (separate launch: every block of k_bicg_half must have read the flags before they change)
-__global__ void k_bicg_half_done(double* sc) {
-  if (sc[S_DONE] != 0.0 || sc[S_HALF] == 0.0) return;
-  sc[S_RR] = sc[S_RED4];
-  sc[S_ITERS] += 1.0;
-  sc[S_PENDING3] = 0.0;
-  sc[S_DONE] = 1.0;
 }
 
 // x += αp + ωs;  r = s - ωt;  p = r + β(p - ωv)  (restart: p = r̂ = r);  partial slot 1 = (r,r)_W (convergence, weights
@@ -463,61 +471,83 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
   // the same number of iterations, so the first batch runs up to one short of the previous solve's count and the
   // next few polls come after every iteration: no iterations are queued past convergence (each would still cost
   // its launch overheads), at the price of two or three extra stream syncs per solve.
-  int launched = 0, polls = 0;
+  // With the half-step test a batch is counted in HALVES and may end in the middle of an iteration: when the previous
+  // solve ended at a half step (the usual case: 3 applications of the polynomial), the second half of the last iteration
+  // is not queued at all -- its 1 + m launches would each find the done flag and return, at ~5 us apiece.
+  int launched = 0, polls = 0;          // launched: iterations whose first half is queued
+  bool mid = false;                     // ... and the second half of the last one is not
   bool done = false, poly_failed = false;
   const int poly_give_up = 40 + 400 / std::max(m, 1);   // iterations; an admitted system needs 2 .. 10
+  const int derive_here = (cx.nranks == 1 && !cx.comm) ? 1 : 0;
+  // out = C in = in - R(Â) in with the dots of `mode_last` (5: (r̂,out); 6: (out,in), (out,out), (r̂,out)); the plain
+  // iteration applies Â itself (modes 1 / 3)
+  auto apply = [&](double* in, double* out, int phase, int nslots, int itn) {
+    const bool second = phase == PH_BICG_2;
+    double* src = in;
+    if (m > 1) timer.begin(st, itn, true, second, m - 1);
+    for (int k = 0; k + 1 < m; ++k) {
+      double* dst = (k & 1) ? w.wb.p : w.wa.p;
+      FinArgs f{nullptr, nullptr, PH_NONE, 0, 0, nullptr};
+      f.pc0 = 1.0; f.pc1 = -tau[k];
+      spmv_with_halo(4, A, nb, slab, src, dst, nullptr, nullptr, w.sc.p, G, st, &f);   // w <- w - τ_k Â w
+      src = dst;
+    }
+    if (m > 1) timer.end(st);
+    // the scalar phase that follows is evaluated by the last block of the launch (stencil-slice kernel); with
+    // several ranks the halo exchange of the input overlaps the rows that need no ghost value (spmv_with_halo)
+    FinArgs f{w.ticket.p, w.sc.p, phase, nslots, derive_here, nullptr};
+    int mode = phase == PH_BICG_1 ? 1 : 3;
+    if (poly) {
+      mode = phase == PH_BICG_1 ? 5 : 6;
+      f.pc0 = 1.0; f.pc1 = -tau[m - 1];
+      f.base = in;      // mode 5: out = in - (w - τ_m Â w)
+      f.dotx = in;      // mode 6: the same, `in` is the operand of the (out, in) dot as well
+    }
+    timer.begin(st, itn, false, second);
+    const bool folded = spmv_with_halo(mode, A, nb, slab, src, out, w.rhat.p, w.partials.p, w.sc.p, G, st, &f);
+    timer.end(st);
+    if (folded) finalize_folded(phase, nslots, w, st); else finalize(phase, nslots, w, st, true);
+  };
+  auto first_half = [&](int itn) {
+    apply(w.p.p, w.v.p, PH_BICG_1, 3, itn);     // v = C p, (r̂,v); previous iteration's (r,r): convergence / restart; then α
+    unsigned* tk = (half_test && derive_here) ? w.ticket.p : nullptr;   // the half-step test inside k_bicg_s
+    if (ntv) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_s<true>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p, (const double*)A.ds.p, tk);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_s<false>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p, (const double*)A.ds.p, tk);
+    if (half_test) {   // does s already meet the tolerance?  then x += αp and stop: the second half is 1 + m launches
+      if (!tk) finalize(PH_BICG_S, 1, w, st, true, 4);
+      hipLaunchKernelGGL(k_bicg_half, dim3(G), dim3(BLOCK), 0, st, n, (const double*)w.sc.p, (const double*)w.p.p, xit, poly ? 1 : 0, itn + 1);
+    }
+  };
+  auto second_half = [&](int itn) {
+    apply(w.r.p, w.t.p, PH_BICG_2, 5, itn);     // t = C s (r holds s), (t,s), (t,t), (r̂,t); then ω, ρ, β / restart
+    if (ntv) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_xrp<true>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.t.p, w.v.p, xit, w.r.p,
+                                w.p.p, w.rhat.p, w.partials.p, (const double*)A.ds.p, poly ? 1 : 0);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_xrp<false>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.t.p, w.v.p, xit, w.r.p,
+                            w.p.p, w.rhat.p, w.partials.p, (const double*)A.ds.p, poly ? 1 : 0);
+  };
   while (!done) {
     int want = check_every;
     if (w.last_iters > 1) want = polls == 0 ? w.last_iters - 1 : (polls <= 4 ? 1 : check_every);
     if (expect_halves > 0) want = polls == 0 ? (expect_halves + 1) / 2 : (polls <= 4 ? 1 : check_every);   // the predicted count at once
     const int batch = std::max(1, std::min(want, maxiter - launched));
+    int halves = 2 * batch;
+    static const bool half_batches = getenv("PG_HALF_BATCH") ? atoi(getenv("PG_HALF_BATCH")) != 0 : true;   // (0: whole iterations, for A/B runs)
+    if (!cg && half_test && half_batches && expect_halves > 0 && polls == 0) halves = std::max(1, std::min(expect_halves, 2 * (maxiter - launched)));
     ++polls;
-    for (int it = 0; it < batch; ++it) {
-      if (!cg) {
-        // out = C in = in - R(Â) in with the dots of `mode_last` (5: (r̂,out); 6: (out,in), (out,out), (r̂,out)); the plain
-        // iteration applies Â itself (modes 1 / 3)
-        const int derive_here = (cx.nranks == 1 && !cx.comm) ? 1 : 0;
-        auto apply = [&](double* in, double* out, int phase, int nslots) {
-          const bool second = phase == PH_BICG_2;
-          double* src = in;
-          if (m > 1) timer.begin(st, launched + it, true, second, m - 1);
-          for (int k = 0; k + 1 < m; ++k) {
-            double* dst = (k & 1) ? w.wb.p : w.wa.p;
-            FinArgs f{nullptr, nullptr, PH_NONE, 0, 0, nullptr};
-            f.pc0 = 1.0; f.pc1 = -tau[k];
-            spmv_with_halo(4, A, nb, slab, src, dst, nullptr, nullptr, w.sc.p, G, st, &f);   // w <- w - τ_k Â w
-            src = dst;
-          }
-          if (m > 1) timer.end(st);
-          // the scalar phase that follows is evaluated by the last block of the launch (stencil-slice kernel); with
-          // several ranks the halo exchange of the input overlaps the rows that need no ghost value (spmv_with_halo)
-          FinArgs f{w.ticket.p, w.sc.p, phase, nslots, derive_here, nullptr};
-          int mode = phase == PH_BICG_1 ? 1 : 3;
-          if (poly) {
-            mode = phase == PH_BICG_1 ? 5 : 6;
-            f.pc0 = 1.0; f.pc1 = -tau[m - 1];
-            f.base = in;      // mode 5: out = in - (w - τ_m Â w)
-            f.dotx = in;      // mode 6: the same, `in` is the operand of the (out, in) dot as well
-          }
-          timer.begin(st, launched + it, false, second);
-          const bool folded = spmv_with_halo(mode, A, nb, slab, src, out, w.rhat.p, w.partials.p, w.sc.p, G, st, &f);
-          timer.end(st);
-          if (folded) finalize_folded(phase, nslots, w, st); else finalize(phase, nslots, w, st, true);
-        };
-        apply(w.p.p, w.v.p, PH_BICG_1, 3);     // v = C p, (r̂,v); previous iteration's (r,r): convergence / restart; then α
-        if (ntv) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_s<true>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p, (const double*)A.ds.p);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_s<false>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p, (const double*)A.ds.p);
-        if (half_test) {   // does s already meet the tolerance?  then x += αp and stop: the second half is 1 + m launches
-          finalize(PH_BICG_S, 1, w, st, true, 4);
-          hipLaunchKernelGGL(k_bicg_half, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, (const double*)w.p.p, xit, poly ? 1 : 0);
-          hipLaunchKernelGGL(k_bicg_half_done, dim3(1), dim3(1), 0, st, w.sc.p);
+    if (!cg) {
+      for (int h = 0; h < halves; ++h) {
+        if (!mid) {
+          if (launched >= maxiter) break;
+          first_half(launched);
+          ++launched;
+          mid = true;
+        } else {
+          second_half(launched - 1);
+          mid = false;
         }
-        apply(w.r.p, w.t.p, PH_BICG_2, 5);     // t = C s (r holds s), (t,s), (t,t), (r̂,t); then ω, ρ, β / restart
-        if (ntv) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_xrp<true>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.t.p, w.v.p, xit, w.r.p,
-                                    w.p.p, w.rhat.p, w.partials.p, (const double*)A.ds.p, poly ? 1 : 0);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_xrp<false>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.t.p, w.v.p, xit, w.r.p,
-                                w.p.p, w.rhat.p, w.partials.p, (const double*)A.ds.p, poly ? 1 : 0);
-      } else {
+      }
+    } else {
+      for (int it = 0; it < batch; ++it) {
         timer.begin(st, launched + it);
         spmv_with_halo(2, A, nb, slab, w.p.p, w.v.p, nullptr, w.partials.p, w.sc.p, G, st);   // v = A p ; (v.p), (v.v)
         timer.end(st);
@@ -526,13 +556,13 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
         finalize(PH_CG_2, 2, w, st, true);
         hipLaunchKernelGGL(k_cg_p, dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.r.p, w.p.p);
       }
+      launched += batch;
     }
-    if (!cg) finalize(PH_BICG_3, 2, w, st, true, 1);   // the last iteration's (r,r), not yet folded into a next one
+    if (!cg && !mid) finalize(PH_BICG_3, 2, w, st, true, 1);   // the last iteration's (r,r), not yet folded into a next one
     PG_HIP(hipGetLastError());
-    launched += batch;
     PG_HIP(hipMemcpyAsync(w.h_sc, w.sc.p, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, st));
     PG_HIP(hipStreamSynchronize(st));
-    if (w.h_sc[S_DONE] != 0.0 || launched >= maxiter) done = true;
+    if (w.h_sc[S_DONE] != 0.0 || (launched >= maxiter && !mid)) done = true;
     // safety net of the polynomial preconditioner: its roots assume a (nearly) real spectrum inside the Gershgorin
     // interval; a matrix that defeats that assumption shows as stagnation, and the solve falls back to the plain iteration
     // from the iterate reached (the matrix keeps the verdict)

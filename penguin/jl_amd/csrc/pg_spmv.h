@@ -119,7 +119,15 @@ __device__ inline void derive(int phase, double* sc) {
       // half step: s = r - αv already meets the tolerance (S_RED4 = (s,s)_W): x += αp and stop (k_bicg_half) -- with a
       // polynomial of degree m in every application of the operator a whole iteration is 2m products, worth testing in
       // the middle
-      if (sc[S_DONE] == 0.0 && sc[S_RED4] <= sc[S_TOL2]) sc[S_HALF] = 1.0;
+      // (S_HALF = the number of the iteration that ended this way: k_bicg_half applies x += αp in that iteration only --
+      // iterations queued past it find S_DONE set and must not repeat the update)
+      if (sc[S_DONE] == 0.0 && sc[S_RED4] <= sc[S_TOL2]) {
+        sc[S_RR] = sc[S_RED4];
+        sc[S_ITERS] += 1.0;
+        sc[S_PENDING3] = 0.0;
+        sc[S_DONE] = 1.0;
+        sc[S_HALF] = sc[S_ITERS];
+      }
       break;
     case PH_CG_1:
       if (r0 == 0.0) sc[S_DONE] = 2.0; else sc[S_ALPHA] = sc[S_RR] / r0;

@@ -14,6 +14,6 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCP
   timeout -k 5 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/pmc_${tag}_$i -- python3 scripts/dev_perf.py 512 4 > gpurun_out/pmc_${tag}_$i.log 2>&1
   echo "pmc pass $i ($set) rc=$?" >> gpurun_out/prof_${tag}_progress.txt
 done
-python3 scripts/pmc_traffic_json.py gpurun_out/pmc_${tag} $(ls gpurun_out/prof_$tag/*/*kernel_stats.csv gpurun_out/prof_$tag/*kernel_stats.csv 2>/dev/null | head -1) > gpurun_out/prof_${tag}_traffic.json 2> gpurun_out/prof_${tag}_traffic.err
+python3 scripts/pmc_traffic_json.py gpurun_out/pmc_${tag} $(ls gpurun_out/prof_$tag/*/*kernel_trace.csv gpurun_out/prof_$tag/*kernel_trace.csv 2>/dev/null | head -1) > gpurun_out/prof_${tag}_traffic.json 2> gpurun_out/prof_${tag}_traffic.err
 cat gpurun_out/prof_${tag}_progress.txt
 cat gpurun_out/prof_${tag}_traffic.json
