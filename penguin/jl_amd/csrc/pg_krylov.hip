@@ -249,6 +249,22 @@ __global__ void k_sc_reset(double* sc, double reltol2, double abstol2) {
   if (i < S_COUNT) sc[i] = i == S_RELTOL2 ? reltol2 : (i == S_ABSTOL2 ? abstol2 : 0.0);
 }
 
+// k_sc_reset + the start phase's k_finalize in one launch (one rank, BiCGStab with a prepared start: nothing reads the
+// scalars in between)
+__global__ __launch_bounds__(BLOCK) void k_start(int phase, int nslots, int grid, const double* __restrict__ partials,
+                                                 double* __restrict__ sc, double reltol2, double abstol2) {
+  __shared__ double s_red[BLOCK / 64];
+  if (threadIdx.x < S_COUNT) sc[threadIdx.x] = threadIdx.x == S_RELTOL2 ? reltol2 : (threadIdx.x == S_ABSTOL2 ? abstol2 : 0.0);
+  __syncthreads();
+  for (int s = 0; s < nslots; ++s) {
+    double a = 0.0;
+    for (int i = threadIdx.x; i < grid; i += BLOCK) a += partials[(size_t)s * grid + i];
+    const double t = block_sum(a, s_red);
+    if (threadIdx.x == 0) sc[S_RED0 + s] = t;
+  }
+  if (threadIdx.x == 0) derive(phase, sc);
+}
+
 __global__ void k_derive(int phase, double* sc, int check_done) {
   if (check_done && sc[S_DONE] != 0.0) return;
   derive(phase, sc);
@@ -416,7 +432,9 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
     maxiter = 100000;
   }
   // tolerances -> device scalars (a one-thread kernel: a host-to-device copy out of pageable memory stalls the stream)
-  hipLaunchKernelGGL(k_sc_reset, dim3(1), dim3(S_COUNT), 0, st, w.sc.p, opts.reltol * opts.reltol, opts.abstol * opts.abstol);
+  const bool fused_start = preinit && opts.method == PG_METHOD_BICGSTAB && cx.nranks == 1 && !cx.comm;   // k_start below
+  if (!fused_start)
+    hipLaunchKernelGGL(k_sc_reset, dim3(1), dim3(S_COUNT), 0, st, w.sc.p, opts.reltol * opts.reltol, opts.abstol * opts.abstol);
   SpmvTimer timer(cx.profiling);
 
   const bool cg = opts.method == PG_METHOD_CG;
@@ -460,7 +478,12 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
     if (!preinit)
       hipLaunchKernelGGL(k_bicg_init, dim3(G), dim3(BLOCK), 0, st, n, nvec, b, x0, Ax0, x, w.r.p, w.rhat.p, w.p.p, w.v.p,
                        w.partials.p, (const double*)A.ds.p);
-    finalize(PH_INIT, 3, w, st, false);
+    static_assert(S_COUNT <= BLOCK, "k_start resets the scalar block with one thread per scalar");
+    if (fused_start)
+      hipLaunchKernelGGL(k_start, dim3(1), dim3(BLOCK), 0, st, (int)PH_INIT, 3, w.grid, (const double*)w.partials.p, w.sc.p,
+                         opts.reltol * opts.reltol, opts.abstol * opts.abstol);
+    else
+      finalize(PH_INIT, 3, w, st, false);
   } else {
     hipLaunchKernelGGL(k_cg_init, dim3(G), dim3(BLOCK), 0, st, n, nvec, b, x, w.r.p, w.p.p, w.partials.p, (const double*)A.ds.p);
     finalize(PH_CG_INIT, 2, w, st, false);
@@ -508,8 +531,12 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
     timer.end(st);
     if (folded) finalize_folded(phase, nslots, w, st); else finalize(phase, nslots, w, st, true);
   };
-  auto first_half = [&](int itn) {
+  // test: make the half-step test in this iteration.  (Not before the half step the previous solve ended at: a solve that
+  // could have stopped one application earlier stops at the end of that iteration instead, which happens about never,
+  // and the k_bicg_half launches of the earlier iterations -- which return at once -- are not queued.)
+  auto first_half = [&](int itn, bool test) {
     apply(w.p.p, w.v.p, PH_BICG_1, 3, itn);     // v = C p, (r̂,v); previous iteration's (r,r): convergence / restart; then α
+    const bool half_test = test;
     unsigned* tk = (half_test && derive_here) ? w.ticket.p : nullptr;   // the half-step test inside k_bicg_s
     if (ntv) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_s<true>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p, (const double*)A.ds.p, tk);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_s<false>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p, (const double*)A.ds.p, tk);
@@ -525,20 +552,21 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_xrp<false>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.t.p, w.v.p, xit, w.r.p,
                             w.p.p, w.rhat.p, w.partials.p, (const double*)A.ds.p, poly ? 1 : 0);
   };
+  static const bool half_batches = getenv("PG_HALF_BATCH") ? atoi(getenv("PG_HALF_BATCH")) != 0 : true;   // (0: whole iterations, for A/B runs)
   while (!done) {
     int want = check_every;
     if (w.last_iters > 1) want = polls == 0 ? w.last_iters - 1 : (polls <= 4 ? 1 : check_every);
     if (expect_halves > 0) want = polls == 0 ? (expect_halves + 1) / 2 : (polls <= 4 ? 1 : check_every);   // the predicted count at once
     const int batch = std::max(1, std::min(want, maxiter - launched));
     int halves = 2 * batch;
-    static const bool half_batches = getenv("PG_HALF_BATCH") ? atoi(getenv("PG_HALF_BATCH")) != 0 : true;   // (0: whole iterations, for A/B runs)
     if (!cg && half_test && half_batches && expect_halves > 0 && polls == 0) halves = std::max(1, std::min(expect_halves, 2 * (maxiter - launched)));
     ++polls;
     if (!cg) {
+      const bool predicted = half_test && half_batches && expect_halves > 0 && polls == 1;
       for (int h = 0; h < halves; ++h) {
         if (!mid) {
           if (launched >= maxiter) break;
-          first_half(launched);
+          first_half(launched, half_test && (!predicted || h + 2 >= halves));
           ++launched;
           mid = true;
         } else {
