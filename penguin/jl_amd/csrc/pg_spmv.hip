@@ -456,6 +456,9 @@ __device__ inline void slice_dispatch(int cnt, const SDesc& d, int nrows, int re
 #ifndef PG_MARCH_K
 #define PG_MARCH_K 4
 #endif
+#ifndef PG_MARCH_SPLIT
+#define PG_MARCH_SPLIT 1
+#endif
 constexpr int MARCH_K = PG_MARCH_K, MARCH_KS = 2, MARCH_REC = 64, MARCH_W = 126;   // planes per unit: full / short units
 static_assert(MARCH_K > MARCH_KS && 18 + 4 * MARCH_K <= MARCH_REC, "unit record layout");
 
@@ -534,7 +537,9 @@ __device__ __forceinline__ double march_plane(const double (&c)[CNT], int rng, i
 // compiler issues them up front (as far as registers allow) and the wave pays ONE memory round trip per unit.  A loop
 // over the planes with prefetch registers did not get there: the registers carried around the back edge are copied,
 // and a copy waits for the load that fills it (2.2 us per plane, measured).
-template <int CNT, int MODE, int KK>
+// (Q0, KTOT: planes [Q0, Q0 + KK) of a unit of KTOT planes -- the launches with fused dots take a full unit in two halves,
+// see march_dispatch)
+template <int CNT, int MODE, int KK, int Q0 = 0, int KTOT = KK>
 __device__ __forceinline__ void march_unit(int rec, int lane, const double* __restrict__ x, double* __restrict__ y,
                                   const double* __restrict__ pa, const double* __restrict__ pb, double pc0, double pc1,
                                   double pc2, double& acc0, double& acc1, double& acc2, int dbg) {
@@ -559,19 +564,19 @@ __device__ __forceinline__ void march_unit(int rec, int lane, const double* __re
   for (int q = 0; q < KK + 2; ++q) ln[q] = zero;
 #pragma unroll
   for (int q = 0; q < KK; ++q) {
-    rb[q] = rlane(rec, 18 + 4 * q) & amask;
+    rb[q] = rlane(rec, 18 + 4 * (Q0 + q)) & amask;
     sd[q].ym = sd[q].yp = sd[q].ax = sd[q].ax2 = zero;
   }
   if (act) {
-    ln[0] = load_pair<false>(x + (rlane(rec, 16) & amask) + l2);
+    ln[0] = load_pair<false>(x + (rlane(rec, Q0 == 0 ? 16 : 18 + 4 * (Q0 - 1)) & amask) + l2);
 #pragma unroll
     for (int q = 0; q < KK; ++q) ln[q + 1] = load_pair<false>(x + rb[q] + l2);
-    ln[KK + 1] = load_pair<false>(x + (rlane(rec, 17) & amask) + l2);
+    ln[KK + 1] = load_pair<false>(x + (rlane(rec, Q0 + KK == KTOT ? 17 : 18 + 4 * (Q0 + KK)) & amask) + l2);
 #pragma unroll
     for (int q = 0; q < KK; ++q) {
       if (Y && !nolat) {
-        sd[q].ym = load_pair<false>(x + rb[q] + (rlane(rec, 19 + 4 * q) & amask) + l2 + one);
-        sd[q].yp = load_pair<false>(x + rb[q] + (rlane(rec, 20 + 4 * q) & amask) + l2 + one);
+        sd[q].ym = load_pair<false>(x + rb[q] + (rlane(rec, 19 + 4 * (Q0 + q)) & amask) + l2 + one);
+        sd[q].yp = load_pair<false>(x + rb[q] + (rlane(rec, 20 + 4 * (Q0 + q)) & amask) + l2 + one);
       }
       if (MI::HAS_A) sd[q].ax = load_pair<false>(pa + rb[q] + l2 + one);
       if (MI::HAS_B) sd[q].ax2 = load_pair<false>(pb + rb[q] + l2 + one);
@@ -580,7 +585,7 @@ __device__ __forceinline__ void march_unit(int rec, int lane, const double* __re
   double xm_n = lane_up(ln[0].x);
 #pragma unroll
   for (int q = 0; q < KK; ++q)
-    xm_n = march_plane<CNT, MODE>(c, rlane(rec, 21 + 4 * q), l2, y + rb[q] + l2 + one, ln[q], xm_n, ln[q + 1], ln[q + 2], sd[q], pc0,
+    xm_n = march_plane<CNT, MODE>(c, rlane(rec, 21 + 4 * (Q0 + q)), l2, y + rb[q] + l2 + one, ln[q], xm_n, ln[q + 1], ln[q + 2], sd[q], pc0,
                                   pc1, pc2, const_cast<double*>(pa) + rb[q] + l2 + one, acc0, acc1, acc2, dbg);
 }
 
@@ -588,8 +593,20 @@ template <int CNT, int MODE>
 __device__ __forceinline__ void march_dispatch(int rec, int lane, const double* __restrict__ x, double* __restrict__ y,
                                       const double* __restrict__ pa, const double* __restrict__ pb, double pc0, double pc1,
                                       double pc2, double& acc0, double& acc1, double& acc2, int dbg) {
-  if ((rlane(rec, 0) & 255) == MARCH_K) march_unit<CNT, MODE, MARCH_K>(rec, lane, x, y, pa, pb, pc0, pc1, pc2, acc0, acc1, acc2, dbg);
-  else march_unit<CNT, MODE, MARCH_KS>(rec, lane, x, y, pa, pb, pc0, pc1, pc2, acc0, acc1, acc2, dbg);
+  // The launches with fused dots and two more operand vectors per plane (modes 5, 6: the closing launches of the polynomial)
+  // do not fit a unit of MARCH_K planes into the 128 VGPRs of four waves per SIMD (10 / 14 VGPRs went to scratch): they take
+  // it in two halves -- two more line loads per unit, which hit L1
+  constexpr bool SPLIT = (MODE == 5 || MODE == 6) && MARCH_K == 2 * MARCH_KS && PG_MARCH_SPLIT;
+  if ((rlane(rec, 0) & 255) == MARCH_K) {
+    if (SPLIT) {
+      march_unit<CNT, MODE, MARCH_KS, 0, MARCH_K>(rec, lane, x, y, pa, pb, pc0, pc1, pc2, acc0, acc1, acc2, dbg);
+      march_unit<CNT, MODE, MARCH_KS, MARCH_KS, MARCH_K>(rec, lane, x, y, pa, pb, pc0, pc1, pc2, acc0, acc1, acc2, dbg);
+    } else {
+      march_unit<CNT, MODE, MARCH_K>(rec, lane, x, y, pa, pb, pc0, pc1, pc2, acc0, acc1, acc2, dbg);
+    }
+  } else {
+    march_unit<CNT, MODE, MARCH_KS>(rec, lane, x, y, pa, pb, pc0, pc1, pc2, acc0, acc1, acc2, dbg);
+  }
 }
 
 template <int MODE, bool NT>
