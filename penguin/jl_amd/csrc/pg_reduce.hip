@@ -113,10 +113,12 @@ __global__ void k_gamma_couple(i64 n_wg, const int* __restrict__ wg_rows, const 
 }
 
 // the start sums of k_rhs_init, slots 0 = (r,r) and 2 = (r,r)_W, again -- only if the residual really changed
-__global__ __launch_bounds__(BLOCK) void k_renorm(i64 n_w, const int* __restrict__ flag, const double* __restrict__ r,
+// (flag == stamp: some row moved in this step; the Dirichlet-interface variant uses 0 / 1 and resets the flag per step, the
+// compact variant stamps it with the step number -- k_rhs_init_c, pg_solver.hip -- and never resets it)
+__global__ __launch_bounds__(BLOCK) void k_renorm(i64 n_w, const int* __restrict__ flag, int stamp, const double* __restrict__ r,
                                                   const double* __restrict__ ds, double* __restrict__ partials) {
   __shared__ double s_red[BLOCK / 64];
-  if (*flag == 0) return;
+  if (*flag != stamp) return;
   double acc = 0.0, accw = 0.0;
   for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n_w; i += (i64)gridDim.x * BLOCK) {
     const double v = r[i], d = ds[i];
@@ -146,7 +148,7 @@ __global__ void k_maps(i64 n, const int* __restrict__ is_e, const int* __restric
                        int* rlist, int* elist, double* gdiag, double* ds_c) {
   for (i64 r = blockIdx.x * (i64)blockDim.x + threadIdx.x; r < n; r += (i64)gridDim.x * blockDim.x) {
     if (is_e[r]) {
-      cmap[r] = -1;
+      cmap[r] = -1 - pos_e[r];   // (k_rhs_init_c finds the row's entry of gdiag / delta through it)
       elist[pos_e[r]] = (int)r;
       gdiag[pos_e[r]] = val[rowptr[r]];
     } else {
@@ -201,23 +203,12 @@ __global__ void k_c_coupling(i64 n_wg, const int* __restrict__ wg_rows, const in
   }
 }
 
-__global__ void k_e_snap(i64 n_e, const int* __restrict__ elist, const double* __restrict__ gdiag, double* __restrict__ x,
-                         const double* __restrict__ r_full, double* __restrict__ delta, int* flag) {
-  int f = 0;
-  for (i64 e = blockIdx.x * (i64)blockDim.x + threadIdx.x; e < n_e; e += (i64)gridDim.x * blockDim.x) {
-    const int i = elist[e];
-    const double d = r_full[i] / gdiag[e], xo = x[i];
-    delta[e] = d;
-    x[i] = xo + d;
-    if (fabs(d) > 1e-12 * fabs(xo)) f = 1;
-  }
-  if (f) atomicOr(flag, 1);
-}
-
 // coupled remaining rows (compact index cmap[wg_rows[q]]): r -= Â_RE δ, r̂ and p alike
 __global__ void k_c_couple(i64 n_wg, const int* __restrict__ wg_rows, const int* __restrict__ wg_ptr, const int* __restrict__ wg_col,
                            const double* __restrict__ wg_val, const double* __restrict__ delta, const int* __restrict__ cmap,
-                           double* __restrict__ r, double* __restrict__ rhat, double* __restrict__ p) {
+                           double* __restrict__ r, double* __restrict__ rhat, double* __restrict__ p,
+                           const int* __restrict__ flag, int stamp) {
+  if (*flag != stamp) return;   // no diagonal row moved in this step (constant Dirichlet data after the first step)
   for (i64 q = blockIdx.x * (i64)blockDim.x + threadIdx.x; q < n_wg; q += (i64)gridDim.x * blockDim.x) {
     double s = 0.0;
     for (int e = wg_ptr[q]; e < wg_ptr[q + 1]; ++e) s += wg_val[e] * delta[wg_col[e]];
@@ -324,7 +315,7 @@ void gamma_fix(const GammaElim& E, double* x, double* r, double* rhat, double* p
   if (E.n_wg > 0)
     hipLaunchKernelGGL(k_gamma_couple, dim3(grid_for(E.n_wg, 256)), dim3(256), 0, st, E.n_wg, E.wg_rows.p, E.wg_ptr.p, E.wg_col.p,
                        E.wg_val.p, E.delta.p, r, rhat, p);
-  hipLaunchKernelGGL(k_renorm, dim3(grid), dim3(BLOCK), 0, st, E.n_w, E.flag.p, r, E.A.ds.p, partials);
+  hipLaunchKernelGGL(k_renorm, dim3(grid), dim3(BLOCK), 0, st, E.n_w, (const int*)E.flag.p, 1, (const double*)r, E.A.ds.p, partials);
   PG_HIP(hipGetLastError());
 }
 
@@ -348,6 +339,7 @@ void build_diag_elim(const CsrMatrix& A, const Numbering& nb, DiagElim& E) {
   if (n_e * 50 < n || n_c <= 0) return;             // fewer than 2 % of the rows: not worth a second matrix
   E.n = n; E.n_c = n_c; E.n_e = n_e;
   E.cmap.alloc(n); E.rlist.alloc(n_c); E.elist.alloc(n_e); E.gdiag.alloc(n_e); E.delta.alloc(n_e); E.flag.alloc(1);
+  E.flag.zero();   // (stamped with the step number when a diagonal row moves: k_rhs_init_c; never reset)
   CsrMatrix& R = E.A;
   R.n = n_c;
   R.scheme = A.scheme;
@@ -411,15 +403,12 @@ void build_diag_elim(const CsrMatrix& A, const Numbering& nb, DiagElim& E) {
             (long long)A.nnz, n_wg, nnz_g, (long long)A.rows_g, (long long)R.rows_g);
 }
 
-void diag_fix(const DiagElim& E, double* x, double* r_full, double* r, double* rhat, double* p, double* partials, int grid,
-              hipStream_t st) {
-  PG_HIP(hipMemsetAsync(E.flag.p, 0, sizeof(int), st));
-  hipLaunchKernelGGL(k_e_snap, dim3(grid_for(E.n_e, 256)), dim3(256), 0, st, E.n_e, E.elist.p, E.gdiag.p, x, (const double*)r_full,
-                     E.delta.p, E.flag.p);
+void diag_fix(const DiagElim& E, int stamp, double* r, double* rhat, double* p, double* partials, int grid, hipStream_t st) {
+  // (the rows themselves were solved by k_rhs_init_c: x += δ, δ kept in E.delta, E.flag = stamp if any δ != 0)
   if (E.n_wg > 0)
     hipLaunchKernelGGL(k_c_couple, dim3(grid_for(E.n_wg, 256)), dim3(256), 0, st, E.n_wg, E.wg_rows.p, E.wg_ptr.p, E.wg_col.p, E.wg_val.p,
-                       E.delta.p, E.cmap.p, r, rhat, p);
-  hipLaunchKernelGGL(k_renorm, dim3(grid), dim3(BLOCK), 0, st, E.n_c, E.flag.p, (const double*)r, E.A.ds.p, partials);
+                       E.delta.p, E.cmap.p, r, rhat, p, (const int*)E.flag.p, stamp);
+  hipLaunchKernelGGL(k_renorm, dim3(grid), dim3(BLOCK), 0, st, E.n_c, (const int*)E.flag.p, stamp, (const double*)r, E.A.ds.p, partials);
   PG_HIP(hipGetLastError());
 }
 

@@ -291,18 +291,21 @@ __global__ __launch_bounds__(BLOCK) void k_rhs_init(i64 n, i64 nvec, int scheme,
 }
 
 // k_rhs_init for a COMPACT loop system (pg_reduce.hip, DiagElim): cmap[i] >= 0: the row stays, r = r̂ = p go to that index of
-// the compact vectors and count in the start sums; cmap[i] < 0: the row is alone on its diagonal, its residual is kept at
-// r_e[i] (the snap needs it) and is left out of the sums.  b̂ is written for every row, (b̂,b̂)_W sums over all of them.
-__global__ __launch_bounds__(BLOCK) void k_rhs_init_c(i64 n, int scheme, const double* __restrict__ z,
+// the compact vectors and count in the start sums; cmap[i] = -1 - e: the row is alone on its diagonal (entry e of gdiag /
+// delta): solved on the spot, left out of the sums.  b̂ is written for every row, (b̂,b̂)_W sums over all of them.
+__global__ __launch_bounds__(BLOCK) void k_rhs_init_c(i64 n, int scheme, const double* z,
                                                       const double* __restrict__ yhat, const double* __restrict__ ds,
                                                       const double* __restrict__ mass, const double* __restrict__ bconst,
                                                       const unsigned char* __restrict__ fixed,
                                                       const unsigned char* __restrict__ isblk, const int* __restrict__ cmap,
-                                                      double* __restrict__ b, double* __restrict__ r_e, double* __restrict__ r,
-                                                      double* __restrict__ rhat, double* __restrict__ p,
+                                                      double* __restrict__ b, const double* __restrict__ gdiag,
+                                                      double* __restrict__ delta, int* __restrict__ flag, int stamp,
+                                                      double* __restrict__ r, double* __restrict__ rhat, double* __restrict__ p,
                                                       double* __restrict__ partials) {
   __shared__ double s_red[BLOCK / 64];
   double acc = 0.0, accb = 0.0, accw = 0.0;
+  int moved = 0;
+  double* zw = const_cast<double*>(z);   // (a lane writes only elements it has read itself)
   auto one = [&](i64 i, double zi, double yh, double d, double ms, double bc, bool fx, bool blk, double bold, int c, double& bi) {
     double ri;
     rhs_init_one(scheme, zi, yh, d, ms, bc, fx, blk, bold, bi, ri);
@@ -312,7 +315,13 @@ __global__ __launch_bounds__(BLOCK) void k_rhs_init_c(i64 n, int scheme, const d
       acc += ri * ri;
       accw += (d * ri) * (d * ri);
     } else {
-      r_e[i] = ri;
+      // a row alone on its diagonal: solved here, x += δ = r / a_ii (δ = 0 once the row's datum has stopped changing);
+      // δ is what the rows coupled to it need (diag_fix), the flag says whether any δ of this step is non-zero
+      const int e = -1 - c;
+      const double dl = ri / gdiag[e];
+      delta[e] = dl;
+      if (dl != 0.0) zw[i] = zi + dl;
+      if (fabs(dl) > 1e-12 * fabs(zi)) moved = 1;
     }
   };
   // two rows per lane, 16-byte loads of the seven input streams (as k_rhs_init); the compact stores are 8-byte
@@ -343,6 +352,7 @@ __global__ __launch_bounds__(BLOCK) void k_rhs_init_c(i64 n, int scheme, const d
       b[i] = b0;
     }
   }
+  if (__any(moved) && (threadIdx.x & 63) == 0) atomicMax(flag, stamp);
   const double t = block_sum(acc, s_red);
   if (threadIdx.x == 0) partials[blockIdx.x] = t;
   const double tb = block_sum(accb, s_red);
@@ -756,11 +766,13 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
     if (!DE.tried) build_diag_elim(A, s->nb, DE);
     bool solved = false;
     if (DE.active && krylov_uses_polynomial(DE.A, o)) {
-      // r = r̂ = p of the remaining rows go straight to the compact vectors, the residuals of the others to scratch (t)
+      // r = r̂ = p of the remaining rows go straight to the compact vectors; the other rows are solved in the same pass
+      const int stamp = (int)((s->steps_done % 2000000000) + 1);   // marks E.flag when a diagonal row moved in THIS step
       hipLaunchKernelGGL(k_rhs_init_c, dim3(w.grid), dim3(BLOCK), 0, stream, n, scheme, s->z.p, s->y.p, A.ds.p, s->mass.p, s->bconst.p,
-                         s->fixed.p, A.isblk.p, DE.cmap.p, s->b.p, w.t.p, w.r.p, w.rhat.p, w.p.p, w.partials.p);
+                         s->fixed.p, A.isblk.p, DE.cmap.p, s->b.p, (const double*)DE.gdiag.p, DE.delta.p, DE.flag.p, stamp, w.r.p, w.rhat.p,
+                         w.p.p, w.partials.p);
       PG_HIP(hipGetLastError());
-      diag_fix(DE, s->z.p, w.t.p, w.r.p, w.rhat.p, w.p.p, w.partials.p, w.grid, stream);
+      diag_fix(DE, stamp, w.r.p, w.rhat.p, w.p.p, w.partials.p, w.grid, stream);
       w.scatter = DE.rlist.p;
       try {
         krylov_solve(DE.A, DE.nb, s->slab, nullptr, s->z.p, w, o, st, nullptr, nullptr, true);
