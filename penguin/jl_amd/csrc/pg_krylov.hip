@@ -138,15 +138,16 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_xrp(i64 n, double* sc, const dou
                                                     const double* __restrict__ v, double* __restrict__ x,
                                                     double* __restrict__ r, double* __restrict__ p,
                                                     double* __restrict__ rhat, double* __restrict__ partials,
-                                                    const double* __restrict__ ds, int fresh) {
+                                                    const double* __restrict__ ds, int fresh, int p_in_rhat) {
   __shared__ double s_red[BLOCK / 64];
   if (sc[S_DONE] != 0.0) return;
   const double alpha = sc[S_ALPHA], omega = sc[S_OMEGA], beta = sc[S_BETA];
   const bool restart = sc[S_RESTART] != 0.0;
   const bool first = fresh != 0 && sc[S_ITERS] == 0.0;   // (see k_bicg_half)
+  const bool prhat = p_in_rhat != 0 && sc[S_ITERS] == 0.0;   // first iteration of a start that left p = r̂ unwritten
   double a0 = 0.0, aw = 0.0;
   for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) {
-    const double si = r[i], pi = p[i];
+    const double si = r[i], pi = prhat ? rhat[i] : p[i];
     const double xi = (first ? 0.0 : (NTV ? __builtin_nontemporal_load(x + i) : x[i])) + alpha * pi + omega * si;
     if (NTV) __builtin_nontemporal_store(xi, x + i); else x[i] = xi;
     const double ri = si - omega * (NTV ? __builtin_nontemporal_load(t + i) : t[i]);
@@ -432,6 +433,8 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
     maxiter = 100000;
   }
   // tolerances -> device scalars (a one-thread kernel: a host-to-device copy out of pageable memory stalls the stream)
+  const bool p_in_rhat = w.p_in_rhat && preinit && opts.method == PG_METHOD_BICGSTAB;
+  w.p_in_rhat = false;
   const bool fused_start = preinit && opts.method == PG_METHOD_BICGSTAB && cx.nranks == 1 && !cx.comm;   // k_start below
   if (!fused_start)
     hipLaunchKernelGGL(k_sc_reset, dim3(1), dim3(S_COUNT), 0, st, w.sc.p, opts.reltol * opts.reltol, opts.abstol * opts.abstol);
@@ -535,22 +538,23 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
   // could have stopped one application earlier stops at the end of that iteration instead, which happens about never,
   // and the k_bicg_half launches of the earlier iterations -- which return at once -- are not queued.)
   auto first_half = [&](int itn, bool test) {
-    apply(w.p.p, w.v.p, PH_BICG_1, 3, itn);     // v = C p, (r̂,v); previous iteration's (r,r): convergence / restart; then α
+    double* pvec = (p_in_rhat && itn == 0) ? w.rhat.p : w.p.p;
+    apply(pvec, w.v.p, PH_BICG_1, 3, itn);     // v = C p, (r̂,v); previous iteration's (r,r): convergence / restart; then α
     const bool half_test = test;
     unsigned* tk = (half_test && derive_here) ? w.ticket.p : nullptr;   // the half-step test inside k_bicg_s
     if (ntv) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_s<true>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p, (const double*)A.ds.p, tk);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_s<false>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p, (const double*)A.ds.p, tk);
     if (half_test) {   // does s already meet the tolerance?  then x += αp and stop: the second half is 1 + m launches
       if (!tk) finalize(PH_BICG_S, 1, w, st, true, 4);
-      hipLaunchKernelGGL(k_bicg_half, dim3(G), dim3(BLOCK), 0, st, n, (const double*)w.sc.p, (const double*)w.p.p, xit, poly ? 1 : 0, itn + 1);
+      hipLaunchKernelGGL(k_bicg_half, dim3(G), dim3(BLOCK), 0, st, n, (const double*)w.sc.p, (const double*)pvec, xit, poly ? 1 : 0, itn + 1);
     }
   };
   auto second_half = [&](int itn) {
     apply(w.r.p, w.t.p, PH_BICG_2, 5, itn);     // t = C s (r holds s), (t,s), (t,t), (r̂,t); then ω, ρ, β / restart
     if (ntv) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_xrp<true>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.t.p, w.v.p, xit, w.r.p,
-                                w.p.p, w.rhat.p, w.partials.p, (const double*)A.ds.p, poly ? 1 : 0);
+                                w.p.p, w.rhat.p, w.partials.p, (const double*)A.ds.p, poly ? 1 : 0, p_in_rhat ? 1 : 0);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_xrp<false>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.t.p, w.v.p, xit, w.r.p,
-                            w.p.p, w.rhat.p, w.partials.p, (const double*)A.ds.p, poly ? 1 : 0);
+                            w.p.p, w.rhat.p, w.partials.p, (const double*)A.ds.p, poly ? 1 : 0, p_in_rhat ? 1 : 0);
   };
   static const bool half_batches = getenv("PG_HALF_BATCH") ? atoi(getenv("PG_HALF_BATCH")) != 0 : true;   // (0: whole iterations, for A/B runs)
   while (!done) {

@@ -212,7 +212,7 @@ __global__ void k_rhs_block(i64 nblk, int scheme, const int* __restrict__ blk_ro
 
 // K8 + the BiCGStab start in one pass (loop form, warm start): from the scaled state z and ŷ = Âz
 //   b̂ = S(2 mass∘(S z) + bconst) - ŷ  (CN) | S(mass∘(S z) + bconst) (BE) | S bconst (fixed rows) | as written by k_rhs_block
-//   r = r̂ = p = b̂ - ŷ,  x = z (in place),  partial sums of (r,r) and (b̂,b̂) in slots 0 / 1
+//   r = r̂ = p = b̂ - ŷ,  x = z (in place),  partial sums of (r,r) and (b̂,b̂) in slots 0 / 1   (k_rhs_init_c: r = r̂ only)
 // replaces k_rhs + k_bicg_init: 9.3 instead of 14.1 vector passes, and no separate scaling kernels per step
 typedef double rd2_t __attribute__((ext_vector_type(2)));
 typedef unsigned char ruc2_t __attribute__((ext_vector_type(2)));
@@ -300,8 +300,9 @@ __global__ __launch_bounds__(BLOCK) void k_rhs_init_c(i64 n, int scheme, const d
                                                       const unsigned char* __restrict__ isblk, const int* __restrict__ cmap,
                                                       double* __restrict__ b, const double* __restrict__ gdiag,
                                                       double* __restrict__ delta, int* __restrict__ flag, int stamp,
-                                                      double* __restrict__ r, double* __restrict__ rhat, double* __restrict__ p,
+                                                      double* __restrict__ r, double* __restrict__ rhat,
                                                       double* __restrict__ partials) {
+  // (p = r̂ is NOT written: the first iteration reads r̂ for it, KrylovWork::p_in_rhat)
   __shared__ double s_red[BLOCK / 64];
   double acc = 0.0, accb = 0.0, accw = 0.0;
   int moved = 0;
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(BLOCK) void k_rhs_init_c(i64 n, int scheme, const d
     rhs_init_one(scheme, zi, yh, d, ms, bc, fx, blk, bold, bi, ri);
     accb += (d * bi) * (d * bi);
     if (c >= 0) {
-      r[c] = ri; rhat[c] = ri; p[c] = ri;
+      r[c] = ri; rhat[c] = ri;
       acc += ri * ri;
       accw += (d * ri) * (d * ri);
     } else {
@@ -770,10 +771,11 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
       const int stamp = (int)((s->steps_done % 2000000000) + 1);   // marks E.flag when a diagonal row moved in THIS step
       hipLaunchKernelGGL(k_rhs_init_c, dim3(w.grid), dim3(BLOCK), 0, stream, n, scheme, s->z.p, s->y.p, A.ds.p, s->mass.p, s->bconst.p,
                          s->fixed.p, A.isblk.p, DE.cmap.p, s->b.p, (const double*)DE.gdiag.p, DE.delta.p, DE.flag.p, stamp, w.r.p, w.rhat.p,
-                         w.p.p, w.partials.p);
+                         w.partials.p);
       PG_HIP(hipGetLastError());
-      diag_fix(DE, stamp, w.r.p, w.rhat.p, w.p.p, w.partials.p, w.grid, stream);
+      diag_fix(DE, stamp, w.r.p, w.rhat.p, w.partials.p, w.grid, stream);
       w.scatter = DE.rlist.p;
+      w.p_in_rhat = true;
       try {
         krylov_solve(DE.A, DE.nb, s->slab, nullptr, s->z.p, w, o, st, nullptr, nullptr, true);
       } catch (...) {
