@@ -289,12 +289,16 @@ def main() -> None:
     #   per application of the operator (2 per iteration, 1 in an iteration that ends at its half step):
     #       (m - 1) lean launches (b_fmt) + the closing launch (b_fmt + 16 n);  plain iteration: one launch, b_fmt + 8 n (+ 8 n)
     #   per iteration: k_bicg_s (r, v, r-hat, S -> s: 5 x 8 n) + k_bicg_xrp (y, p, s: read + written, t, v, S: 9 x 8 n)
-    #   per step: the right-hand side's SpMV (b_fmt) + k_rhs_init (74 n) + y = 0 (8 n) + the recovery x = x0 + q(A) y:
+    #   per step: the right-hand side's SpMV (b_fmt) + the fused right-hand side / solver start (full rows: y-hat, S, constant
+    #       part, mass, z, flags, compact index in, b-hat out = 54 n_full; compact rows: r and r-hat out = 16 n; p is not
+    #       written, the first iteration reads r-hat for it -- so the first closing launch reads ONE extra vector: - 8 n; y
+    #       is not zeroed, its first update assigns) + the recovery x = x0 + q(A) y:
     #       (m - 1) Horner launches (b_fmt + 8 n: the y vector as a third stream) + x += tau_0 u (24 n)
     # divided by the measured wall time of the step (launch gaps, host polls and the per-step kernels included).
     if m >= 2:
         per_apply = (m - 1) * b_fmt + (b_fmt + 16.0 * n_rows)
-        step_bytes = (2.0 * iters_eff) * per_apply + iters * (40.0 + 72.0) * n_rows + b_fmt_full + 74.0 * n_full + 8.0 * n_rows \
+        start_bytes = (54.0 * n_full + 16.0 * n_rows - 8.0 * n_rows) if reduced else (74.0 * n_full + 8.0 * n_rows)
+        step_bytes = (2.0 * iters_eff) * per_apply + iters * (40.0 + 72.0) * n_rows + b_fmt_full + start_bytes \
             + (m - 1) * (b_fmt + 8.0 * n_rows) + 24.0 * n_rows
     else:
         step_bytes = 2.0 * iters * b_fmt + b_fmt_full + iters * (12.0 + 40.0 + 72.0) * n_rows + 74.0 * n_full
