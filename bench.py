@@ -198,7 +198,16 @@ def main() -> None:
     dots_ms = run.spmv_ms_total / max(run.spmv_launches, 1)
     b_dots = b_fmt + (16 if m else 12) * n_rows        # plain iteration: r-hat in both launches, s in every second one
     dominant_lean = m >= 2 and run.spmv_lean_launches > 0
-    k_ms, k_bytes = (lean_ms, b_fmt) if dominant_lean else (dots_ms, b_dots)
+    # x-space form of the preconditioned loop (the default, pg_krylov.hip): the m - 1 launches of a chain are HORNER steps
+    # u <- tau in + (I - tau A) u -- the matrix, u in, u out and the chain's input vector as a third stream (+ 8 n), except the
+    # first, whose u is the input itself; the closing launch is the plain product with its dots: + r-hat (first application of
+    # an iteration) or + r-hat and s (second): + 12 n on average.  y-space form: lean launches of two streams (b_fmt), closing
+    # launches + 16 n, and a recovery per solve.
+    xspace = m >= 2 and int(run.poly_xspace) != 0
+    b_chain = (b_fmt + 8.0 * n_rows * (m - 2) / (m - 1)) if xspace else float(b_fmt)
+    if xspace:
+        b_dots = b_fmt + 12 * n_rows
+    k_ms, k_bytes = (lean_ms, b_chain) if dominant_lean else (dots_ms, b_dots)
     achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     # Krylov iterations: an iteration that ended at its half step ran one application of the operator, not two
     iters = run.total_iters / max(run.steps, 1)
@@ -253,15 +262,17 @@ def main() -> None:
         },
         "roofline": {
             "kernel": "k_spmv_s (marching units + stencil slices + packed irregular rows, fp64): " +
-                      ("lean launch w <- w - tau A w of the preconditioner polynomial (x in, y out, matrix)" if dominant_lean
-                       else "launch with fused dots"),
+                      (("Horner step u <- tau p + (I - tau A) u of the preconditioner polynomial (u in, u out, matrix, + the chain's "
+                        "input p as a third stream in m - 2 of the m - 1 launches of a chain: bytes_per_launch is the chain's mean)"
+                        if xspace else "lean launch w <- w - tau A w of the preconditioner polynomial (x in, y out, matrix)")
+                       if dominant_lean else "launch with fused dots"),
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
-            "bytes_per_launch": k_bytes,
+            "bytes_per_launch": k_bytes, "form": ("x-space: Horner chains, no recovery" if xspace else "y-space: lean chains + recovery") if m >= 2 else "plain iteration",
             "avg_launch_ms": k_ms,
             "launches_timed": int(run.spmv_lean_launches if dominant_lean else run.spmv_launches),
             # HIP events bracket whole chains of launches back to back, i.e. kernel + the gap to the next dependent kernel;
@@ -295,7 +306,16 @@ def main() -> None:
     #       is not zeroed, its first update assigns) + the recovery x = x0 + q(A) y:
     #       (m - 1) Horner launches (b_fmt + 8 n: the y vector as a third stream) + x += tau_0 u (24 n)
     # divided by the measured wall time of the step (launch gaps, host polls and the per-step kernels included).
-    if m >= 2:
+    #   x-space form: per application the chain's m - 1 launches (b_chain each) + the closing launch (b_fmt + 8 n, + 8 n more in
+    #       the second application of an iteration); k_bicg_xrp additionally reads the two preconditioned vectors and the index
+    #       map of the compact system (11.5 x 8 n); the half-step update x += alpha M^-1 p (28 n) once per solve that ends there;
+    #       no recovery.
+    if xspace:
+        half_per_step = run.half_exits / max(run.steps, 1)
+        start_bytes = (54.0 * n_full + 16.0 * n_rows) if reduced else 74.0 * n_full
+        step_bytes = (2.0 * iters_eff) * ((m - 1) * b_chain + b_fmt + 8.0 * n_rows) + (iters - half_per_step) * 8.0 * n_rows \
+            + iters * 40.0 * n_rows + (iters - half_per_step) * 92.0 * n_rows + half_per_step * 28.0 * n_rows + b_fmt_full + start_bytes
+    elif m >= 2:
         per_apply = (m - 1) * b_fmt + (b_fmt + 16.0 * n_rows)
         start_bytes = (54.0 * n_full + 16.0 * n_rows - 8.0 * n_rows) if reduced else (74.0 * n_full + 8.0 * n_rows)
         step_bytes = (2.0 * iters_eff) * per_apply + iters * (40.0 + 72.0) * n_rows + b_fmt_full + start_bytes \

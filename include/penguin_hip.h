@@ -118,6 +118,9 @@ typedef struct {
   int64_t poly_degree;       /* products with Â per application of the preconditioned operator in the last solve (0: plain) */
   int64_t half_exits;        /* solves that met the tolerance after the first half of their last iteration (such an
                                 iteration counts as one in total_iters but runs only one application of the operator)  */
+  int64_t poly_xspace;       /* 1: the last solve ran the x-space form of the preconditioned loop: the m - 1 launches of a chain
+                                are Horner steps (x, the chain's input and the matrix in, one vector out; the first of a chain
+                                reads one vector), no recovery; 0: y-space form (lean chains + recovery) or plain iteration       */
 } pg_run_info;
 
 typedef struct {

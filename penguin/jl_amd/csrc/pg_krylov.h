@@ -27,6 +27,7 @@ struct KrylovWork {
   // polynomial right preconditioner (pg_krylov.hip), n_vec each, on first use: the accumulated solution of the
   // preconditioned system (x = x0 + q(Â) ya) and the two work vectors the chain of products alternates between
   DevBuf<double> ya, wa, wb;
+  DevBuf<double> yb;        // x-space form: ya = M⁻¹p, yb = M⁻¹s of the running iteration
   // GMRES(m) only, allocated on first use (pg_gmres.hip): m+1 basis vectors, H / rotations / g, per-block partial sums
   DevBuf<double> gm_basis, gm, gm_partials;
   int gm_m = -1;
@@ -44,6 +45,7 @@ struct SolveStats {
   i64 spmv_launches = 0, spmv_lean_launches = 0;
   int poly_degree = 0;      // products with Â per application of the preconditioned operator (0: plain iteration)
   int half_exit = 0;        // 1: the solve ended at the half step of its last iteration (counted as an iteration)
+  int poly_xspace = 0;      // 1: x-space form of the preconditioned loop (Horner chains, no recovery), pg_krylov.hip
 };
 
 // halo exchange of the ghost segments of `vec` (no-op on one rank)

@@ -119,13 +119,18 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_s(i64 n, double* __restrict__ sc
 // the half step accepted (PH_BICG_S: derive has set S_DONE and S_HALF = this iteration's number): x += αp; r = s stands
 // fresh != 0: x is the accumulated solution of the preconditioned system, which starts at zero and has not been written yet
 // in the first iteration -- assigned instead of read (its memset and its first read are saved)
+// (x-space form of the preconditioned loop: p = M⁻¹p of this iteration, x the solution itself -- the caller's full vector
+// through `map` when the system is a compact image of it)
 __global__ __launch_bounds__(BLOCK) void k_bicg_half(i64 n, const double* __restrict__ sc, const double* __restrict__ p,
-                                                     double* __restrict__ x, int fresh, int iteration) {
+                                                     double* __restrict__ x, int fresh, int iteration,
+                                                     const int* __restrict__ map) {
   if (sc[S_HALF] != (double)iteration) return;
   const double alpha = sc[S_ALPHA];
   const bool first = fresh != 0 && iteration == 1;
-  for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK)
-    x[i] = (first ? 0.0 : x[i]) + alpha * p[i];
+  for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) {
+    const i64 j = map ? map[i] : i;
+    x[j] = (first ? 0.0 : x[j]) + alpha * p[i];
+  }
 }
 
 // x += αp + ωs;  r = s - ωt;  p = r + β(p - ωv)  (restart: p = r̂ = r);  partial slot 1 = (r,r)_W (convergence, weights
@@ -138,7 +143,9 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_xrp(i64 n, double* sc, const dou
                                                     const double* __restrict__ v, double* __restrict__ x,
                                                     double* __restrict__ r, double* __restrict__ p,
                                                     double* __restrict__ rhat, double* __restrict__ partials,
-                                                    const double* __restrict__ ds, int fresh, int p_in_rhat) {
+                                                    const double* __restrict__ ds, int fresh, int p_in_rhat,
+                                                    const double* __restrict__ phat, const double* __restrict__ shat,
+                                                    const int* __restrict__ map) {
   __shared__ double s_red[BLOCK / 64];
   if (sc[S_DONE] != 0.0) return;
   const double alpha = sc[S_ALPHA], omega = sc[S_OMEGA], beta = sc[S_BETA];
@@ -148,8 +155,14 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_xrp(i64 n, double* sc, const dou
   double a0 = 0.0, aw = 0.0;
   for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) {
     const double si = r[i], pi = prhat ? rhat[i] : p[i];
-    const double xi = (first ? 0.0 : (NTV ? __builtin_nontemporal_load(x + i) : x[i])) + alpha * pi + omega * si;
-    if (NTV) __builtin_nontemporal_store(xi, x + i); else x[i] = xi;
+    if (phat) {
+      // x-space form: x += α M⁻¹p + ω M⁻¹s with the two preconditioned vectors the applications of the operator left
+      const i64 j = map ? map[i] : i;
+      x[j] += alpha * (NTV ? __builtin_nontemporal_load(phat + i) : phat[i]) + omega * (NTV ? __builtin_nontemporal_load(shat + i) : shat[i]);
+    } else {
+      const double xi = (first ? 0.0 : (NTV ? __builtin_nontemporal_load(x + i) : x[i])) + alpha * pi + omega * si;
+      if (NTV) __builtin_nontemporal_store(xi, x + i); else x[i] = xi;
+    }
     const double ri = si - omega * (NTV ? __builtin_nontemporal_load(t + i) : t[i]);
     r[i] = ri;
     if (restart) {
@@ -412,6 +425,8 @@ bool krylov_uses_polynomial(const CsrMatrix& A, const pg_krylov_opts& opts) {
   return (opts.precond > 0 ? opts.precond : degree_env) >= 2;
 }
 
+constexpr int MAX_POLY_DEGREE = 40;   // products per application of the polynomial preconditioner
+
 void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, const double* b, double* x, KrylovWork& w,
                   const pg_krylov_opts& opts, SolveStats& stats, const double* x0, const double* Ax0, bool preinit) {
   Context& cx = ctx();
@@ -448,7 +463,7 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
   // |λ - 1| < 0.95; m products with Â per application of C = I - R(Â)  (m < 2: the plain iteration)
   int m = 0;
   if (poly_env && opts.precond >= 0 && !cg && A.poly_ok && spmv_supports_preconditioner_product() && n > 0)
-    m = std::min(opts.precond > 0 ? opts.precond : degree_env, 16);
+    m = std::min(opts.precond > 0 ? opts.precond : degree_env, MAX_POLY_DEGREE);
   // auto mode: the degree that fits the number of products the previous solve on this matrix would have needed (below)
   static const bool adapt_env = getenv("PG_POLY_ADAPT") ? atoi(getenv("PG_POLY_ADAPT")) != 0 : !getenv("PG_POLY_DEGREE");
   const bool adaptive = adapt_env && m >= 2 && opts.precond == 0 && preinit;
@@ -458,20 +473,30 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
   const bool poly = m > 0;
   stats.poly_degree = m;
   PG_REQUIRE(!w.scatter || (poly && preinit), "a compact system needs the polynomial path and a prepared start");
-  double tau[16];
+  double tau[MAX_POLY_DEGREE];
   if (poly) {
     // 1 / Chebyshev nodes of [1 - g, 1 + g], the largest and the smallest remaining root in turn
     const double g = std::min(std::max(A.gersh, 0.05), 0.95);
-    double lam[16];
+    double lam[MAX_POLY_DEGREE];
     for (int k = 0; k < m; ++k) lam[k] = 1.0 + g * std::cos(M_PI * (2.0 * k + 1.0) / (2.0 * m));   // descending
     for (int k = 0, lo = 0, hi = m - 1; k < m; ++k) tau[k] = 1.0 / ((k & 1) ? lam[hi--] : lam[lo++]);
     if (w.ya.n < nvec) {
-      w.ya.alloc(nvec); w.wa.alloc(nvec); w.wb.alloc(nvec);
-      w.ya.zero(); w.wa.zero(); w.wb.zero();
+      w.ya.alloc(nvec); w.wa.alloc(nvec); w.wb.alloc(nvec); w.yb.alloc(nvec);
+      w.ya.zero(); w.wa.zero(); w.wb.zero(); w.yb.zero();
     }
     // y0 = 0 (x = x0 + q(Â) y): not written here -- the first update of y assigns (k_bicg_half / k_bicg_xrp, `fresh`)
   }
-  double* const xit = poly ? w.ya.p : x;   // what the iteration updates
+  // x-space form (default): every application of the operator computes M⁻¹in = q(Â) in by Horner's rule (m - 1 launches
+  // of three streams, the first of two) and closes with the plain product Â(M⁻¹in) and its dots; the iteration updates x
+  // itself.  The y-space form (PG_POLY_XSPACE=0) applies C = I - R(Â) in product form (m - 1 launches of two streams),
+  // accumulates the solution y of the preconditioned system and recovers x = x0 + q(Â) y at the end: m - 1 Horner launches
+  // and an update per SOLVE -- with 3 applications of degree 9 that recovery was 0.49 ms of a 2.4 ms step, the third stream
+  // of 21 launches costs 0.17.
+  static const bool xspace_env = getenv("PG_POLY_XSPACE") ? atoi(getenv("PG_POLY_XSPACE")) != 0 : true;
+  const bool xspace = poly && xspace_env;
+  stats.poly_xspace = xspace ? 1 : 0;
+  double* const xit = (poly && !xspace) ? w.ya.p : x;   // what the iteration updates
+  const int* const xmap = xspace ? w.scatter : nullptr; // ... through the caller's index map when the system is a compact image
   // convergence is also tested after the first half of an iteration when a half costs several products (the test itself
   // costs two small launches); PG_HALF_TEST=0/1 forces it off / on
   static const int half_env = getenv("PG_HALF_TEST") ? atoi(getenv("PG_HALF_TEST")) : -1;
@@ -509,6 +534,29 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
   // iteration applies Â itself (modes 1 / 3)
   auto apply = [&](double* in, double* out, int phase, int nslots, int itn) {
     const bool second = phase == PH_BICG_2;
+    if (xspace) {
+      // hat = q(Â) in:  u_(m-1) = τ_(m-1) in,  u_k = τ_k in + (I - τ_k Â) u_(k+1),  hat = u_0   (mode 8: pc2 base + pc0 x + pc1 Â x;
+      // the first launch has x = base = in)
+      double* hat = second ? w.yb.p : w.ya.p;
+      double* src = in;
+      timer.begin(st, itn, true, second, m - 1);
+      for (int k = m - 2; k >= 0; --k) {
+        double* dst = k == 0 ? hat : ((k & 1) ? w.wb.p : w.wa.p);
+        FinArgs f{nullptr, nullptr, PH_NONE, 0, 0, nullptr};
+        const double lead = k == m - 2 ? tau[m - 1] : 1.0;
+        f.pc0 = lead; f.pc1 = -lead * tau[k]; f.pc2 = tau[k]; f.base = in;
+        spmv_with_halo(8, A, nb, slab, src, dst, nullptr, nullptr, w.sc.p, G, st, &f);
+        src = dst;
+      }
+      timer.end(st);
+      FinArgs f{w.ticket.p, w.sc.p, phase, nslots, derive_here, nullptr};
+      f.dotx = in;      // mode 3: `in` (= s) is the operand of the (out, .) dot, not the launch's x
+      timer.begin(st, itn, false, second);
+      const bool folded = spmv_with_halo(phase == PH_BICG_1 ? 1 : 3, A, nb, slab, hat, out, w.rhat.p, w.partials.p, w.sc.p, G, st, &f);
+      timer.end(st);
+      if (folded) finalize_folded(phase, nslots, w, st); else finalize(phase, nslots, w, st, true);
+      return;
+    }
     double* src = in;
     if (m > 1) timer.begin(st, itn, true, second, m - 1);
     for (int k = 0; k + 1 < m; ++k) {
@@ -546,15 +594,18 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_s<false>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p, (const double*)A.ds.p, tk);
     if (half_test) {   // does s already meet the tolerance?  then x += αp and stop: the second half is 1 + m launches
       if (!tk) finalize(PH_BICG_S, 1, w, st, true, 4);
-      hipLaunchKernelGGL(k_bicg_half, dim3(G), dim3(BLOCK), 0, st, n, (const double*)w.sc.p, (const double*)pvec, xit, poly ? 1 : 0, itn + 1);
+      hipLaunchKernelGGL(k_bicg_half, dim3(G), dim3(BLOCK), 0, st, n, (const double*)w.sc.p,
+                         xspace ? (const double*)w.ya.p : (const double*)pvec, xit, (poly && !xspace) ? 1 : 0, itn + 1, xmap);
     }
   };
   auto second_half = [&](int itn) {
     apply(w.r.p, w.t.p, PH_BICG_2, 5, itn);     // t = C s (r holds s), (t,s), (t,t), (r̂,t); then ω, ρ, β / restart
     if (ntv) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_xrp<true>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.t.p, w.v.p, xit, w.r.p,
-                                w.p.p, w.rhat.p, w.partials.p, (const double*)A.ds.p, poly ? 1 : 0, p_in_rhat ? 1 : 0);
+                                w.p.p, w.rhat.p, w.partials.p, (const double*)A.ds.p, (poly && !xspace) ? 1 : 0, p_in_rhat ? 1 : 0,
+                                xspace ? (const double*)w.ya.p : nullptr, xspace ? (const double*)w.yb.p : nullptr, xmap);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_xrp<false>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.t.p, w.v.p, xit, w.r.p,
-                            w.p.p, w.rhat.p, w.partials.p, (const double*)A.ds.p, poly ? 1 : 0, p_in_rhat ? 1 : 0);
+                            w.p.p, w.rhat.p, w.partials.p, (const double*)A.ds.p, (poly && !xspace) ? 1 : 0, p_in_rhat ? 1 : 0,
+                                xspace ? (const double*)w.ya.p : nullptr, xspace ? (const double*)w.yb.p : nullptr, xmap);
   };
   static const bool half_batches = getenv("PG_HALF_BATCH") ? atoi(getenv("PG_HALF_BATCH")) != 0 : true;   // (0: whole iterations, for A/B runs)
   while (!done) {
@@ -600,7 +651,24 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
     // from the iterate reached (the matrix keeps the verdict)
     if (!done && poly && launched >= poly_give_up) { poly_failed = true; done = true; }
   }
-  if (poly && w.h_sc[S_ITERS] > 0.0) {      // (no iteration: the start already met the tolerance, y was never written)
+  if (xspace && poly_failed) {              // x is the iterate reached: nothing to recover
+    const_cast<CsrMatrix&>(A).poly_ok = false;
+    timer.collect(stats, launched, false);
+    if (w.scatter) {                        // (the caller solves again on its full system, which has a right-hand side vector)
+      stats.iters = launched;
+      stats.converged = 0;
+      stats.poly_degree = -1;
+      return;
+    }
+    if (getenv("PG_DEBUG")) fprintf(stderr, "[pg_krylov] polynomial preconditioner (m = %d) stagnated after %d iterations: plain iteration\n", m, launched);
+    spmv_with_halo(0, A, nb, slab, x, w.t.p, nullptr, nullptr, nullptr, G, st);   // Â x of the iterate reached
+    SolveStats rest;
+    krylov_solve(A, nb, slab, b, x, w, opts, rest, x, w.t.p, false);
+    stats = rest;
+    stats.iters += launched;
+    return;
+  }
+  if (poly && !xspace && w.h_sc[S_ITERS] > 0.0) {      // (no iteration: the start already met the tolerance, y was never written)
     // x = x0 + q(Â) y,  q(Â) y = Σ_k τ_k w_k,  w_0 = y, w_(k+1) = (I - τ_k Â) w_k  -- evaluated by Horner's rule from the inside,
     //   u_(m-1) = τ_(m-1) y,   u_k = τ_k y + (I - τ_k Â) u_(k+1),   q(Â) y = u_0,
     // in the scaled variable ũ_k = u_k / τ_k so that a launch needs no scaled copy of y:
@@ -616,7 +684,7 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
         double* dst = (k & 1) ? w.wb.p : w.wa.p;
         FinArgs f{nullptr, nullptr, PH_NONE, 0, 0, nullptr};
         const double c = tau[k + 1] / tau[k];
-        f.pc0 = c; f.pc1 = -c * tau[k]; f.base = w.ya.p;
+        f.pc0 = c; f.pc1 = -c * tau[k]; f.pc2 = 1.0; f.base = w.ya.p;
         spmv_with_halo(8, A, nb, slab, src, dst, nullptr, nullptr, nullptr, G, st, &f);
         src = dst;
       }
@@ -668,8 +736,13 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
   // step to step).  This solve applied P = (2 iters - half) m products and took (r,r)_W from rr0 to rr; at that rate the
   // tolerance needed  P log(tol²/rr0) / log(rr/rr0)  of them.  An application of the operator costs its m - 1 lean launches
   // + one closing launch with its vector kernel (≈ 3.2 lean launches): take the (applications h, degree m) with h m >= need
-  // that is cheapest -- 27 products are 3 x 9, not 5 x 6 (2.5 iterations of 12) or 2 x 16 of degree 8.  No safety margin: a
-  // miss costs one more application once, and the next estimate is made from that solve (335 -> 370 steps/s at 512^3).
+  // that is cheapest -- in the y-space form 27 products are 3 x 9, not 5 x 6 (2.5 iterations of 12) or 2 x 16 of degree 8
+  // (335 -> 370 steps/s at 512^3), because its recovery costs m - 1 launches per solve.  The x-space form has no such term and
+  // no exactness requirement on the polynomial (x and r move by the SAME computed M⁻¹p, so r stays the residual of x whatever
+  // rounding does inside the Horner chain): there the cheapest is ONE application of degree ~26 that ends at the half-step
+  // test -- a Chebyshev step with BiCGStab's α, its residual test and, if the estimate was short, its continuation
+  // (444 -> 546 steps/s at 512^3 against 3 x 9 in the same form).  No safety margin: a miss costs one more application
+  // once, and the next estimate is made from that solve.
   w.adapt_matrix = nullptr;
   if (adaptive && stats.converged && stats.iters > 0) {
     const double rr0 = w.h_sc[S_RR0], rr = w.h_sc[S_HALF] != 0.0 ? w.h_sc[S_RED4] : w.h_sc[S_RR], tol2 = w.h_sc[S_TOL2];
@@ -681,8 +754,11 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
       double best = 1e300;
       for (int h = 1; h <= 16; ++h) {
         const int mm = (int)std::ceil(need / h);
-        if (mm < 4 || mm > 10) continue;
-        const double cost = h * ((mm - 1) + 3.2) + 1.25 * (mm - 1);   // + the recovery's mm - 1 Horner launches
+        const int maxdeg = getenv("PG_POLY_MAXDEG") ? std::min(MAX_POLY_DEGREE, std::max(4, atoi(getenv("PG_POLY_MAXDEG")))) : (xspace ? 32 : 10);
+        if (mm < 4 || mm > maxdeg) continue;
+        // x-space: a chain = one lean launch + mm - 2 Horner launches (1.18 lean launches each), closing launch + vector
+        // kernel ≈ 3.6; y-space: mm - 1 lean launches, closing ≈ 3.2, + the recovery's mm - 1 Horner launches per solve
+        const double cost = xspace ? h * (1.0 + 1.18 * (mm - 2) + 3.6) : h * ((mm - 1) + 3.2) + 1.25 * (mm - 1);
         if (cost < best) { best = cost; w.adapt_m = mm; w.adapt_h = h; }
       }
       if (best < 1e300) w.adapt_matrix = &A;

@@ -1097,6 +1097,7 @@ int32_t pg_solver_run(pg_solver* s, double Tend, int32_t scheme, const pg_krylov
     iters += st.iters; tot.spmv_ms += st.spmv_ms; tot.spmv_launches += st.spmv_launches;
     tot.spmv_lean_ms += st.spmv_lean_ms; tot.spmv_lean_launches += st.spmv_lean_launches;
     tot.poly_degree = st.poly_degree;
+    tot.poly_xspace = st.poly_xspace;
     tot.half_exit += st.half_exit;
     if (!st.converged) ++unconverged;
     if (st.bnorm > 0.0) worst = std::max(worst, st.resnorm / st.bnorm);
@@ -1132,6 +1133,7 @@ int32_t pg_solver_run(pg_solver* s, double Tend, int32_t scheme, const pg_krylov
     info->spmv_lean_ms_total = tot.spmv_lean_ms;
     info->spmv_lean_launches = tot.spmv_lean_launches;
     info->poly_degree = tot.poly_degree;
+    info->poly_xspace = tot.poly_xspace;
     info->half_exits = tot.half_exit;
   }
   PG_API_END

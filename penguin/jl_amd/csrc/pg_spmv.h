@@ -189,7 +189,7 @@ struct FinArgs {
   int do_derive;      // 0: sums only (several ranks: an all-reduce follows)
   const double* dotx; // operand of the (y, .) dot of modes 2 / 3; nullptr: the input vector x itself
   double pc0 = 2.0, pc1 = -1.0;   // modes 4..7: pc0 x + pc1 A x  (default: the Neumann product 2x - Âx)
-  const double* base = nullptr;   // mode 5: y = base - (pc0 x + pc1 A x)
+  const double* base = nullptr;   // mode 5: y = base - (pc0 x + pc1 A x);  mode 8: y = pc2 base + pc0 x + pc1 A x
   double* accv = nullptr;         // mode 7: accv += pc2 x
   double pc2 = 0.0;
 };

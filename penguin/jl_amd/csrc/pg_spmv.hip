@@ -305,11 +305,11 @@ struct ModeInfo {
 
 // y of one row from its product s; a, b = the operands A, B at the row
 template <int MODE>
-__device__ __forceinline__ double mode_out(double s, double own, double a, double b, double pc0, double pc1) {
+__device__ __forceinline__ double mode_out(double s, double own, double a, double b, double pc0, double pc1, double pc2) {
   if (MODE == 4 || MODE == 7) return mode4_out(own, s, pc0, pc1);
   if (MODE == 5) return b - mode4_out(own, s, pc0, pc1);
   if (MODE == 6) return a - mode4_out(own, s, pc0, pc1);
-  if (MODE == 8) return b + mode4_out(own, s, pc0, pc1);
+  if (MODE == 8) return pc2 * b + mode4_out(own, s, pc0, pc1);   // Horner step: pc2 base + pc0 x + pc1 A x
   return s;
 }
 
@@ -373,8 +373,8 @@ __device__ inline void slice_rows(const SDesc& d, int nrows, int rec, const doub
   }
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    sum[b].x = mode_out<MODE>(sum[b].x, own[b].x, ax[b].x, ax2[b].x, pc0, pc1);
-    sum[b].y = mode_out<MODE>(sum[b].y, own[b].y, ax[b].y, ax2[b].y, pc0, pc1);
+    sum[b].x = mode_out<MODE>(sum[b].x, own[b].x, ax[b].x, ax2[b].x, pc0, pc1, pc2);
+    sum[b].y = mode_out<MODE>(sum[b].y, own[b].y, ax[b].y, ax2[b].y, pc0, pc1, pc2);
     const bool st = !(dbg & 8) || sum[b].x == 1.2345e-300;
     double* yp = y + d.r0 + l0[b];
     double* ap = const_cast<double*>(pa) + d.r0 + l0[b];   // mode 7: the accumulated vector
@@ -492,8 +492,8 @@ __device__ __forceinline__ double march_plane(const double (&c)[CNT], int rng, i
   s1 += c[j] * xm.y;  s2 += c[j] * xm_n;  ++j;
   s1 += c[j] * xc.y;  s2 += c[j] * xc_nx;
   // (the row's own x: elements 2l+1, 2l+2 of the centre line)
-  s1 = mode_out<MODE>(s1, xc.y, sd.ax.x, sd.ax2.x, pc0, pc1);
-  s2 = mode_out<MODE>(s2, xc_nx, sd.ax.y, sd.ax2.y, pc0, pc1);
+  s1 = mode_out<MODE>(s1, xc.y, sd.ax.x, sd.ax2.x, pc0, pc1, pc2);
+  s2 = mode_out<MODE>(s2, xc_nx, sd.ax.y, sd.ax2.y, pc0, pc1, pc2);
   const int lo = rng & 255, hi = rng >> 8;
   const bool nost = (dbg & 32) && s1 != 1.2345e-300;   // diagnostics: no stores
   const bool allst = (dbg & 512) != 0;                  // diagnostics: every lane stores its pair (whole windows)
@@ -593,10 +593,11 @@ template <int CNT, int MODE>
 __device__ __forceinline__ void march_dispatch(int rec, int lane, const double* __restrict__ x, double* __restrict__ y,
                                       const double* __restrict__ pa, const double* __restrict__ pb, double pc0, double pc1,
                                       double pc2, double& acc0, double& acc1, double& acc2, int dbg) {
-  // The launches with fused dots and two more operand vectors per plane (modes 5, 6: the closing launches of the polynomial)
-  // do not fit a unit of MARCH_K planes into the 128 VGPRs of four waves per SIMD (10 / 14 VGPRs went to scratch): they take
-  // it in two halves -- two more line loads per unit, which hit L1
-  constexpr bool SPLIT = (MODE == 5 || MODE == 6) && MARCH_K == 2 * MARCH_KS && PG_MARCH_SPLIT;
+  // The launches with fused dots and one or two more operand vectors per plane (modes 1, 3: the closing launch of an
+  // application of the operator; 5, 6: the same in the y-space form of the preconditioned loop) do not fit a unit of MARCH_K
+  // planes into the 128 VGPRs of four waves per SIMD (10 / 14 VGPRs went to scratch in modes 5 / 6): they take it in two
+  // halves -- two more line loads per unit, which hit L1
+  constexpr bool SPLIT = (MODE == 1 || MODE == 3 || MODE == 5 || MODE == 6) && MARCH_K == 2 * MARCH_KS && PG_MARCH_SPLIT;
   if ((rlane(rec, 0) & 255) == MARCH_K) {
     if (SPLIT) {
       march_unit<CNT, MODE, MARCH_KS, 0, MARCH_K>(rec, lane, x, y, pa, pb, pc0, pc1, pc2, acc0, acc1, acc2, dbg);
@@ -768,7 +769,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_spmv_s(i64 nslices, const int* __r
       }
       __builtin_amdgcn_wave_barrier();
       if (live) {
-        sum = mode_out<MODE>(sum, xown, opa, opb, fin.pc0, fin.pc1);
+        sum = mode_out<MODE>(sum, xown, opa, opb, fin.pc0, fin.pc1, fin.pc2);
         y[rid] = sum;
         if (MODE == 7) const_cast<double*>(pa)[rid] = opa + fin.pc2 * xown;
         if (MI::DOT0) acc0 += opa * sum;
