@@ -312,7 +312,9 @@ def main() -> None:
     #       no recovery.
     if xspace:
         half_per_step = run.half_exits / max(run.steps, 1)
-        start_bytes = (54.0 * n_full + 16.0 * n_rows) if reduced else 74.0 * n_full
+        # (compact loop system: the start writes r-hat only -- r = p = r-hat are read from it in the first iteration, whose
+        #  k_bicg_s therefore reads one vector less)
+        start_bytes = (54.0 * n_full + 8.0 * n_rows - 8.0 * n_rows) if reduced else 74.0 * n_full
         step_bytes = (2.0 * iters_eff) * ((m - 1) * b_chain + b_fmt + 8.0 * n_rows) + (iters - half_per_step) * 8.0 * n_rows \
             + iters * 40.0 * n_rows + (iters - half_per_step) * 92.0 * n_rows + half_per_step * 28.0 * n_rows + b_fmt_full + start_bytes
     elif m >= 2:

@@ -20,9 +20,9 @@ struct KrylovWork {
   // set by the caller around one krylov_solve: the system is a compact image of the caller's (pg_reduce.hip, DiagElim) and
   // x is the caller's FULL vector -- the solution update x += q(Â)y lands at x[scatter[i]].  Needs the polynomial path.
   const int* scatter = nullptr;
-  // set by the caller of a prepared start that left p unwritten: p = r̂ = r at the start, so the first iteration reads r̂
-  // wherever it needs p (the closing launch then reads ONE vector for both operands) and the start kernel writes one
-  // vector less; k_bicg_xrp writes p at the end of that iteration as always.  Reset by krylov_solve.
+  // set by the caller of a prepared start that wrote r̂ only: p = r = r̂ at the start, so the first iteration reads r̂
+  // wherever it needs p or r (k_bicg_s writes r = s, k_bicg_xrp writes p, as always) and the start kernel writes two
+  // vectors less.  Reset by krylov_solve.
   bool p_in_rhat = false;
   // polynomial right preconditioner (pg_krylov.hip), n_vec each, on first use: the accumulated solution of the
   // preconditioned system (x = x0 + q(Â) ya) and the two work vectors the chain of products alternates between

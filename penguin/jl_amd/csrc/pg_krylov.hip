@@ -80,15 +80,17 @@ template <bool NTV>
 __global__ __launch_bounds__(BLOCK) void k_bicg_s(i64 n, double* __restrict__ sc, const double* __restrict__ v,
                                                   const double* __restrict__ rhat, double* __restrict__ r,
                                                   double* __restrict__ partials, const double* __restrict__ ds,
-                                                  unsigned* __restrict__ ticket) {
+                                                  unsigned* __restrict__ ticket, int r_in_rhat) {
   __shared__ double s_red[BLOCK / 64];
   if (sc[S_DONE] != 0.0) return;
   const double alpha = sc[S_ALPHA];
+  const bool rrhat = r_in_rhat != 0 && sc[S_ITERS] == 0.0;   // first iteration of a start that left r = r̂ unwritten
   double a0 = 0.0, a1 = 0.0, aw = 0.0;
   for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) {
-    const double si = r[i] - alpha * (NTV ? __builtin_nontemporal_load(v + i) : v[i]);
+    const double rh = rhat[i];
+    const double si = (rrhat ? rh : r[i]) - alpha * (NTV ? __builtin_nontemporal_load(v + i) : v[i]);
     r[i] = si;
-    a0 += rhat[i] * si;
+    a0 += rh * si;
     a1 += si * si;
     const double ws = ds[i] * si;
     aw += ws * ws;
@@ -590,8 +592,8 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
     apply(pvec, w.v.p, PH_BICG_1, 3, itn);     // v = C p, (r̂,v); previous iteration's (r,r): convergence / restart; then α
     const bool half_test = test;
     unsigned* tk = (half_test && derive_here) ? w.ticket.p : nullptr;   // the half-step test inside k_bicg_s
-    if (ntv) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_s<true>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p, (const double*)A.ds.p, tk);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_s<false>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p, (const double*)A.ds.p, tk);
+    if (ntv) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_s<true>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p, (const double*)A.ds.p, tk, p_in_rhat ? 1 : 0);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_s<false>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p, (const double*)A.ds.p, tk, p_in_rhat ? 1 : 0);
     if (half_test) {   // does s already meet the tolerance?  then x += αp and stop: the second half is 1 + m launches
       if (!tk) finalize(PH_BICG_S, 1, w, st, true, 4);
       hipLaunchKernelGGL(k_bicg_half, dim3(G), dim3(BLOCK), 0, st, n, (const double*)w.sc.p,

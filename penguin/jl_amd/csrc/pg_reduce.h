@@ -38,7 +38,7 @@ void build_diag_elim(const CsrMatrix& A, const Numbering& nb, DiagElim& E);
 // r_full: the start residuals of the rows that are left out (k_rhs_init_c; entries of the other rows are not read), r / r̂ / p:
 // the compact start residual.  x_E += r_E / d; the change goes through the coupling block into r, r̂, p; the start sums (slots
 // 0 and 2 of partials) are recomputed when the change is more than rounding noise.
-void diag_fix(const DiagElim& E, int stamp, double* r, double* rhat, double* partials, int grid, hipStream_t st);
+void diag_fix(const DiagElim& E, int stamp, double* rhat, double* partials, int grid, hipStream_t st);
 
 // active only for a two-kind (monophasic) system whose γ rows are rows of the identity and whose ω rows reference no ghost
 void build_gamma_elim(const CsrMatrix& A, const Numbering& nb, GammaElim& E);

@@ -206,15 +206,14 @@ __global__ void k_c_coupling(i64 n_wg, const int* __restrict__ wg_rows, const in
 // coupled remaining rows (compact index cmap[wg_rows[q]]): r -= Â_RE δ, r̂ and p alike
 __global__ void k_c_couple(i64 n_wg, const int* __restrict__ wg_rows, const int* __restrict__ wg_ptr, const int* __restrict__ wg_col,
                            const double* __restrict__ wg_val, const double* __restrict__ delta, const int* __restrict__ cmap,
-                           double* __restrict__ r, double* __restrict__ rhat, const int* __restrict__ flag, int stamp) {
+                           double* __restrict__ rhat, const int* __restrict__ flag, int stamp) {
   if (*flag != stamp) return;   // no diagonal row moved in this step (constant Dirichlet data after the first step)
   for (i64 q = blockIdx.x * (i64)blockDim.x + threadIdx.x; q < n_wg; q += (i64)gridDim.x * blockDim.x) {
     double s = 0.0;
     for (int e = wg_ptr[q]; e < wg_ptr[q + 1]; ++e) s += wg_val[e] * delta[wg_col[e]];
     if (s != 0.0) {
       const int c = cmap[wg_rows[q]];
-      const double v = r[c] - s;
-      r[c] = v; rhat[c] = v;   // (p is not stored at the start: KrylovWork::p_in_rhat)
+      rhat[c] -= s;   // (r and p are not stored at the start: KrylovWork::p_in_rhat)
     }
   }
 }
@@ -402,12 +401,12 @@ void build_diag_elim(const CsrMatrix& A, const Numbering& nb, DiagElim& E) {
             (long long)A.nnz, n_wg, nnz_g, (long long)A.rows_g, (long long)R.rows_g);
 }
 
-void diag_fix(const DiagElim& E, int stamp, double* r, double* rhat, double* partials, int grid, hipStream_t st) {
+void diag_fix(const DiagElim& E, int stamp, double* rhat, double* partials, int grid, hipStream_t st) {
   // (the rows themselves were solved by k_rhs_init_c: x += δ, δ kept in E.delta, E.flag = stamp if any δ != 0)
   if (E.n_wg > 0)
     hipLaunchKernelGGL(k_c_couple, dim3(grid_for(E.n_wg, 256)), dim3(256), 0, st, E.n_wg, E.wg_rows.p, E.wg_ptr.p, E.wg_col.p, E.wg_val.p,
-                       E.delta.p, E.cmap.p, r, rhat, (const int*)E.flag.p, stamp);
-  hipLaunchKernelGGL(k_renorm, dim3(grid), dim3(BLOCK), 0, st, E.n_c, (const int*)E.flag.p, stamp, (const double*)r, E.A.ds.p, partials);
+                       E.delta.p, E.cmap.p, rhat, (const int*)E.flag.p, stamp);
+  hipLaunchKernelGGL(k_renorm, dim3(grid), dim3(BLOCK), 0, st, E.n_c, (const int*)E.flag.p, stamp, (const double*)rhat, E.A.ds.p, partials);
   PG_HIP(hipGetLastError());
 }
 
