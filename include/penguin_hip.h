@@ -88,8 +88,8 @@ typedef struct {
   int32_t restart;     /* GMRES only: Krylov vectors per restart cycle (<= 0: 20, IterativeSolvers' default) */
   int32_t precond;     /* BiCGStab only: polynomial right preconditioner in Â (DESIGN.md "Krylov driver").  0: automatic
                           (on where Gershgorin bounds the spectrum; degree 6 for a first solve, then chosen per solve of the
-                          warm time loop from the previous solve's convergence rate, 4 .. 10); -1: off (the plain
-                          iteration IterativeSolvers runs); m >= 1: m products with Â per application where admissible */
+                          warm time loop from the previous solve's convergence rate, 4 .. 32); -1: off (the plain
+                          iteration IterativeSolvers runs); m >= 1: m products with Â per application where admissible (<= 40) */
 } pg_krylov_opts;
 
 typedef struct {
