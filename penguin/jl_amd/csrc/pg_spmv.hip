@@ -579,7 +579,7 @@ __device__ __forceinline__ void march_unit(int rec, int lane, const double* __re
         sd[q].yp = load_pair<false>(x + rb[q] + (rlane(rec, 20 + 4 * (Q0 + q)) & amask) + l2 + one);
       }
       if (MI::HAS_A) sd[q].ax = load_pair<false>(pa + rb[q] + l2 + one);
-      if (MI::HAS_B) sd[q].ax2 = load_pair<false>(pb + rb[q] + l2 + one);
+      if (MI::HAS_B) sd[q].ax2 = load_pair<false>(pb + rb[q] + l2 + one);   // (no stream hint: the chain's input is re-read by every launch of the chain and stays in the Infinity Cache -- with the hint a Horner step took 65.7 instead of 53.8 us)
     }
   }
   double xm_n = lane_up(ln[0].x);
