@@ -772,6 +772,25 @@ def test_spmv_work_item_orders_bitwise_equal_csr_kernels(env):
     assert r.returncode == 0 and "orders ok" in r.stdout, (env, r.stdout[-2000:], r.stderr[-4000:])
 
 
+@pytest.mark.parametrize("env", [{"PG_POLY_XSPACE": "0"}, {"PG_POLY_MAXDEG": "7"}, {"PG_POLY_XSPACE": "0", "PG_DIAG_ELIM": "0"},
+                                 {"PG_DIAG_ELIM": "0", "PG_GAMMA_ELIM": "0"}])
+def test_forms_of_the_preconditioned_loop_match_the_oracle(env):
+    """The loop's variants -- y-space form (lean chains + recovery), low degree cap (several applications per solve), the
+    Dirichlet-interface reduction without the compact system, the full system -- are selected by environment variables read
+    once per process: parity tests against the oracle's direct solve in a child process per setting."""
+    import subprocess
+    root = pathlib.Path(__file__).resolve().parents[1]
+    code = ("import sys; sys.path.insert(0, '.'); import penguin.jl_amd as pj; pj.init(0); import tests.test_gpu_parity as t\n"
+            "t.test_heat3d_config3_shape(pj)\n"
+            "t.test_time_dependent_data_and_variable_coefficient(pj)\n"
+            "t.test_heat_monophasic_reference_test(pj, 'BE', 'CN')\n"
+            "t.test_full_size_properties_256(pj)\n"
+            "t.test_time_loop_is_bitwise_reproducible(pj)\n"
+            "print('forms ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env={**os.environ, **env}, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "forms ok" in r.stdout, (env, r.stdout[-2000:], r.stderr[-4000:])
+
+
 # ------------------------------------------------------------------------------------ steady diffusion (SURVEY §8f.1)
 def test_steady_monophasic_reference_test(pj):
     """test/solver/diffusion_test.jl:5-26: 20^2, circle r=0.5 at (0.5,0.5), Dirichlet(1) everywhere, f = 0."""
