@@ -24,6 +24,9 @@ struct KrylovWork {
   // wherever it needs p or r (k_bicg_s writes r = s, k_bicg_xrp writes p, as always) and the start kernel writes two
   // vectors less.  Reset by krylov_solve.
   bool p_in_rhat = false;
+  // set by the caller whose start kernel has already reset the scalars, summed the start sums and derived PH_INIT
+  // (k_rhs_init_c with a ticket): krylov_solve launches no start kernel.  Reset by krylov_solve.
+  bool start_folded = false;
   // polynomial right preconditioner (pg_krylov.hip), n_vec each, on first use: the accumulated solution of the
   // preconditioned system (x = x0 + q(Â) ya) and the two work vectors the chain of products alternates between
   DevBuf<double> ya, wa, wb;

@@ -452,8 +452,10 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
   // tolerances -> device scalars (a one-thread kernel: a host-to-device copy out of pageable memory stalls the stream)
   const bool p_in_rhat = w.p_in_rhat && preinit && opts.method == PG_METHOD_BICGSTAB;
   w.p_in_rhat = false;
-  const bool fused_start = preinit && opts.method == PG_METHOD_BICGSTAB && cx.nranks == 1 && !cx.comm;   // k_start below
-  if (!fused_start)
+  const bool start_folded = w.start_folded && preinit && opts.method == PG_METHOD_BICGSTAB;
+  w.start_folded = false;
+  const bool fused_start = !start_folded && preinit && opts.method == PG_METHOD_BICGSTAB && cx.nranks == 1 && !cx.comm;   // k_start below
+  if (!fused_start && !start_folded)
     hipLaunchKernelGGL(k_sc_reset, dim3(1), dim3(S_COUNT), 0, st, w.sc.p, opts.reltol * opts.reltol, opts.abstol * opts.abstol);
   SpmvTimer timer(cx.profiling);
 
@@ -509,7 +511,8 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
       hipLaunchKernelGGL(k_bicg_init, dim3(G), dim3(BLOCK), 0, st, n, nvec, b, x0, Ax0, x, w.r.p, w.rhat.p, w.p.p, w.v.p,
                        w.partials.p, (const double*)A.ds.p);
     static_assert(S_COUNT <= BLOCK, "k_start resets the scalar block with one thread per scalar");
-    if (fused_start)
+    if (start_folded) {
+    } else if (fused_start)
       hipLaunchKernelGGL(k_start, dim3(1), dim3(BLOCK), 0, st, (int)PH_INIT, 3, w.grid, (const double*)w.partials.p, w.sc.p,
                          opts.reltol * opts.reltol, opts.abstol * opts.abstol);
     else

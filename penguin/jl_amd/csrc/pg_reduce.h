@@ -23,6 +23,7 @@ struct GammaElim {
 // condition creates (1.05 M of the 10.3 M rows at 512^3: empty cells on the lateral faces).  Those rows are scattered through
 // the numbering, so the loop's vectors are COMPACT: cmap[row] = index among the remaining rows (or -1), rlist the inverse.
 struct DiagElim {
+  long long snapped_version = -1;   // pg_solver's bconst version at the last step that ran this path (-1: none / z moved since)
   bool tried = false, active = false;
   CsrMatrix A;              // the remaining rows and columns, compact numbering, own slices / marching units
   Numbering nb;

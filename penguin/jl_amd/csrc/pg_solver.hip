@@ -351,8 +351,12 @@ __global__ __launch_bounds__(BLOCK) void k_rhs_init_c(i64 n, int scheme, const d
                                                       const unsigned char* __restrict__ isblk, const int* __restrict__ cmap,
                                                       double* __restrict__ b, const double* __restrict__ gdiag,
                                                       double* __restrict__ delta, int* __restrict__ flag, int stamp,
-                                                      double* __restrict__ rhat, double* __restrict__ partials) {
+                                                      double* __restrict__ rhat, double* __restrict__ partials,
+                                                      unsigned* __restrict__ ticket, double* __restrict__ sc, double reltol2,
+                                                      double abstol2) {
   // (p = r = r̂ are NOT written: the first iteration reads r̂ for them, KrylovWork::p_in_rhat)
+  // ticket != NULL: the solver's start phase (scalar reset, start sums, PH_INIT) by the last block of this launch -- the
+  // caller knows that nothing will touch the start sums afterwards (no diagonal row can move: diag_fix is not launched)
   __shared__ double s_red[BLOCK / 64];
   double acc = 0.0, accb = 0.0, accw = 0.0;
   int moved = 0;
@@ -405,11 +409,32 @@ __global__ __launch_bounds__(BLOCK) void k_rhs_init_c(i64 n, int scheme, const d
   }
   if (__any(moved) && (threadIdx.x & 63) == 0) atomicMax(flag, stamp);
   const double t = block_sum(acc, s_red);
-  if (threadIdx.x == 0) partials[blockIdx.x] = t;
   const double tb = block_sum(accb, s_red);
-  if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = tb;
   const double tw = block_sum(accw, s_red);
-  if (threadIdx.x == 0) partials[2 * (size_t)gridDim.x + blockIdx.x] = tw;
+  if (!ticket) {
+    if (threadIdx.x == 0) {
+      partials[blockIdx.x] = t;
+      partials[gridDim.x + blockIdx.x] = tb;
+      partials[2 * (size_t)gridDim.x + blockIdx.x] = tw;
+    }
+    return;
+  }
+  if (threadIdx.x == 0) {
+    pg::store_partial(partials + blockIdx.x, t);
+    pg::store_partial(partials + gridDim.x + blockIdx.x, tb);
+    pg::store_partial(partials + 2 * (size_t)gridDim.x + blockIdx.x, tw);
+  }
+  if (!pg::last_block_arrives(ticket, gridDim.x, s_red)) return;
+  // (k_start's work, in its order of summation)
+  if (threadIdx.x < pg::S_COUNT) sc[threadIdx.x] = threadIdx.x == pg::S_RELTOL2 ? reltol2 : (threadIdx.x == pg::S_ABSTOL2 ? abstol2 : 0.0);
+  __syncthreads();
+  for (int sl = 0; sl < 3; ++sl) {
+    double a = 0.0;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += BLOCK) a += pg::load_partial(partials + (size_t)sl * gridDim.x + i);
+    const double sum = block_sum(a, s_red);
+    if (threadIdx.x == 0) sc[pg::S_RED0 + sl] = sum;
+  }
+  if (threadIdx.x == 0) pg::derive(pg::PH_INIT, sc);
 }
 
 // z refers to S_old: re-express it with S_new (x = S_old z = S_new z')
@@ -800,6 +825,14 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
   const CsrMatrix& A = run_matrix(s);
   const i64 n = s->nb.n_own;
   const bool warm = o.warm_start != 0 && o.method == PG_METHOD_BICGSTAB && n > 0;
+  const DiagElim* used_de = nullptr;   // the compact path taken in this step (its "quiet" bookkeeping stays valid)
+  struct QuietGuard {                  // any other path moves z behind the compact path's back
+    pg_solver* s; const DiagElim*& used;
+    ~QuietGuard() {
+      if (used != &s->diag_ctor) s->diag_ctor.snapped_version = -1;
+      if (used != &s->diag_run) s->diag_run.snapped_version = -1;
+    }
+  } quiet_guard{s, used_de};
   s->t += s->dt;                     // diffusion.jl:287
   ensure_bconst(s, scheme);
   if (warm) {
@@ -829,10 +862,18 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
     if (DE.active && krylov_uses_polynomial(DE.A, o)) {
       // r = r̂ = p of the remaining rows go straight to the compact vectors; the other rows are solved in the same pass
       const int stamp = (int)((s->steps_done % 2000000000) + 1);   // marks E.flag when a diagonal row moved in THIS step
+      // quiet: the previous step ran this path with the same constant data, so every diagonal row already holds its solution
+      // and none can move (beyond rounding) -- the coupling / renorm launches are not queued and the solver's start phase is
+      // folded into the right-hand-side kernel (3 launches less)
+      const bool quiet = DE.snapped_version == s->bconst_version && ctx().nranks == 1 && !ctx().comm;
       hipLaunchKernelGGL(k_rhs_init_c, dim3(w.grid), dim3(BLOCK), 0, stream, n, scheme, s->z.p, s->y.p, A.ds.p, s->mass.p, s->bconst.p,
-                         s->fixed.p, A.isblk.p, DE.cmap.p, s->b.p, (const double*)DE.gdiag.p, DE.delta.p, DE.flag.p, stamp, w.rhat.p, w.partials.p);
+                         s->fixed.p, A.isblk.p, DE.cmap.p, s->b.p, (const double*)DE.gdiag.p, DE.delta.p, DE.flag.p, stamp, w.rhat.p, w.partials.p,
+                         quiet ? w.ticket.p : nullptr, w.sc.p, o.reltol * o.reltol, o.abstol * o.abstol);
       PG_HIP(hipGetLastError());
-      diag_fix(DE, stamp, w.rhat.p, w.partials.p, w.grid, stream);
+      if (!quiet) diag_fix(DE, stamp, w.rhat.p, w.partials.p, w.grid, stream);
+      w.start_folded = quiet;
+      DE.snapped_version = s->bconst_version;
+      used_de = &DE;
       w.scatter = DE.rlist.p;
       w.p_in_rhat = true;
       try {
@@ -845,6 +886,7 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
       solved = st.poly_degree >= 0;            // -1: the polynomial stagnated on the compact system -> the full path below
       if (!solved) {        // z's rows were already set to their solution: ŷ and b̂ have to see that
         DE.active = false;
+        used_de = nullptr;
         st = SolveStats();
         spmv_halo(A, s->nb, s->slab, s->z.p, s->y.p, stream);
         if (A.n_blk > 0)
