@@ -649,7 +649,7 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
     if (!cg && !mid) finalize(PH_BICG_3, 2, w, st, true, 1);   // the last iteration's (r,r), not yet folded into a next one
     PG_HIP(hipGetLastError());
     PG_HIP(hipMemcpyAsync(w.h_sc, w.sc.p, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, st));
-    PG_HIP(hipStreamSynchronize(st));
+    PG_HIP(hipStreamSynchronize(st));   // (spinning on hipStreamQuery instead: no measurable difference)
     if (w.h_sc[S_DONE] != 0.0 || (launched >= maxiter && !mid)) done = true;
     // safety net of the polynomial preconditioner: its roots assume a (nearly) real spectrum inside the Gershgorin
     // interval; a matrix that defeats that assumption shows as stagnation, and the solve falls back to the plain iteration
