@@ -17,6 +17,8 @@ struct KrylovWork {
   // adapt_m products per application, adapt_h applications expected
   const void* adapt_matrix = nullptr;
   int adapt_m = 0, adapt_h = 0;
+  const void* need_matrix = nullptr;    // the last estimates of the products a solve on that matrix needs (newest first)
+  double need_hist[3] = {0.0, 0.0, 0.0};
   // set by the caller around one krylov_solve: the system is a compact image of the caller's (pg_reduce.hip, DiagElim) and
   // x is the caller's FULL vector -- the solution update x += q(Â)y lands at x[scatter[i]].  Needs the polynomial path.
   const int* scatter = nullptr;

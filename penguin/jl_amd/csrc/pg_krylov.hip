@@ -759,7 +759,14 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
       // 1.75 % with 0.3: 575; none with 0.6: 600 -- but 27 instead of 26 products in the bench's first 20 steps)
       static const double slack_env = getenv("PG_POLY_SLACK") ? atof(getenv("PG_POLY_SLACK")) : -1.0;
       const double slack = slack_env >= 0.0 ? slack_env : (xspace ? 0.3 : 0.0);
-      const double need = std::min(P, P * std::log(tol2 / rr0) / std::log(rr / rr0)) * margin + slack;
+      const double need_now = std::min(P, P * std::log(tol2 / rr0) / std::log(rr / rr0)) * margin + slack;
+      // the largest of the last three estimates on this matrix: the estimate wobbles by a few tenths of a product from step
+      // to step, and with one application per solve falling short by a tenth costs a whole second application
+      static const int hist_n = getenv("PG_POLY_HIST") ? std::max(1, std::min(3, atoi(getenv("PG_POLY_HIST")))) : 3;
+      if (w.need_matrix != &A) { w.need_matrix = &A; w.need_hist[0] = w.need_hist[1] = w.need_hist[2] = 0.0; }
+      w.need_hist[2] = w.need_hist[1]; w.need_hist[1] = w.need_hist[0]; w.need_hist[0] = need_now;
+      double need = need_now;
+      if (xspace) for (int q = 1; q < hist_n; ++q) need = std::max(need, std::min(w.need_hist[q], need_now + 0.6));   // (wobble, not trend)
       double best = 1e300;
       for (int h = 1; h <= 16; ++h) {
         const int mm = (int)std::ceil(need / h);
