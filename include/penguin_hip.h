@@ -143,6 +143,10 @@ typedef struct {
   int64_t rows_marched;   /* rows covered by them (counted in rows_uniform too; they are in no slice)             */
   int64_t rows_matrix;    /* rows of the matrix the other SpMV figures describe: n_own, or fewer for which = 6 / 7 (the
                              warm loop's matrix without the rows that are alone on their diagonal)                   */
+  int64_t n_ghost_loop;   /* ghost unknowns of the vectors that matrix works on (which = 6 / 7: the compact loop system
+                             keeps the remaining ghosts only; otherwise = n_ghost)                                      */
+  int64_t loop_is_compact;/* 1: the warm loop of this system iterates on the compact system (rows alone on their diagonal
+                             solved in the right-hand-side pass, pg_reduce.hip) -- on several ranks with halos too     */
 } pg_system_info;
 
 /* ---- library / device -------------------------------------------------------------------- */
@@ -156,6 +160,9 @@ int32_t pg_finalize(void);
 int32_t pg_device_synchronize(void);
 int32_t pg_set_profiling(int32_t on);
 int32_t pg_device_name(char* buf, size_t n);
+/* the tuning / variant selectors this process runs with (read once from the PG_* environment, pg_common.h Config), as
+   "name=value ..." -- so that a measurement can say exactly which variant of the path it timed */
+int32_t pg_config_string(char* buf, size_t n);
 
 /* ---- Mesh                                       replaces Mesh(n, L, x0), src/mesh.jl:47-78 ---- */
 int32_t pg_mesh_create(int32_t N, const int64_t* n, const double* L, const double* x0, pg_mesh** out);
@@ -326,6 +333,16 @@ int32_t pg_debug_run_virtual_ranks(int32_t nranks, int32_t N, const int64_t* n, 
                                    int64_t* n_ghost_out, int64_t* iters_out);
 /* Krylov method (PG_METHOD_*) and GMRES restart length of the virtual-rank runs that follow (default BiCGStab) */
 int32_t pg_debug_set_virtual_rank_method(int32_t method, int32_t restart);
+/* ramp != 0: the virtual-rank runs that follow change the interface value every step, g = interface_value (1 + ramp step)
+   (host-driven steps): rows alone on their diagonal move in every step, on every rank */
+int32_t pg_debug_set_virtual_rank_ramp(double ramp);
+/* per virtual rank of the last run: rows of the full system, rows / bytes per launch / ghost entries of the system the
+   warm loop iterated on (the compact one when loop_rows < full_rows) */
+int32_t pg_debug_virtual_rank_info(int32_t rank, int64_t* full_rows, int64_t* loop_rows, int64_t* loop_bytes,
+                                   int64_t* loop_ghosts);
+/* test hook: multiply the state at every row that is alone on its diagonal by `factor` WITHOUT telling the time loop --
+   the next quiet step must notice (S_MOVED) and still end at the right state */
+int32_t pg_debug_scale_diagonal_rows(pg_solver* s, double factor);
 
 #ifdef __cplusplus
 }

@@ -81,7 +81,8 @@ class pg_system_info(C.Structure):
                 ("n_gamma", C.c_int64), ("M_global", C.c_int64), ("spmv_bytes", C.c_int64), ("spmv_slices", C.c_int64),
                 ("rows_uniform", C.c_int64), ("rows_pattern", C.c_int64), ("rows_irregular", C.c_int64),
                 ("neumann_ok", C.c_int64), ("gershgorin", C.c_double), ("spmv_units", C.c_int64),
-                ("rows_marched", C.c_int64), ("rows_matrix", C.c_int64)]
+                ("rows_marched", C.c_int64), ("rows_matrix", C.c_int64), ("n_ghost_loop", C.c_int64),
+                ("loop_is_compact", C.c_int64)]
 
 
 def declared_symbols() -> list[str]:

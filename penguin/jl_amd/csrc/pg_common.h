@@ -59,6 +59,49 @@ void set_last_error(const std::string& msg);
     return 2;                                       \
   }
 
+// Every tuning / variant selector of the library, read from the environment ONCE (first use) into this struct: nothing
+// else in the library calls getenv, no selector is re-read per solve, and pg_config_string() reports what is active so that
+// a measurement can name exactly what ran.  Defaults = the shipped configuration; the variants exist for A/B measurements
+// and for the kernel-vs-kernel parity tests.
+struct Config {
+  bool debug = false;             // PG_DEBUG: set-up laps and solver diagnostics on stderr
+  int alloc_poison = 0;           // PG_ALLOC_POISON=1: every device allocation is filled with a NaN pattern (uninitialised reads show)
+  int async_alloc = 0;            // PG_ASYNC_ALLOC: 1 every allocation from the stream-ordered pool, -1 none
+  int alloc_guard = 0;            // PG_ALLOC_GUARD=1: guard bands around every device block, checked at free (out-of-bounds writes)
+  int alloc_sync = 0;             // PG_ALLOC_SYNC (experiments): 1 hipDeviceSynchronize before hipFree, 2 stream sync before every
+                                  // hipMalloc, 4 NO stream sync before a hipMalloc that follows pool use (reproduces round 2's corruption)
+  long long pool_limit_mb = 1024; // PG_POOL_LIMIT_MB: requests of this size and more bypass the pool (0: no limit)
+  // Krylov driver (pg_krylov.hip)
+  bool poly = true;               // PG_POLY: polynomial right preconditioner where admissible
+  int poly_degree = 6;            // PG_POLY_DEGREE: degree of the first solve on a matrix / of every solve when adaptation is off
+  bool poly_adapt = true;         // PG_POLY_ADAPT (default: on unless PG_POLY_DEGREE is given)
+  bool poly_xspace = true;        // PG_POLY_XSPACE
+  int half_test = -1;             // PG_HALF_TEST: -1 automatic (degree >= 3), 0 off, 1 on
+  bool half_batch = true;         // PG_HALF_BATCH
+  bool krylov_nt = true;          // PG_KRYLOV_NT: stream hints on the dead vectors of the vector kernels
+  double poly_margin = 1.0;       // PG_POLY_MARGIN
+  double poly_slack = -1.0;       // PG_POLY_SLACK (< 0: 0.3 products in the x-space form, 0 otherwise)
+  int poly_hist = 3;              // PG_POLY_HIST
+  int poly_maxdeg = 0;            // PG_POLY_MAXDEG (0: 32 x-space / 10 y-space)
+  bool recovery_horner = true;    // PG_RECOVERY_HORNER (y-space form)
+  int profile_sample = 3;         // PG_PROFILE_SAMPLE
+  bool gamma_elim = true;         // PG_GAMMA_ELIM
+  bool diag_elim = true;          // PG_DIAG_ELIM
+  // SpMV (pg_spmv.hip)
+  int spmv_variant = 70;          // PG_SPMV_VARIANT
+  int spmv_xcd = 1;               // PG_SPMV_XCD (bits 8..: diagnostics that give WRONG products, in the diagnostic build of the kernel only)
+  int spmv_strip = 16;            // PG_SPMV_STRIP
+  int spmv_march_k = 0;           // PG_SPMV_MARCH_K (0: the compiled-in unit depth)
+  int spmv_minrun = 24;           // PG_SPMV_MINRUN
+  bool spmv_march = true;         // PG_SPMV_MARCH
+  int spmv_tile_units = 0;        // PG_SPMV_TILE_UNITS
+  int spmv_blocks_per_cu = 0;     // PG_SPMV_BLOCKS_PER_CU (0: 4 slice kernel / 6 CSR kernels)
+  bool halo_overlap = true;       // PG_HALO_OVERLAP
+  int unit_order = 0;             // PG_SPMV_UNIT_ORDER: 0 by first row within (strip, plane); 1 units cut at common planes, window-major
+                                  // (a block's four waves on four neighbouring lines; measured 59.0 vs 54.6 us per Horner launch: off)
+};
+const Config& config();              // pg_context.hip
+
 struct LocalComm;   // in-process "virtual ranks" backend (pg_comm.hip), diagnostics only
 
 struct Context {
@@ -89,9 +132,9 @@ void comm_allreduce_sum_u64(unsigned long long* dev, i64 count, hipStream_t st);
 // Allocation: hipMalloc / hipFree, or the stream-ordered allocator on the compute stream (a pool that is never trimmed).
 // hipMalloc / hipFree synchronise the device, and a caller that rebuilds capacities and systems every time step -- the
 // moving-body solver: ~60 buffers per slab -- pays that ~120 times per step (17 -> 5 ms per slab at 1024²).  The pool serves
-// the allocations below 64 MB made inside an AsyncAllocScope (the moving path's entry points), or everywhere with
-// PG_ASYNC_ALLOC=1 (opt-in); larger blocks misbehave in this runtime's pool (pg_context.hip, pool_limit); pointers remember
-// where they came from.
+// the allocations (below 1 GiB) made inside an AsyncAllocScope (the moving path's entry points), or everywhere with
+// PG_ASYNC_ALLOC=1 (opt-in); a plain hipMalloc that follows pool use drains the compute stream first (pg_context.hip,
+// pool_limit: the two allocators do not mix otherwise); pointers remember where they came from.
 void* dev_alloc(size_t bytes);   // pg_context.hip
 void dev_free(void* p);
 struct AsyncAllocScope {
@@ -157,7 +200,7 @@ inline void* pinned_scratch(int slot, size_t bytes) {
 struct Laps {
   bool on;
   std::chrono::steady_clock::time_point t0;
-  explicit Laps() : on(getenv("PG_DEBUG") != nullptr), t0(std::chrono::steady_clock::now()) {}
+  explicit Laps() : on(config().debug), t0(std::chrono::steady_clock::now()) {}
   void lap(const char* what) {
     if (!on) return;
     (void)hipDeviceSynchronize();

@@ -1,7 +1,13 @@
 // pg_context.hip -- device / stream / RCCL communicator lifetime, error channel, Mesh.
 #include "pg_common.h"
 
+#include <cxxabi.h>
+#include <execinfo.h>
+
+#include <atomic>
+#include <map>
 #include <mutex>
+#include <unordered_map>
 #include <unordered_set>
 #include "pg_host_algos.h"
 
@@ -19,6 +25,47 @@ Context& ctx() {
   static Context c;
   Context* t = thread_context();
   return t ? *t : c;
+}
+
+const Config& config() {
+  static const Config c = [] {
+    Config k;
+    auto geti = [](const char* name, long long dflt) { const char* v = getenv(name); return v ? atoll(v) : dflt; };
+    auto getd = [](const char* name, double dflt) { const char* v = getenv(name); return v ? atof(v) : dflt; };
+    k.debug = getenv("PG_DEBUG") != nullptr;
+    k.alloc_poison = (int)geti("PG_ALLOC_POISON", 0);
+    k.async_alloc = (int)geti("PG_ASYNC_ALLOC", 0);
+    k.alloc_sync = (int)geti("PG_ALLOC_SYNC", 0);
+    k.alloc_guard = (int)geti("PG_ALLOC_GUARD", 0);
+    k.pool_limit_mb = geti("PG_POOL_LIMIT_MB", 1024);
+    k.poly = geti("PG_POLY", 1) != 0;
+    k.poly_degree = (int)geti("PG_POLY_DEGREE", 6);
+    k.poly_adapt = geti("PG_POLY_ADAPT", getenv("PG_POLY_DEGREE") ? 0 : 1) != 0;
+    k.poly_xspace = geti("PG_POLY_XSPACE", 1) != 0;
+    k.half_test = (int)geti("PG_HALF_TEST", -1);
+    k.half_batch = geti("PG_HALF_BATCH", 1) != 0;
+    k.krylov_nt = geti("PG_KRYLOV_NT", 1) != 0;
+    k.poly_margin = getd("PG_POLY_MARGIN", 1.0);
+    k.poly_slack = getd("PG_POLY_SLACK", -1.0);
+    k.poly_hist = (int)std::max<long long>(1, std::min<long long>(3, geti("PG_POLY_HIST", 3)));
+    k.poly_maxdeg = (int)geti("PG_POLY_MAXDEG", 0);
+    k.recovery_horner = geti("PG_RECOVERY_HORNER", 1) != 0;
+    k.profile_sample = (int)std::max<long long>(1, geti("PG_PROFILE_SAMPLE", 3));
+    k.gamma_elim = geti("PG_GAMMA_ELIM", 1) != 0;
+    k.diag_elim = geti("PG_DIAG_ELIM", 1) != 0;
+    k.spmv_variant = (int)geti("PG_SPMV_VARIANT", 70);
+    k.spmv_xcd = (int)geti("PG_SPMV_XCD", 1);
+    k.spmv_strip = (int)geti("PG_SPMV_STRIP", 16);
+    k.spmv_march_k = (int)geti("PG_SPMV_MARCH_K", 0);
+    k.spmv_minrun = (int)geti("PG_SPMV_MINRUN", 24);
+    k.spmv_march = geti("PG_SPMV_MARCH", 1) != 0;
+    k.spmv_tile_units = (int)geti("PG_SPMV_TILE_UNITS", 0);
+    k.spmv_blocks_per_cu = (int)geti("PG_SPMV_BLOCKS_PER_CU", 0);
+    k.halo_overlap = geti("PG_HALO_OVERLAP", 1) != 0;
+    k.unit_order = (int)geti("PG_SPMV_UNIT_ORDER", 0);
+    return k;
+  }();
+  return c;
 }
 
 void require_init() {
@@ -52,24 +99,139 @@ namespace {
 thread_local int t_async_scope = 0;
 std::mutex g_pool_mutex;
 std::unordered_set<void*> g_pool_ptrs;
-int async_mode() {      // PG_ASYNC_ALLOC: 1 every allocation from the pool, -1 none (not even inside an AsyncAllocScope)
-  static const int m = getenv("PG_ASYNC_ALLOC") ? atoi(getenv("PG_ASYNC_ALLOC")) : 0;
-  return m;
+// PG_ALLOC_SYNC bit 32 (debugging): every live block, pooled or plain, with its size: a new block that overlaps a live one is
+// reported (two owners of one piece of memory: an allocator bug, ours or the runtime's)
+std::map<char*, std::pair<size_t, int>> g_live;   // start -> (bytes, 1 pooled / 0 plain)
+void live_insert(void* p, size_t bytes, int pooled) {
+  if (!(config().alloc_sync & 32) || !p) return;
+  std::lock_guard<std::mutex> lk(g_pool_mutex);
+  char* a = static_cast<char*>(p);
+  auto it = g_live.lower_bound(a);
+  auto report = [&](const std::pair<char* const, std::pair<size_t, int>>& o) {
+    fprintf(stderr, "[pg_alloc] OVERLAP: new %s block %p + %zu overlaps live %s block %p + %zu\n", pooled ? "pool" : "plain", p, bytes,
+            o.second.second ? "pool" : "plain", (void*)o.first, o.second.first);
+  };
+  if (it != g_live.end() && it->first < a + bytes) report(*it);
+  if (it != g_live.begin()) {
+    auto pr = std::prev(it);
+    if (pr->first + pr->second.first > a) report(*pr);
+  }
+  g_live[a] = {bytes, pooled};
 }
+void live_erase(void* p) {
+  if (!(config().alloc_sync & 32) || !p) return;
+  std::lock_guard<std::mutex> lk(g_pool_mutex);
+  g_live.erase(static_cast<char*>(p));
+}
+int async_mode() { return config().async_alloc; }   // 1 every allocation from the pool, -1 none (not even inside an AsyncAllocScope)
 bool async_everywhere() { return async_mode() > 0; }
-// Requests of this size and more go the ordinary way (PG_POOL_LIMIT_MB, default 64).  Measured on this runtime: with blocks of
-// 370 MB in the pool (a 3072² slab) buffers came back with stale zeros in them and slabs took 100+ ms, with > 2 GiB requests
-// the process aborted; up to 165 MB (2048²) everything was fine.  The gain is in the dozens of SMALL buffers a slab creates
-// and frees (lists, counters, per-row flags): 64 MB keeps all of it (1024²: 5.5 ms per slab against 17 without the pool).
+// Requests of this size and more go the ordinary way (PG_POOL_LIMIT_MB, default 1024: a pool request above 2 GiB aborts the
+// process in this runtime).
+// MIXING the two allocators needs care, and that -- not the size of the pooled blocks -- is what corrupted the 3072² / 4096²
+// slabs of round 2 (profiles/r03_pool_experiment.txt): a plain hipMalloc issued while stream-ordered frees are still
+// PENDING on the compute stream may be served with a block that a hipFreeAsync has released in stream order only -- its
+// last kernels have not run yet -- and the new owner's first writes (a memset, an upload) land in the old owner's data.
+// With everything in the pool, or nothing, the same slabs are bitwise identical; with a 64 MB or a 256 MB limit they were
+// wrong (different active sets from run to run), and a stream synchronisation before every plain hipMalloc made them right
+// again.  scripts/repro/hip_pool_then_malloc.hip is the 60-line demonstration on the bare runtime.  Hence: once this process
+// has used the pool, dev_alloc drains the compute stream before a plain hipMalloc (g_pool_used).
+std::atomic<bool> g_pool_used{false};
 size_t pool_limit() {
-  static const size_t lim = (size_t)(getenv("PG_POOL_LIMIT_MB") ? atoi(getenv("PG_POOL_LIMIT_MB")) : 64) << 20;
-  return lim;
+  const long long mb = config().pool_limit_mb;
+  return mb > 0 ? (size_t)mb << 20 : ~(size_t)0;
 }
 }  // namespace
+// PG_ALLOC_GUARD=1 (debugging): every block sits between two 4 KiB guard bands of 0xA5 bytes that are checked when the block
+// is freed -- an out-of-bounds WRITE shows with the size of the block it ran off, the side, the first damaged byte and the
+// call stack that allocated the block.  (Plain hipMalloc blocks are padded to large pages, so an overrun is silent there;
+// pool blocks are packed 256 bytes apart and an overrun lands in another buffer's data.)
+constexpr size_t GUARD = 4096;
+struct GuardInfo { char* raw; size_t bytes; unsigned long long seq; std::string where; };
+std::unordered_map<void*, GuardInfo> g_guarded;
+unsigned long long g_alloc_seq = 0;
+std::string call_stack() {
+  void* frames[24];
+  const int nf = backtrace(frames, 24);
+  char** sym = backtrace_symbols(frames, nf);
+  std::string s;
+  for (int i = 2; sym && i < nf && i < 12; ++i) {
+    std::string f = sym[i];
+    const size_t a = f.find('('), b = f.find('+', a == std::string::npos ? 0 : a);
+    if (a != std::string::npos && b != std::string::npos && b > a + 1) {
+      std::string mangled = f.substr(a + 1, b - a - 1);
+      int st = 0;
+      char* dem = abi::__cxa_demangle(mangled.c_str(), nullptr, nullptr, &st);
+      f = st == 0 && dem ? dem : mangled;
+      free(dem);
+      const size_t par = f.find('(');
+      if (par != std::string::npos) f = f.substr(0, par);
+    }
+    s += (s.empty() ? "" : " <- ") + f;
+  }
+  free(sym);
+  return s;
+}
 AsyncAllocScope::AsyncAllocScope() { ++t_async_scope; }
 AsyncAllocScope::~AsyncAllocScope() { --t_async_scope; }
 
+// PG_ALLOC_POISON=1 (debugging): every block starts as 0xFF bytes -- NaN as a double, -1 as an int -- on the stream its first
+// user is ordered on.  A buffer that is read before it is written then shows in the results instead of passing by the
+// accident of fresh (zeroed) device pages; pool blocks and hipMalloc blocks alike.
+static void poison(void* p, size_t bytes) {
+  if (!config().alloc_poison || !p || bytes == 0) return;
+  Context& c = ctx();
+  if (c.inited && c.stream) PG_HIP(hipMemsetAsync(p, 0xFF, bytes, c.stream));
+  else PG_HIP(hipMemset(p, 0xFF, bytes));
+}
+
+static void* dev_alloc_raw(size_t bytes);
+static void dev_free_raw(void* p);
+
 void* dev_alloc(size_t bytes) {
+  if (!config().alloc_guard) return dev_alloc_raw(bytes);
+  char* raw = static_cast<char*>(dev_alloc_raw(bytes + 2 * GUARD));
+  Context& c = ctx();
+  hipStream_t st = (c.inited && c.stream) ? c.stream : nullptr;
+  PG_HIP(hipMemsetAsync(raw, 0xA5, GUARD, st));
+  PG_HIP(hipMemsetAsync(raw + GUARD + bytes, 0xA5, GUARD, st));
+  void* user = raw + GUARD;
+  std::lock_guard<std::mutex> lk(g_pool_mutex);
+  g_guarded[user] = GuardInfo{raw, bytes, ++g_alloc_seq, call_stack()};
+  return user;
+}
+
+void dev_free(void* p) {
+  if (!config().alloc_guard) { dev_free_raw(p); return; }
+  GuardInfo gi;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    auto it = g_guarded.find(p);
+    if (it == g_guarded.end()) { dev_free_raw(p); return; }
+    gi = it->second;
+    g_guarded.erase(it);
+  }
+  (void)hipDeviceSynchronize();
+  std::vector<unsigned char> lo(GUARD), hi(GUARD);
+  (void)hipMemcpy(lo.data(), gi.raw, GUARD, hipMemcpyDeviceToHost);
+  (void)hipMemcpy(hi.data(), gi.raw + GUARD + gi.bytes, GUARD, hipMemcpyDeviceToHost);
+  auto first_bad = [](const std::vector<unsigned char>& g, bool from_end) -> long {
+    if (from_end) { for (long i = (long)g.size() - 1; i >= 0; --i) if (g[i] != 0xA5) return i; }
+    else { for (size_t i = 0; i < g.size(); ++i) if (g[i] != 0xA5) return (long)i; }
+    return -1;
+  };
+  const long bl = first_bad(lo, true), bh = first_bad(hi, false);
+  if (bl >= 0 || bh >= 0) {
+    long nl = 0, nh = 0;
+    for (unsigned char v : lo) nl += v != 0xA5;
+    for (unsigned char v : hi) nh += v != 0xA5;
+    fprintf(stderr, "[pg_alloc] GUARD DAMAGED: block #%llu of %zu bytes (incl. 64 of slack): %ld bytes written BELOW it (nearest %ld bytes "
+            "before the start), %ld bytes written ABOVE it (first %ld bytes past the end); allocated by: %s\n", gi.seq, gi.bytes, nl,
+            bl >= 0 ? (long)GUARD - bl : 0, nh, bh >= 0 ? bh : 0, gi.where.c_str());
+  }
+  dev_free_raw(gi.raw);
+}
+
+static void* dev_alloc_raw(size_t bytes) {
   void* p = nullptr;
   Context& c = ctx();
   if ((t_async_scope > 0 || async_everywhere()) && async_mode() >= 0 && c.inited && c.stream && !c.local && bytes < pool_limit()) {
@@ -82,19 +244,34 @@ void* dev_alloc(size_t bytes) {
       }
       pool_set = true;
     }
+    if (config().alloc_sync & 8) (void)hipStreamSynchronize(c.stream);
     if (hipMallocAsync(&p, bytes, c.stream) == hipSuccess && p) {
-      std::lock_guard<std::mutex> lk(g_pool_mutex);
-      g_pool_ptrs.insert(p);
+      {
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        g_pool_ptrs.insert(p);
+      }
+      g_pool_used.store(true, std::memory_order_relaxed);
+      live_insert(p, bytes, 1);
+      poison(p, bytes);
       return p;
     }
     (void)hipGetLastError();
     p = nullptr;
   }
+  // (see pool_limit: pending stream-ordered frees and a plain hipMalloc do not mix; PG_ALLOC_SYNC=4 switches the drain off
+  //  to reproduce the failure)
+  if ((g_pool_used.load(std::memory_order_relaxed) && !(config().alloc_sync & 4)) || (config().alloc_sync & 2)) {
+    Context& pc = ctx();
+    if (pc.inited && pc.stream) (void)hipStreamSynchronize(pc.stream);
+  }
   PG_HIP(hipMalloc(&p, bytes));
+  live_insert(p, bytes, 0);
+  poison(p, bytes);
   return p;
 }
 
-void dev_free(void* p) {
+static void dev_free_raw(void* p) {
+  live_erase(p);
   bool pooled = false;
   {
     std::lock_guard<std::mutex> lk(g_pool_mutex);
@@ -103,9 +280,11 @@ void dev_free(void* p) {
   if (pooled) {
     Context* c = thread_context();
     Context& cc = c ? *c : ctx();
+    if (cc.inited && cc.stream && (config().alloc_sync & 16)) (void)hipStreamSynchronize(cc.stream);
     if (cc.inited && cc.stream && hipFreeAsync(p, cc.stream) == hipSuccess) return;
     (void)hipGetLastError();
   }
+  if (config().alloc_sync & 1) (void)hipDeviceSynchronize();
   (void)hipFree(p);
 }
 }  // namespace pg
@@ -186,6 +365,26 @@ int32_t pg_device_synchronize(void) {
 int32_t pg_set_profiling(int32_t on) {
   PG_API_BEGIN
   ctx().profiling = on != 0;
+  PG_API_END
+}
+
+int32_t pg_config_string(char* buf, size_t n) {
+  PG_API_BEGIN
+  const Config& k = config();
+  char tmp[1024];
+  snprintf(tmp, sizeof(tmp),
+           "spmv_variant=%d spmv_xcd=%d spmv_strip=%d spmv_unit_order=%d spmv_march=%d spmv_march_k=%d spmv_minrun=%d spmv_tile_units=%d "
+           "spmv_blocks_per_cu=%d halo_overlap=%d poly=%d poly_degree=%d poly_adapt=%d poly_xspace=%d half_test=%d half_batch=%d "
+           "krylov_nt=%d poly_margin=%g poly_slack=%g poly_hist=%d poly_maxdeg=%d recovery_horner=%d gamma_elim=%d diag_elim=%d "
+           "async_alloc=%d pool_limit_mb=%lld alloc_poison=%d profile_sample=%d debug=%d",
+           k.spmv_variant, k.spmv_xcd, k.spmv_strip, k.unit_order, (int)k.spmv_march, k.spmv_march_k, k.spmv_minrun, k.spmv_tile_units,
+           k.spmv_blocks_per_cu, (int)k.halo_overlap, (int)k.poly, k.poly_degree, (int)k.poly_adapt, (int)k.poly_xspace, k.half_test,
+           (int)k.half_batch, (int)k.krylov_nt, k.poly_margin, k.poly_slack, k.poly_hist, k.poly_maxdeg, (int)k.recovery_horner,
+           (int)k.gamma_elim, (int)k.diag_elim, k.async_alloc, k.pool_limit_mb, k.alloc_poison, k.profile_sample, (int)k.debug);
+  if (buf && n > 0) {
+    std::strncpy(buf, tmp, n - 1);
+    buf[n - 1] = 0;
+  }
   PG_API_END
 }
 

@@ -40,6 +40,12 @@ struct VArgs {
 
 // Krylov method of the virtual-rank runs (pg_debug_set_virtual_rank_method): BiCGStab unless a test asks otherwise
 int g_method = PG_METHOD_BICGSTAB, g_restart = 0;
+// pg_debug_set_virtual_rank_ramp: != 0: the interface value changes from step to step, g = value (1 + ramp step) -- the rows
+// alone on their diagonal then MOVE in every step and the compact loop has to carry their change to the rows coupled to
+// them, across slab faces too (pg_reduce.hip diag_fix with the exchange of the deltas)
+double g_ramp = 0.0;
+// what the loop of each rank iterated on in the last run (pg_debug_virtual_rank_info)
+int64_t g_loop_rows[8], g_loop_bytes[8], g_loop_ghosts[8], g_full_rows[8];
 
 void check(int32_t st, const char* what) {
   if (st != 0) {
@@ -81,9 +87,31 @@ void rank_main(const VArgs& a, int rank, LocalComm* lc, int device, std::string*
                                          a.scheme_ctor, &sol), "solver");
     pg_krylov_opts o{g_method, 1e-13, 0.0, 0, 4, g_method == PG_METHOD_BICGSTAB ? 1 : 0, g_restart};
     pg_run_info info{};
-    check(pg_solver_run(sol, 1e300, a.scheme_run, &o, 1, a.steps, 0, &info), "run");
+    if (g_ramp == 0.0) {
+      check(pg_solver_run(sol, 1e300, a.scheme_run, &o, 1, a.steps, 0, &info), "run");
+    } else {
+      pg_step_info sti{};
+      check(pg_solver_initial_solve(sol, &o, &sti), "initial solve");
+      info.total_iters = sti.iters;
+      std::vector<double> g0(M), g1(M);
+      for (int64_t k = 0; k < a.steps; ++k) {
+        std::fill(g0.begin(), g0.end(), a.interface_value * (1.0 + g_ramp * (double)k));
+        std::fill(g1.begin(), g1.end(), a.interface_value * (1.0 + g_ramp * (double)(k + 1)));
+        check(pg_solver_set_interface_value(sol, g0.data(), g1.data()), "interface value");
+        check(pg_solver_step(sol, a.scheme_run, &o, &sti), "step");
+        info.total_iters += sti.iters;
+      }
+    }
     pg_system_info si{};
     check(pg_solver_system_info(sol, 1, &si), "info");
+    {
+      pg_system_info li{};
+      check(pg_solver_system_info(sol, 1 | 4 | 2, &li), "loop info");
+      g_loop_rows[rank] = li.rows_matrix;
+      g_loop_bytes[rank] = li.spmv_bytes;
+      g_loop_ghosts[rank] = li.n_ghost_loop;
+      g_full_rows[rank] = si.n_own;
+    }
     a.n_own_out[rank] = si.n_own;
     a.nnz_out[rank] = si.nnz;
     a.n_ghost_out[rank] = si.n_ghost;
@@ -112,6 +140,23 @@ extern "C" int32_t pg_debug_set_virtual_rank_method(int32_t method, int32_t rest
   PG_REQUIRE(method == PG_METHOD_BICGSTAB || method == PG_METHOD_CG || method == PG_METHOD_GMRES, "unknown Krylov method");
   g_method = method;
   g_restart = restart;
+  PG_API_END
+}
+
+extern "C" int32_t pg_debug_set_virtual_rank_ramp(double ramp) {
+  PG_API_BEGIN
+  g_ramp = ramp;
+  PG_API_END
+}
+
+extern "C" int32_t pg_debug_virtual_rank_info(int32_t rank, int64_t* full_rows, int64_t* loop_rows, int64_t* loop_bytes,
+                                              int64_t* loop_ghosts) {
+  PG_API_BEGIN
+  PG_REQUIRE(rank >= 0 && rank < 8, "pg_debug_virtual_rank_info: rank out of range");
+  if (full_rows) *full_rows = g_full_rows[rank];
+  if (loop_rows) *loop_rows = g_loop_rows[rank];
+  if (loop_bytes) *loop_bytes = g_loop_bytes[rank];
+  if (loop_ghosts) *loop_ghosts = g_loop_ghosts[rank];
   PG_API_END
 }
 

@@ -44,6 +44,10 @@ struct MarchGeometry {
   // cell = (plane * lines + line) * ext0 + i, and the units are ordered strip by strip (see below)
   int64_t ext0 = 0, lines = 0;
   int strip = 0;      // lateral lines per strip (0: order by first row)
+  // 1 (needs the grid geometry): units are cut at COMMON planes (every unit starts at a multiple of kmax or at the start of
+  // its chain) and ordered window-major inside a (strip, plane group): the four waves of a block then hold four
+  // neighbouring lines of one window over the same planes, and a unit's lateral lines are its block mates' own lines
+  int unit_order = 0;
 };
 
 // place of a grid cell in the order of the work items: strip of lateral lines, then plane; ties by row number
@@ -107,7 +111,13 @@ inline void plan_march_units(int64_t n, const std::vector<MRun>& runs, const std
     }
     if (best >= 0) { succ[i] = (int)best; pred[best] = (int)i; }
   }
-  struct Unit { int key; int64_t order; std::vector<int> rec; };
+  struct Unit { int key; int64_t order; int64_t sub; std::vector<int> rec; };
+  const bool aligned = geo.unit_order == 1 && geo.strip > 0 && geo.ext0 > 0 && geo.lines > 0 && RI > 24;
+  // absolute plane of a run (-1: unknown)
+  auto plane_of = [&](i64 run) -> i64 {
+    const i64 cell = info[RI * run + 24];
+    return cell >= 0 ? cell / (geo.ext0 * geo.lines) : -1;
+  };
   std::vector<Unit> units;
   // every load of a unit reads elements idx0 .. idx0 + 129 of a vector of >= n elements (+ 8 of slack, DevBuf)
   auto safe = [&](i64 idx0) { return idx0 >= 0 && idx0 + 130 <= n + 8; };
@@ -143,7 +153,10 @@ inline void plan_march_units(int64_t n, const std::vector<MRun>& runs, const std
         i64 lo, hi;
         if (!range(k, lo, hi)) { ++k; continue; }
         i64 k1 = k;
-        while (k1 < L && k1 - k < geo.kmax && range(k1, lo, hi)) ++k1;
+        while (k1 < L && k1 - k < geo.kmax && range(k1, lo, hi)) {
+          ++k1;
+          if (aligned && Y && k1 < L && plane_of(chain[k1]) >= 0 && plane_of(chain[k1]) % geo.kmax == 0) break;   // common cut
+        }
         const int K = (int)(k1 - k);
         bool fits = safe(B[k] + off(chain[k], dn_e) + W) && safe(B[k1 - 1] + off(chain[k1 - 1], up_e) + W);
         for (i64 q = k; q < k1 && fits; ++q) {
@@ -163,10 +176,18 @@ inline void plan_march_units(int64_t n, const std::vector<MRun>& runs, const std
         range(k, lo, hi);
         u.key = (int)(B[k] + lo);
         u.order = 0;
+        u.sub = 0;
         if (Y && geo.strip > 0 && geo.ext0 > 0 && geo.lines > 0 && RI > 24) {
           const i64 cell = info[RI * chain[k] + 24];
           if (cell >= 0) {
             u.order = march_order(cell, geo.ext0, geo.lines, geo.strip);
+            if (aligned) {
+              // plane GROUP instead of plane; then the window (grid position of the unit's first row along the line), then the line
+              const i64 line = (cell / geo.ext0) % geo.lines, plane = cell / (geo.ext0 * geo.lines);
+              u.order = (line / geo.strip) * ((i64)1 << 20) + plane / geo.kmax;
+              const i64 x0 = cell % geo.ext0 + ((B[k] + lo) - (i64)runs[chain[k]].r0);
+              u.sub = (x0 / geo.W) * ((i64)1 << 20) + line;
+            }
           }
         }
         const int Kp = K <= geo.KS ? geo.KS : geo.K;   // the kernel's two unit sizes: shorter units end with empty planes
@@ -201,7 +222,10 @@ inline void plan_march_units(int64_t n, const std::vector<MRun>& runs, const std
       }
     }
   }
-  std::sort(units.begin(), units.end(), [](const Unit& a, const Unit& b) { return a.order != b.order ? a.order < b.order : a.key < b.key; });
+  std::sort(units.begin(), units.end(), [](const Unit& a, const Unit& b) {
+    if (a.order != b.order) return a.order < b.order;
+    return a.sub != b.sub ? a.sub < b.sub : a.key < b.key;
+  });
   mrec.reserve(units.size() * geo.REC);
   for (auto& u : units) mrec.insert(mrec.end(), u.rec.begin(), u.rec.end());
   if (okeys) {   // the order as one number per unit (build_tiles lines the slices up with it)

@@ -346,7 +346,7 @@ struct SpmvTimer {
     // chain of lean launches and the closing launch of each half, so all four are sampled in turn).  A pair of event
     // records costs the stream ~10 µs (the kernel behind a record starts late): a lean chain is bracketed as a WHOLE so
     // that this cost is spread over its m - 1 launches; rocprofv3's per-kernel durations (profiles/) are the cross-check
-    static const int sample = getenv("PG_PROFILE_SAMPLE") ? std::max(1, atoi(getenv("PG_PROFILE_SAMPLE"))) : 3;
+    const int sample = config().profile_sample;
     static thread_local unsigned long long counter = 0;
     armed = on && (counter++ % sample == 0);
     if (!armed) return;
@@ -420,8 +420,8 @@ void spmv(const CsrMatrix& A, const double* x, double* y, hipStream_t st) {
 }
 
 bool krylov_uses_polynomial(const CsrMatrix& A, const pg_krylov_opts& opts) {
-  static const bool poly_env = getenv("PG_POLY") ? atoi(getenv("PG_POLY")) != 0 : true;
-  static const int degree_env = getenv("PG_POLY_DEGREE") ? atoi(getenv("PG_POLY_DEGREE")) : 6;
+  const bool poly_env = config().poly;
+  const int degree_env = config().poly_degree;
   if (!(poly_env && opts.precond >= 0 && opts.method == PG_METHOD_BICGSTAB && A.poly_ok && spmv_supports_preconditioner_product() && A.n > 0))
     return false;
   return (opts.precond > 0 ? opts.precond : degree_env) >= 2;
@@ -460,16 +460,17 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
   SpmvTimer timer(cx.profiling);
 
   const bool cg = opts.method == PG_METHOD_CG;
-  static const bool ntv = getenv("PG_KRYLOV_NT") ? atoi(getenv("PG_KRYLOV_NT")) != 0 : true;
-  static const bool poly_env = getenv("PG_POLY") ? atoi(getenv("PG_POLY")) != 0 : true;
-  static const int degree_env = getenv("PG_POLY_DEGREE") ? atoi(getenv("PG_POLY_DEGREE")) : 6;
+  const Config& cfg = config();
+  const bool ntv = cfg.krylov_nt;
+  const bool poly_env = cfg.poly;
+  const int degree_env = cfg.poly_degree;
   // polynomial right preconditioner: BiCGStab on the slice kernel, where Gershgorin bounds the spectrum inside
   // |λ - 1| < 0.95; m products with Â per application of C = I - R(Â)  (m < 2: the plain iteration)
   int m = 0;
   if (poly_env && opts.precond >= 0 && !cg && A.poly_ok && spmv_supports_preconditioner_product() && n > 0)
     m = std::min(opts.precond > 0 ? opts.precond : degree_env, MAX_POLY_DEGREE);
   // auto mode: the degree that fits the number of products the previous solve on this matrix would have needed (below)
-  static const bool adapt_env = getenv("PG_POLY_ADAPT") ? atoi(getenv("PG_POLY_ADAPT")) != 0 : !getenv("PG_POLY_DEGREE");
+  const bool adapt_env = cfg.poly_adapt;
   const bool adaptive = adapt_env && m >= 2 && opts.precond == 0 && preinit;
   int expect_halves = 0;
   if (adaptive && w.adapt_matrix == &A && w.adapt_m >= 2) { m = w.adapt_m; expect_halves = w.adapt_h; }
@@ -496,14 +497,14 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
   // accumulates the solution y of the preconditioned system and recovers x = x0 + q(Â) y at the end: m - 1 Horner launches
   // and an update per SOLVE -- with 3 applications of degree 9 that recovery was 0.49 ms of a 2.4 ms step, the third stream
   // of 21 launches costs 0.17.
-  static const bool xspace_env = getenv("PG_POLY_XSPACE") ? atoi(getenv("PG_POLY_XSPACE")) != 0 : true;
+  const bool xspace_env = cfg.poly_xspace;
   const bool xspace = poly && xspace_env;
   stats.poly_xspace = xspace ? 1 : 0;
   double* const xit = (poly && !xspace) ? w.ya.p : x;   // what the iteration updates
   const int* const xmap = xspace ? w.scatter : nullptr; // ... through the caller's index map when the system is a compact image
   // convergence is also tested after the first half of an iteration when a half costs several products (the test itself
   // costs two small launches); PG_HALF_TEST=0/1 forces it off / on
-  static const int half_env = getenv("PG_HALF_TEST") ? atoi(getenv("PG_HALF_TEST")) : -1;
+  const int half_env = cfg.half_test;
   const bool half_test = !cg && (half_env < 0 ? m >= 3 : half_env != 0);
   PG_REQUIRE(!preinit || !cg, "preinit is a BiCGStab path");
   if (!cg) {
@@ -612,7 +613,7 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
                             w.p.p, w.rhat.p, w.partials.p, (const double*)A.ds.p, (poly && !xspace) ? 1 : 0, p_in_rhat ? 1 : 0,
                                 xspace ? (const double*)w.ya.p : nullptr, xspace ? (const double*)w.yb.p : nullptr, xmap);
   };
-  static const bool half_batches = getenv("PG_HALF_BATCH") ? atoi(getenv("PG_HALF_BATCH")) != 0 : true;   // (0: whole iterations, for A/B runs)
+  const bool half_batches = cfg.half_batch;   // (0: whole iterations, for A/B runs)
   while (!done) {
     int want = check_every;
     if (w.last_iters > 1) want = polls == 0 ? w.last_iters - 1 : (polls <= 4 ? 1 : check_every);
@@ -665,7 +666,7 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
       stats.poly_degree = -1;
       return;
     }
-    if (getenv("PG_DEBUG")) fprintf(stderr, "[pg_krylov] polynomial preconditioner (m = %d) stagnated after %d iterations: plain iteration\n", m, launched);
+    if (cfg.debug) fprintf(stderr, "[pg_krylov] polynomial preconditioner (m = %d) stagnated after %d iterations: plain iteration\n", m, launched);
     spmv_with_halo(0, A, nb, slab, x, w.t.p, nullptr, nullptr, nullptr, G, st);   // Â x of the iterate reached
     SolveStats rest;
     krylov_solve(A, nb, slab, b, x, w, opts, rest, x, w.t.p, false);
@@ -681,7 +682,7 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
     // m - 1 launches of three vector streams each (the accumulating form, mode 7, read and wrote x as a fourth in every
     // launch); the factors are applied in the reverse of the chain's order, which alternates between the two ends of the
     // spectrum either way.  (No done flag here: it is set.)
-    static const bool horner_env = getenv("PG_RECOVERY_HORNER") ? atoi(getenv("PG_RECOVERY_HORNER")) != 0 : true;
+    const bool horner_env = cfg.recovery_horner;
     const bool horner = horner_env || w.scatter != nullptr;
     double* src = w.ya.p;
     if (horner) {
@@ -715,7 +716,7 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
       return;
     }
     if (poly_failed) {
-      if (getenv("PG_DEBUG")) fprintf(stderr, "[pg_krylov] polynomial preconditioner (m = %d) stagnated after %d iterations: plain iteration\n", m, launched);
+      if (cfg.debug) fprintf(stderr, "[pg_krylov] polynomial preconditioner (m = %d) stagnated after %d iterations: plain iteration\n", m, launched);
       const_cast<CsrMatrix&>(A).poly_ok = false;
       spmv_with_halo(0, A, nb, slab, x, w.t.p, nullptr, nullptr, nullptr, G, st);   // Â x of the iterate reached
       timer.collect(stats, launched, false);
@@ -726,7 +727,7 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
       return;
     }
   }
-  if (getenv("PG_DEBUG"))
+  if (cfg.debug)
     fprintf(stderr, "[pg_krylov] done=%g iters=%g rr0=%g rr=%g tol2=%g rho=%g rho_old=%g alpha=%g omega=%g beta=%g red0=%g red1=%g\n",
             w.h_sc[S_DONE], w.h_sc[S_ITERS], w.h_sc[S_RR0], w.h_sc[S_RR], w.h_sc[S_TOL2], w.h_sc[S_RHO], w.h_sc[S_RHO_OLD], w.h_sc[S_ALPHA],
             w.h_sc[S_OMEGA], w.h_sc[S_BETA], w.h_sc[S_RED0], w.h_sc[S_RED1]);
@@ -753,16 +754,16 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
     const double rr0 = w.h_sc[S_RR0], rr = w.h_sc[S_HALF] != 0.0 ? w.h_sc[S_RED4] : w.h_sc[S_RR], tol2 = w.h_sc[S_TOL2];
     const double P = (2.0 * stats.iters - stats.half_exit) * m;
     if (rr0 > tol2 && rr > 0.0 && rr < rr0 && tol2 > 0.0) {
-      static const double margin = getenv("PG_POLY_MARGIN") ? atof(getenv("PG_POLY_MARGIN")) : 1.0;
+      const double margin = cfg.poly_margin;
       // x-space: a third of a product of slack -- with ONE application per solve a miss costs a whole second one, and the
       // estimate moves by a few tenths from step to step (200 steps at 512^3: 7 % of the solves missed without it, 548 steps/s;
       // 1.75 % with 0.3: 575; none with 0.6: 600 -- but 27 instead of 26 products in the bench's first 20 steps)
-      static const double slack_env = getenv("PG_POLY_SLACK") ? atof(getenv("PG_POLY_SLACK")) : -1.0;
+      const double slack_env = cfg.poly_slack;
       const double slack = slack_env >= 0.0 ? slack_env : (xspace ? 0.3 : 0.0);
       const double need_now = std::min(P, P * std::log(tol2 / rr0) / std::log(rr / rr0)) * margin + slack;
       // the largest of the last three estimates on this matrix: the estimate wobbles by a few tenths of a product from step
       // to step, and with one application per solve falling short by a tenth costs a whole second application
-      static const int hist_n = getenv("PG_POLY_HIST") ? std::max(1, std::min(3, atoi(getenv("PG_POLY_HIST")))) : 3;
+      const int hist_n = cfg.poly_hist;
       if (w.need_matrix != &A) { w.need_matrix = &A; w.need_hist[0] = w.need_hist[1] = w.need_hist[2] = 0.0; }
       w.need_hist[2] = w.need_hist[1]; w.need_hist[1] = w.need_hist[0]; w.need_hist[0] = need_now;
       double need = need_now;
@@ -770,7 +771,7 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
       double best = 1e300;
       for (int h = 1; h <= 16; ++h) {
         const int mm = (int)std::ceil(need / h);
-        const int maxdeg = getenv("PG_POLY_MAXDEG") ? std::min(MAX_POLY_DEGREE, std::max(4, atoi(getenv("PG_POLY_MAXDEG")))) : (xspace ? 32 : 10);
+        const int maxdeg = cfg.poly_maxdeg > 0 ? std::min(MAX_POLY_DEGREE, std::max(4, cfg.poly_maxdeg)) : (xspace ? 32 : 10);
         if (mm < 4 || mm > maxdeg) continue;
         // x-space: a chain = one lean launch + mm - 2 Horner launches (1.18 lean launches each), closing launch + vector
         // kernel ≈ 3.6; y-space: mm - 1 lean launches, closing ≈ 3.2, + the recovery's mm - 1 Horner launches per solve
@@ -778,7 +779,7 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
         if (cost < best) { best = cost; w.adapt_m = mm; w.adapt_h = h; }
       }
       if (best < 1e300) w.adapt_matrix = &A;
-      if (getenv("PG_DEBUG")) fprintf(stderr, "[pg_krylov] degree %d used %g products, needed %.1f -> next: %d applications of degree %d\n", m, P, need, w.adapt_h, w.adapt_m);
+      if (cfg.debug) fprintf(stderr, "[pg_krylov] degree %d used %g products, needed %.1f -> next: %d applications of degree %d\n", m, P, need, w.adapt_h, w.adapt_m);
     }
   }
 }

@@ -393,7 +393,7 @@ void assemble_csr_preconditioned(const SysParams& P, const Slab& s, const Number
     unsigned long long h = 0;
     nref.download(&h, 1);
     A.halo_needed = h != 0;
-    if (getenv("PG_DEBUG"))
+    if (config().debug)
       fprintf(stderr, "[pg_precond] rank %d: %llu ghost-column references over all ranks => halo %s\n", ctx().rank, h,
               A.halo_needed ? "exchanged" : "skipped");
   }
@@ -494,7 +494,7 @@ void decide_poly(CsrMatrix& A) {
   worst.download(&h, 1);
   A.gersh = h;
   A.poly_ok = h < 0.95;
-  if (getenv("PG_DEBUG") && !(h < 1e300) && A.n > 0) {   // developer aid: the first rows whose disc is not finite
+  if (config().debug && !(h < 1e300) && A.n > 0) {   // developer aid: the first rows whose disc is not finite
     std::vector<int> rp(A.n + 1), cl(A.nnz);
     std::vector<double> vl(A.nnz), dsv(A.ds.n);
     A.rowptr.download(rp.data(), A.n + 1); A.col.download(cl.data(), A.nnz); A.val.download(vl.data(), A.nnz);
@@ -510,7 +510,7 @@ void decide_poly(CsrMatrix& A) {
       fprintf(stderr, "\n");
     }
   }
-  if (getenv("PG_DEBUG"))
+  if (config().debug)
     fprintf(stderr, "[pg_precond] rank %d: largest Gershgorin radius %.4f => Neumann preconditioner %s\n", ctx().rank, h,
             A.poly_ok ? "admissible" : "not used");
 }

@@ -26,20 +26,28 @@ struct DiagElim {
   long long snapped_version = -1;   // pg_solver's bconst version at the last step that ran this path (-1: none / z moved since)
   bool tried = false, active = false;
   CsrMatrix A;              // the remaining rows and columns, compact numbering, own slices / marching units
+  // compact numbering: the full one restricted to the remaining unknowns -- [owned kinds | lower ghosts | upper ghosts], the
+  // send chunks still contiguous; the halo exchange of the loop's vectors runs on it unchanged (pg_comm.hip)
   Numbering nb;
+  bool halo = false;        // the slabs exchange a halo: ghost entries are part of the compact vectors
   i64 n = 0, n_c = 0, n_e = 0;
-  DevBuf<int> cmap, rlist, elist;
+  DevBuf<int> cmap;         // n_vec of the full numbering: compact index, or -1 - q for an eliminated unknown (k_maps)
+  DevBuf<int> rlist, elist;
   DevBuf<double> gdiag, delta;
+  DevBuf<double> dx;        // halo only: full-layout vector the owned deltas are exchanged in (ghost deltas at [n, n_vec))
   DevBuf<int> flag;
-  i64 n_wg = 0;             // coupling block: full row wg_rows[q], entries wg_ptr[q] .. , columns = position in elist
+  i64 n_wg = 0;             // coupling block: full row wg_rows[q], entries wg_ptr[q] .. , columns = position in elist (owned) or n_e + ghost number
   DevBuf<int> wg_rows, wg_ptr, wg_col;
   DevBuf<double> wg_val;
 };
-void build_diag_elim(const CsrMatrix& A, const Numbering& nb, DiagElim& E);
+// Collective when several ranks run (every rank calls it at the same point: all-reduced activation test, one halo exchange).
+void build_diag_elim(const CsrMatrix& A, const Numbering& nb, const Slab& slab, DiagElim& E);
 // r_full: the start residuals of the rows that are left out (k_rhs_init_c; entries of the other rows are not read), r / r̂ / p:
 // the compact start residual.  x_E += r_E / d; the change goes through the coupling block into r, r̂, p; the start sums (slots
 // 0 and 2 of partials) are recomputed when the change is more than rounding noise.
-void diag_fix(const DiagElim& E, int stamp, double* rhat, double* partials, int grid, hipStream_t st);
+// force: redo coupling and start sums unconditionally, with the neighbours' deltas (several ranks, data changed)
+void diag_fix(const DiagElim& E, const Numbering& nb_full, const Slab& slab, int stamp, bool force, double* rhat, double* partials,
+              int grid, hipStream_t st);
 
 // active only for a two-kind (monophasic) system whose γ rows are rows of the identity and whose ω rows reference no ghost
 void build_gamma_elim(const CsrMatrix& A, const Numbering& nb, GammaElim& E);

@@ -434,7 +434,11 @@ __global__ __launch_bounds__(BLOCK) void k_rhs_init_c(i64 n, int scheme, const d
     const double sum = block_sum(a, s_red);
     if (threadIdx.x == 0) sc[pg::S_RED0 + sl] = sum;
   }
-  if (threadIdx.x == 0) pg::derive(pg::PH_INIT, sc);
+  if (threadIdx.x == 0) {
+    pg::derive(pg::PH_INIT, sc);
+    // (every block's atomicMax on the flag was drained before it drew its ticket)
+    sc[pg::S_MOVED] = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == stamp ? 1.0 : 0.0;
+  }
 }
 
 // z refers to S_old: re-express it with S_new (x = S_old z = S_new z')
@@ -813,6 +817,7 @@ void do_initial(pg_solver* s, const pg_krylov_opts* opts, SolveStats& st) {
   s->z_matrix = &s->A_ctor;
   s->x_valid = false;
   s->initial_done = true;
+  s->diag_ctor.snapped_version = s->diag_run.snapped_version = -1;   // z was replaced behind the compact path's back
 }
 
 void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& st) {
@@ -857,25 +862,30 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
     KrylovWork& w = s->work;
     // rows alone on their diagonal (interface AND border identity rows) left out, compact vectors (pg_reduce.hip, DiagElim)
     DiagElim& DE = (&A == &s->A_ctor) ? s->diag_ctor : s->diag_run;
-    if (!DE.tried) build_diag_elim(A, s->nb, DE);
-    bool solved = false;
+    if (!DE.tried) build_diag_elim(A, s->nb, s->slab, DE);
     if (DE.active && krylov_uses_polynomial(DE.A, o)) {
       // r = r̂ = p of the remaining rows go straight to the compact vectors; the other rows are solved in the same pass
       const int stamp = (int)((s->steps_done % 2000000000) + 1);   // marks E.flag when a diagonal row moved in THIS step
       // quiet: the previous step ran this path with the same constant data, so every diagonal row already holds its solution
       // and none can move (beyond rounding) -- the coupling / renorm launches are not queued and the solver's start phase is
       // folded into the right-hand-side kernel (3 launches less)
-      const bool quiet = DE.snapped_version == s->bconst_version && ctx().nranks == 1 && !ctx().comm;
+      // Several ranks: the host-side knowledge "same constant data as the step before" is the same on every rank, so the
+      // coupling / renorm launches (and the exchange of the deltas they need there) are skipped collectively; only the folded
+      // start is a one-rank thing (the scalar phase of several ranks goes through an all-reduce).
+      const bool single = ctx().nranks == 1 && !ctx().comm;
+      const bool same_data = DE.snapped_version == s->bconst_version;
+      const bool quiet = same_data && single;
       hipLaunchKernelGGL(k_rhs_init_c, dim3(w.grid), dim3(BLOCK), 0, stream, n, scheme, s->z.p, s->y.p, A.ds.p, s->mass.p, s->bconst.p,
                          s->fixed.p, A.isblk.p, DE.cmap.p, s->b.p, (const double*)DE.gdiag.p, DE.delta.p, DE.flag.p, stamp, w.rhat.p, w.partials.p,
                          quiet ? w.ticket.p : nullptr, w.sc.p, o.reltol * o.reltol, o.abstol * o.abstol);
       PG_HIP(hipGetLastError());
-      if (!quiet) diag_fix(DE, stamp, w.rhat.p, w.partials.p, w.grid, stream);
+      if (!same_data) diag_fix(DE, s->nb, s->slab, stamp, !single, w.rhat.p, w.partials.p, w.grid, stream);
       w.start_folded = quiet;
       DE.snapped_version = s->bconst_version;
       used_de = &DE;
       w.scatter = DE.rlist.p;
       w.p_in_rhat = true;
+      bool solved = false;
       try {
         krylov_solve(DE.A, DE.nb, s->slab, nullptr, s->z.p, w, o, st, nullptr, nullptr, true);
       } catch (...) {
@@ -883,19 +893,24 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
         throw;
       }
       w.scatter = nullptr;
-      solved = st.poly_degree >= 0;            // -1: the polynomial stagnated on the compact system -> the full path below
-      if (!solved) {        // z's rows were already set to their solution: ŷ and b̂ have to see that
-        DE.active = false;
+      solved = st.poly_degree >= 0;            // -1: the polynomial stagnated on the compact system -> the full system below
+      // A quiet step rests on "no row alone on its diagonal moves while the data are unchanged"; k_rhs_init_c checks it
+      // anyway and the start phase reports it (S_MOVED): the residual the iteration started from then lacked the coupling
+      // term, and the step is finished on the full system from the state reached.
+      const bool moved_unseen = solved && quiet && w.h_sc[S_MOVED] != 0.0;
+      if (!solved || moved_unseen) {
+        // z has moved (the rows left out hold their solution, the x-space iteration has updated the rest): the right-hand
+        // side b̂ of this step -- written for every row by k_rhs_init_c -- stands, the iteration continues on the full
+        // system from the state reached, r = b̂ - Âz
+        if (!solved) DE.active = false;
         used_de = nullptr;
+        const SolveStats first = st;
         st = SolveStats();
         spmv_halo(A, s->nb, s->slab, s->z.p, s->y.p, stream);
-        if (A.n_blk > 0)
-          hipLaunchKernelGGL(k_rhs_block, dim3(grid_for(A.n_blk, BLOCK)), dim3(BLOCK), 0, stream, A.n_blk, scheme, A.blk_rows.p,
-                             A.blk_idx.p, A.blk_coef.p, A.blk_cn.p, s->z.p, A.ds.p, s->y.p, s->mass.p, s->bconst.p, s->fixed.p,
-                             s->b.p);
+        krylov_solve(A, s->nb, s->slab, s->b.p, s->ysol.p, w, o, st, s->z.p, s->y.p, false);
+        std::swap(s->z.p, s->ysol.p);
+        st.iters += first.iters;
       }
-    }
-    if (solved) {
       s->x_valid = false;
       s->steps_done += 1;
       return;
@@ -1300,6 +1315,8 @@ int32_t pg_solver_system_info(const pg_solver* s, int32_t which, pg_system_info*
   out->spmv_units = A.nunits;
   out->rows_marched = A.rows_m;
   out->rows_matrix = A.n;
+  out->n_ghost_loop = ((which & 4) && DE.active) ? DE.nb.n_ghost : s->nb.n_ghost;
+  out->loop_is_compact = DE.active ? 1 : 0;
   PG_API_END
 }
 
@@ -1410,18 +1427,42 @@ int32_t pg_debug_spmv_compare(pg_solver* s, int32_t which, int32_t variant_a, in
   PG_API_END
 }
 
+__global__ void k_scale_rows(i64 n_e, const int* __restrict__ elist, double factor, double* __restrict__ z) {
+  for (i64 q = blockIdx.x * (i64)blockDim.x + threadIdx.x; q < n_e; q += (i64)gridDim.x * blockDim.x) z[elist[q]] *= factor;
+}
+
+int32_t pg_debug_scale_diagonal_rows(pg_solver* s, double factor) {
+  PG_API_BEGIN
+  require_init();
+  PG_REQUIRE(s && s->have_run, "pg_debug_scale_diagonal_rows: no run matrix yet");
+  const CsrMatrix& A = run_matrix(s);
+  DiagElim& DE = (&A == &s->A_ctor) ? s->diag_ctor : s->diag_run;
+  PG_REQUIRE(DE.active && DE.n_e > 0, "pg_debug_scale_diagonal_rows: the loop of this solver is not the compact one");
+  hipLaunchKernelGGL(k_scale_rows, dim3(grid_for(DE.n_e, BLOCK)), dim3(BLOCK), 0, ctx().stream, DE.n_e, (const int*)DE.elist.p, factor,
+                     s->z.p);
+  PG_HIP(hipGetLastError());
+  PG_HIP(hipStreamSynchronize(ctx().stream));
+  s->x_valid = false;
+  PG_API_END
+}
+
 int32_t pg_solver_time_spmv(pg_solver* s, int32_t which, int32_t reps, double* avg_ms) {
   PG_API_BEGIN
   require_init();
   PG_REQUIRE(s && avg_ms && reps > 0, "pg_solver_time_spmv: bad arguments");
-  const int sel = which & 1, mode = (which >> 4) & 7;   // bits 4-6: mode of the launch (0 plain, 1, 2, 3 fused dots, 4: 2x - Ax)
-  PG_REQUIRE(mode <= 4, "pg_solver_time_spmv: unknown launch mode");
+  // bits 4-6: mode of the launch (0 plain, 1, 2, 3 fused dots, 4: 2x - Ax); bit 11: the Horner step of the x-space loop
+  // (mode 8: out = pc2 base + pc0 x + pc1 A x, three vector streams)
+  const int sel = which & 1, mode = (which & 2048) ? 8 : ((which >> 4) & 7);
+  PG_REQUIRE(mode <= 4 || mode == 8, "pg_solver_time_spmv: unknown launch mode");
   if (sel == 1) PG_REQUIRE(s->have_run, "run matrix not assembled yet");
   const CsrMatrix& Afull = sel == 0 ? s->A_ctor : run_matrix(s);
   // bit 9: the matrix the warm loop iterates on (without the Dirichlet interface rows, pg_reduce.hip), built here if need be
   GammaElim& E = (&Afull == &s->A_ctor) ? s->elim_ctor : s->elim_run;
   if ((which & 512) && !E.tried) build_gamma_elim(Afull, s->nb, E);
-  const CsrMatrix& A = ((which & 512) && E.active) ? E.A : Afull;
+  // bit 12: the compact loop matrix (every row alone on its diagonal left out, DiagElim): what the benchmark's loop streams
+  DiagElim& DE = (&Afull == &s->A_ctor) ? s->diag_ctor : s->diag_run;
+  if ((which & 4096) && !DE.tried) build_diag_elim(Afull, s->nb, s->slab, DE);
+  const CsrMatrix& A = ((which & 4096) && DE.active) ? DE.A : (((which & 512) && E.active) ? E.A : Afull);
   // bit 10: chained launches, each reading what the one before wrote (two vectors in turn): the access pattern of a chain
   // of lean launches in the loop
   const bool chained = (which & 1024) != 0;
@@ -1449,6 +1490,11 @@ int32_t pg_solver_time_spmv(pg_solver* s, int32_t which, int32_t reps, double* a
     const double* ax = cold ? ring[(it + 5) % RING].p : w.rhat.p;
     ++it;
     if (mode == 0) spmv(A, xin, yout, st);
+    else if (mode == 8) {
+      FinArgs f{nullptr, nullptr, PH_NONE, 0, 0, nullptr};
+      f.pc0 = 1.0; f.pc1 = -0.5; f.pc2 = 0.5; f.base = s->b.p;   // (the chain's input: one fixed vector, re-read by every launch)
+      launch_spmv(8, A, xin, yout, nullptr, nullptr, nullptr, w.grid, st, &f);
+    }
     else launch_spmv(mode, A, xin, yout, ax, w.partials.p, nullptr, w.grid, st);
   };
   for (int i = 0; i < 3; ++i) one();

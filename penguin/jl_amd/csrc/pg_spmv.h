@@ -7,6 +7,7 @@ namespace pg {
 // device scalar block of one Krylov solve (KrylovWork::sc)
 enum { S_RHO = 0, S_RHO_OLD, S_ALPHA, S_OMEGA, S_BETA, S_RR, S_BB, S_TOL2, S_DONE, S_ITERS, S_RELTOL2, S_ABSTOL2,
        S_RESTART, S_RHAT2, S_FORCE, S_PENDING3, S_RRW, S_HALF, S_RR0 /* initial (r,r)_W: diagnostics */,
+       S_MOVED /* folded start of a compact step: a row alone on its diagonal moved although the data did not (pg_solver.hip) */,
        S_RED0, S_RED1, S_RED2, S_RED3, S_RED4, S_COUNT };
 
 constexpr int BLOCK = 256;

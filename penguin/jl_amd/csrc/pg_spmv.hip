@@ -133,7 +133,7 @@ struct StreamW {
 };
 
 template <bool NT>
-__device__ inline void stream_issue_w(StreamW& q, const Desc& d, const int* __restrict__ rowptr,
+__device__ __forceinline__ void stream_issue_w(StreamW& q, const Desc& d, const int* __restrict__ rowptr,
                                       const int* __restrict__ col, const double* __restrict__ val, int lane) {
   const int r = d.r0 + lane;
   q.ra = stream_load<NT>(rowptr + (r < d.r1 ? r : d.r1));
@@ -316,7 +316,7 @@ __device__ __forceinline__ double mode_out(double s, double own, double a, doubl
 // rows of one U (PSL = false) or P (PSL = true) slice with CNT stencil slots; rec = the slice's record (lane & 31).
 // NB batches of 128 rows: every load of the slice is issued before the first FMA (one exposed latency per slice).
 template <int CNT, int NB, bool PSL, int MODE, bool NT>
-__device__ inline void slice_rows(const SDesc& d, int nrows, int rec, const double* __restrict__ pval,
+__device__ __forceinline__ void slice_rows(const SDesc& d, int nrows, int rec, const double* __restrict__ pval,
                                   const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ pa,
                                   const double* __restrict__ pb, int lane, double& acc0, double& acc1, double& acc2, int dbg,
                                   double pc0, double pc1, double pc2) {
@@ -404,7 +404,7 @@ __device__ inline void slice_rows(const SDesc& d, int nrows, int rec, const doub
 }
 
 template <int CNT, bool PSL, int MODE, bool NT>
-__device__ inline void slice_nb(const SDesc& d, int nrows, int rec, const double* __restrict__ pval,
+__device__ __forceinline__ void slice_nb(const SDesc& d, int nrows, int rec, const double* __restrict__ pval,
                                 const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ pa,
                                 const double* __restrict__ pb, int lane, double& acc0, double& acc1, double& acc2, int dbg,
                                 double pc0, double pc1, double pc2) {
@@ -413,7 +413,7 @@ __device__ inline void slice_nb(const SDesc& d, int nrows, int rec, const double
 }
 
 template <bool PSL, int MODE, bool NT>
-__device__ inline void slice_dispatch(int cnt, const SDesc& d, int nrows, int rec, const double* __restrict__ pval,
+__device__ __forceinline__ void slice_dispatch(int cnt, const SDesc& d, int nrows, int rec, const double* __restrict__ pval,
                                       const double* __restrict__ x, double* __restrict__ y,
                                       const double* __restrict__ pa, const double* __restrict__ pb, int lane, double& acc0,
                                       double& acc1, double& acc2, int dbg, double pc0, double pc1, double pc2) {
@@ -610,7 +610,10 @@ __device__ __forceinline__ void march_dispatch(int rec, int lane, const double* 
   }
 }
 
-template <int MODE, bool NT>
+// DIAG: the diagnostic build of the kernel (ablations for profiles/: PG_SPMV_XCD bits 8.. skip parts of the work or force
+// access patterns and give WRONG products).  The shipped instantiation has DIAG = false: `dbg` is the constant 0 there and
+// none of the switches exists in its code.
+template <int MODE, bool NT, bool DIAG>
 __global__ __launch_bounds__(BLOCK, 4) void k_spmv_s(i64 nslices, const int* __restrict__ srec,
                                                   const double* __restrict__ pval, const int* __restrict__ g_rowid,
                                                   const int* __restrict__ g_rowptr, const int* __restrict__ g_col,
@@ -641,7 +644,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_spmv_s(i64 nslices, const int* __r
   // 64 no lateral lines in the units, 128 every access of the units 16-byte aligned, 256 non-temporal y stores in the
   // units, 512 the units store whole windows, 2048 plain y stores in the units, 4096 slices before units (the latency-bound
   // irregular chunks then run alone at the start instead of under the streaming units of slower waves: 52 vs 45.6 us)
-  const int dbg = xcd >> 8;
+  const int dbg = DIAG ? (xcd >> 8) : 0;
   xcd &= 255;
   // ---- marching units first (the bulk of the rows), then the slices.  (Alternating units and slices in every wave, so
   // that the latency-bound irregular chunks of some waves overlap the streaming of others, measured no faster, and one
@@ -870,13 +873,11 @@ __global__ void k_fill_records(i64 nslices, int* __restrict__ srec, const int* _
 
 int variant() {
   // default 70 = stencil slices + non-temporal streams; 38 = the chunked CSR kernel + non-temporal streams; 1 = first kernel
-  static const int v = getenv("PG_SPMV_VARIANT") ? atoi(getenv("PG_SPMV_VARIANT")) : 70;
-  return v;
+  return config().spmv_variant;
 }
 
 int xcd_map() {
-  static const int v = getenv("PG_SPMV_XCD") ? atoi(getenv("PG_SPMV_XCD")) : 1;
-  return v;
+  return config().spmv_xcd;
 }
 
 }  // namespace
@@ -898,12 +899,16 @@ bool launch_slices(int v, const CsrMatrix& A, i64 s0, i64 ns, const double* x, d
   const bool tiled = units && A.tiles_per_xcd > 0 && s0 == 0 && ns == A.tile_ns && (xcd_map() & 1) && grid >= 8;
   const int* tiles = tiled ? (const int*)A.tiles.p : nullptr;
   const int tpx = tiled ? A.tiles_per_xcd : 0;
-  if (v & 4)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_s<MODE, true>), dim3(grid), dim3(BLOCK), 0, st, ns, rec, A.pval.p,
+  if (xcd_map() >= 256)   // diagnostic switches set: the diagnostic build (wrong products; ablation runs only)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_s<MODE, true, true>), dim3(grid), dim3(BLOCK), 0, st, ns, rec, A.pval.p,
+                       A.g_rowid.p, A.g_rowptr.p, A.g_col.p, A.g_val.p, x, y, aux, partials, sc, xcd_map(), fa, pstride, accum,
+                       (const int*)A.mrec.p, nu, tiles, tpx);
+  else if (v & 4)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_s<MODE, true, false>), dim3(grid), dim3(BLOCK), 0, st, ns, rec, A.pval.p,
                        A.g_rowid.p, A.g_rowptr.p, A.g_col.p, A.g_val.p, x, y, aux, partials, sc, xcd_map(), fa, pstride, accum,
                        (const int*)A.mrec.p, nu, tiles, tpx);
   else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_s<MODE, false>), dim3(grid), dim3(BLOCK), 0, st, ns, rec, A.pval.p,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spmv_s<MODE, false, false>), dim3(grid), dim3(BLOCK), 0, st, ns, rec, A.pval.p,
                        A.g_rowid.p, A.g_rowptr.p, A.g_col.p, A.g_val.p, x, y, aux, partials, sc, xcd_map(), fa, pstride, accum,
                        (const int*)A.mrec.p, nu, tiles, tpx);
   return fa.ticket != nullptr;
@@ -1008,8 +1013,7 @@ __global__ void k_row_cells(i64 nrows, const int* __restrict__ rows, const int* 
 }
 
 int march_strip() {
-  static const int strip = getenv("PG_SPMV_STRIP") ? atoi(getenv("PG_SPMV_STRIP")) : 16;
-  return strip;
+  return config().spmv_strip;
 }
 bool has_geo(const CsrMatrix& A) { return A.geo_cell && A.geo_ext0 > 0 && A.geo_lines > 0 && march_strip() > 0; }
 
@@ -1055,8 +1059,9 @@ void build_march_units(CsrMatrix& A, const std::vector<MRun>& runs, std::vector<
     PG_HIP(hipGetLastError());
     d_info.download(info.data(), RUN_INFO * nr);
   }
-  static const int kmax = getenv("PG_SPMV_MARCH_K") ? std::max(1, std::min(MARCH_K, atoi(getenv("PG_SPMV_MARCH_K")))) : MARCH_K;
-  pghost::MarchGeometry geo{MARCH_K, MARCH_KS, MARCH_REC, MARCH_W, RUN_INFO, kmax, A.geo_ext0, A.geo_lines, march_strip()};
+  const int kmax = config().spmv_march_k > 0 ? std::max(1, std::min(MARCH_K, config().spmv_march_k)) : MARCH_K;
+  pghost::MarchGeometry geo{MARCH_K, MARCH_KS, MARCH_REC, MARCH_W, RUN_INFO, kmax, A.geo_ext0, A.geo_lines, march_strip(),
+                            has_geo(A) ? config().unit_order : 0};
   std::vector<pghost::RowRange> fallback;
   i64 rows_m = 0;
   pghost::plan_march_units(A.n, runs, info, geo, mrec, fallback, rows_m, &ukeys);
@@ -1069,7 +1074,7 @@ void build_slices(CsrMatrix& A, const int* rp) {
   hipStream_t st = ctx().stream;
   Laps laps;
   const i64 n = A.n;
-  static const int minrun = getenv("PG_SPMV_MINRUN") ? atoi(getenv("PG_SPMV_MINRUN")) : 24;
+  const int minrun = config().spmv_minrun;
   unsigned char* fl = static_cast<unsigned char*>(pinned_scratch(1, (size_t)n));
   A.rowflags.alloc(n);
   hipLaunchKernelGGL(k_row_same, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, st, n, A.rowptr.p, A.col.p, A.val.p,
@@ -1085,7 +1090,7 @@ void build_slices(CsrMatrix& A, const int* rp) {
     std::vector<MRun> runs;     // U runs of 2-D / 3-D stencil rows: candidates for marching units
     i64 rows_u = 0, rows_p = 0, nnz_p = 0;
   };
-  static const bool march_env = getenv("PG_SPMV_MARCH") ? atoi(getenv("PG_SPMV_MARCH")) != 0 : true;
+  const bool march_env = config().spmv_march;
   const bool march_on = march_env && A.want_units;
   auto classify = [&](i64 lo, i64 hi, Part& out) {
     auto emit = [&](int type, i64 a, i64 b, int cnt) {
@@ -1272,7 +1277,7 @@ void build_slices(CsrMatrix& A, const int* rp) {
   // 512^3, tiles of 512 units take 5 MB off the 159 MB a lean launch reads but cost 6 us of its 45 -- a wave then has one
   // unit and about one slice per tile and nothing to prefetch the next record behind
   {
-    static const int tile_units = getenv("PG_SPMV_TILE_UNITS") ? atoi(getenv("PG_SPMV_TILE_UNITS")) : 0;
+    const int tile_units = config().spmv_tile_units;
     const i64 T = tile_units > 0 ? std::min<i64>(256, (A.nunits / 8 + tile_units / 2) / tile_units) : 0;
     A.tiles_per_xcd = 0;
     A.tile_ns = 0;
@@ -1308,7 +1313,7 @@ void build_slices(CsrMatrix& A, const int* rp) {
   PG_HIP(hipStreamSynchronize(st));
   laps.lap("    slices: packing + records");
   A.spmv_bytes = 4 * SL_REC * A.nslices + 4 * MARCH_REC * A.nunits + 8 * A.nnz_p + 12 * A.nnz_g + 8 * ng + 16 * n;
-  if (getenv("PG_DEBUG"))
+  if (config().debug)
     fprintf(stderr, "[pg_spmv] slices %lld (%lld wait for the halo), marching units %lld (%lld rows): rows U %lld P %lld G %lld of %lld; nnz P %lld G %lld of %lld; bytes/launch %lld (CSR %lld)\n",
             (long long)A.nslices, (long long)(A.nslices - A.nslices_int), (long long)A.nunits, (long long)A.rows_m, (long long)A.rows_u, (long long)A.rows_p, (long long)A.rows_g,
             (long long)n, (long long)A.nnz_p, (long long)A.nnz_g, (long long)A.nnz, (long long)A.spmv_bytes,
@@ -1434,7 +1439,7 @@ bool spmv_supports_preconditioner_product() { return (variant() & 64) != 0; }
 
 int spmv_default_grid(i64 n) {
   // resident blocks per CU: the slice kernel holds ~100 VGPRs (4 waves / SIMD), the CSR kernels 24.6 KB of LDS (6 blocks)
-  static const int per_cu = getenv("PG_SPMV_BLOCKS_PER_CU") ? atoi(getenv("PG_SPMV_BLOCKS_PER_CU")) : ((variant() & 64) ? 4 : 6);
+  const int per_cu = config().spmv_blocks_per_cu > 0 ? config().spmv_blocks_per_cu : ((variant() & 64) ? 4 : 6);
   static int cus = 0;
   if (cus == 0) {
     hipDeviceProp_t prop;
@@ -1468,7 +1473,7 @@ bool spmv_with_halo(int mode, const CsrMatrix& A, const Numbering& nb, const Sla
     return launch_spmv(mode, A, x, y, aux, partials, sc, grid, st, fin);
   }
   const int v = variant();
-  static const bool overlap = getenv("PG_HALO_OVERLAP") ? atoi(getenv("PG_HALO_OVERLAP")) != 0 : true;
+  const bool overlap = config().halo_overlap;
   const i64 ni = A.nslices_int, nbnd = A.nslices - A.nslices_int;
   if (!(v & 64) || !overlap || (ni == 0 && A.nunits == 0) || nbnd == 0) {
     halo_exchange(nb, slab, x, st);

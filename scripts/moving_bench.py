@@ -85,4 +85,8 @@ out = {"what": "prescribed-motion diffusion, 2-D growing disc (fluid outside), o
        "krylov_iters_per_slab": float(np.mean(its)),
        "per_slab_ms": {k: (v if k.endswith("_ms") else v * 1e3) / slabs for k, v in T.items()},
        "capacity_cells_per_s": M * slabs / (T["capacity_kernels_ms"] * 1e-3), "time_nodes": 64, "device": pj.device_name()}
+if x is not None:      # (a checksum of the last state: runs with different allocator settings must agree on it)
+    out["state_l2"] = float(np.linalg.norm(x))
+    out["state_max"] = float(np.max(np.abs(x)))
+    out["state_finite"] = bool(np.all(np.isfinite(x)))
 print(json.dumps(out))

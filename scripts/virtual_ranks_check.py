@@ -36,6 +36,16 @@ def run(nranks, n, Lz_factor, centers, steps, scheme_run, nn=None, LL=None, radi
     return x, n_own, nnz, ngh, its
 
 
+def loop_info(nranks):
+    """per rank of the last run: (rows of the full system, rows / ghost entries of the system the warm loop iterated on)"""
+    res = []
+    for r in range(nranks):
+        full, rows, nbytes, gh = (C.c_int64() for _ in range(4))
+        L.check(lib.pg_debug_virtual_rank_info(r, C.byref(full), C.byref(rows), C.byref(nbytes), C.byref(gh)))
+        res.append((full.value, rows.value, gh.value))
+    return res
+
+
 out = {}
 for case, (n, zf, centers) in {"sphere": (24, 1, [(2.01, 2.01, 2.01)]),
                                "two_spheres": (16, 2, [(2.01, 2.01, 2.01), (2.01, 2.01, 6.01)])}.items():
@@ -44,7 +54,20 @@ for case, (n, zf, centers) in {"sphere": (24, 1, [(2.01, 2.01, 2.01)]),
         x, n_own, nnz, ngh, its = run(nr, n, zf, centers, 3, 1)
         err = float(np.linalg.norm(x - ref) / np.linalg.norm(ref))
         out[f"{case}_{nr}"] = {"rel_l2": err, "n_own": n_own.tolist(), "n_total_1": int(n1[0]), "nnz": nnz.tolist(),
-                               "nnz_total_1": int(nnz1[0]), "n_ghost": ngh.tolist(), "iters": its.tolist(), "iters_1": int(it1[0])}
+                               "nnz_total_1": int(nnz1[0]), "n_ghost": ngh.tolist(), "iters": its.tolist(), "iters_1": int(it1[0]),
+                               "loop": loop_info(nr)}
+# data that change every step (interface value ramp): the rows alone on their diagonal move in every step on every rank, and
+# their change reaches the rows coupled to them through the compact loop's coupling block -- across slab faces by one
+# exchange of the deltas
+L.check(lib.pg_debug_set_virtual_rank_ramp(C.c_double(0.25)))
+ref, n1, nnz1, _, it1 = run(1, 24, 1, [(2.01, 2.01, 2.01)], 4, 1)
+for nr in (2, 3):
+    x, n_own, nnz, ngh, its = run(nr, 24, 1, [(2.01, 2.01, 2.01)], 4, 1)
+    out[f"ramp_sphere_{nr}"] = {"rel_l2": float(np.linalg.norm(x - ref) / np.linalg.norm(ref)), "n_own": n_own.tolist(),
+                                "n_total_1": int(n1[0]), "nnz": nnz.tolist(), "nnz_total_1": int(nnz1[0]),
+                                "n_ghost": ngh.tolist(), "iters": its.tolist(), "iters_1": int(it1[0]), "loop": loop_info(nr),
+                                "ref_max": float(np.max(np.abs(ref)))}
+L.check(lib.pg_debug_set_virtual_rank_ramp(C.c_double(0.0)))
 # random slab problems: anisotropic 2-D / 3-D grids, a ball anywhere in the box (cut by slab faces, touching borders),
 # 2-4 ranks, BE / CN -- against the same problem on one rank
 rng = np.random.default_rng(77)

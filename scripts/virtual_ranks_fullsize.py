@@ -46,6 +46,15 @@ def run(nr, zf):
                                            1, C.c_int64(steps), L.dptr(x) if with_state else None, L.iptr(n_own), L.iptr(nnz),
                                            L.iptr(ngh), L.iptr(its)))
     out = dict(n_own=n_own.tolist(), nnz=nnz.tolist(), n_ghost=ngh.tolist(), iters=its.tolist(), wall_s=time.time() - t0)
+    # what the warm loop of every rank iterated on: the compact system (rows alone on their diagonal solved in the
+    # right-hand-side pass, pg_reduce.hip) when loop_rows < n_own
+    loop_rows, loop_bytes, loop_ghosts = [], [], []
+    for r in range(nr):
+        full, rows, nbytes, gh = (C.c_int64() for _ in range(4))
+        L.check(lib.pg_debug_virtual_rank_info(r, C.byref(full), C.byref(rows), C.byref(nbytes), C.byref(gh)))
+        loop_rows.append(rows.value); loop_bytes.append(nbytes.value); loop_ghosts.append(gh.value)
+    out.update(loop_rows=loop_rows, loop_bytes_per_launch=loop_bytes, loop_ghosts=loop_ghosts,
+               rows_alone_on_their_diagonal=[int(a - b) for a, b in zip(n_own.tolist(), loop_rows)])
     if with_state:
         states[nr] = x
     return out

@@ -99,5 +99,12 @@ def test_config4_strong_8_slabs_reproduce_the_one_rank_state():
     assert out["slabs_sum_to_one_rank"], out
     assert sum(out["virtual"]["n_own"]) == N512_ROWS
     assert all(g > 0 for g in out["virtual"]["n_ghost"])
+    # the halo-exchanging slabs run the loop the 1-GPU benchmark runs: the compact system on every rank (pg_reduce.hip)
+    v = out["virtual"]
+    assert all(e > 0 for e in v["rows_alone_on_their_diagonal"]), v
+    assert sum(v["rows_alone_on_their_diagonal"]) == out["one_rank"]["rows_alone_on_their_diagonal"][0], (v, out["one_rank"])
+    assert sum(v["loop_rows"]) == out["one_rank"]["loop_rows"][0]
+    assert all(0 < g for g in v["loop_ghosts"]), v
+    assert out["virtual"]["iters"][0] == out["one_rank"]["iters"][0], out       # identical iteration counts
     assert out["state_max"] > 0.5                                               # a real field, not zeros
     assert out["state_rel_l2"] <= 1e-10, out

@@ -17,7 +17,8 @@ def test_virtual_ranks_reproduce_single_rank():
                        text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
-    assert set(out) >= {"sphere_2", "sphere_3", "sphere_4", "two_spheres_2", "two_spheres_4", "gmres_sphere_2"}
+    assert set(out) >= {"sphere_2", "sphere_3", "sphere_4", "two_spheres_2", "two_spheres_4", "gmres_sphere_2", "ramp_sphere_2",
+                        "ramp_sphere_3"}
     assert sum(1 for k in out if k.startswith("random")) == 8
     for case, v in out.items():
         assert v["rel_l2"] <= 1e-12, (case, v)                       # same solution as one rank
@@ -30,6 +31,16 @@ def test_virtual_ranks_reproduce_single_rank():
             continue
         assert v["iters"][0] == v["iters_1"], (case, v)              # identical Krylov history
         assert all(g > 0 for g in v["n_ghost"]), (case, v)           # every rank exchanges a halo
+        if "loop" in v:
+            # the halo-exchanging slabs iterate on the COMPACT system, as one rank does: rows alone on their diagonal are
+            # solved in the right-hand-side pass on every rank, the loop's vectors keep the remaining ghosts only
+            for (full, rows, ghosts), ng in zip(v["loop"], v["n_ghost"]):
+                assert 0 < rows < full, (case, v["loop"])
+                assert 0 <= ghosts <= ng, (case, v["loop"], v["n_ghost"])
+                if case.startswith(("sphere", "ramp")):
+                    assert ghosts > 0, (case, v["loop"])             # one body across all slabs: every face exchanges
+    for case in ("ramp_sphere_2", "ramp_sphere_3"):
+        assert out[case]["ref_max"] > 1.2                            # the ramp reached the field
     # one sphere per slab (the weak-scaling body): the partition by active rows is balanced
     v = out["two_spheres_2"]
     assert max(v["n_own"]) <= 1.15 * min(v["n_own"])
