@@ -493,13 +493,18 @@ def cg_ref(A: sp.csr_matrix, b: np.ndarray, reltol: float = 1e-12, abstol: float
 
 
 def gmres_ref(A: sp.csr_matrix, b: np.ndarray, reltol: float = 1e-12, abstol: float = 0.0, restart: int = 20,
-              maxiter: int = 10000):
+              maxiter: int = 10000, weights: Optional[np.ndarray] = None):
     """Restarted GMRES as IterativeSolvers 0.9.4 `gmres` runs it (the default `method` of solve_system!,
     src/solver.jl:158): zero initial guess, Arnoldi with modified Gram-Schmidt, Givens rotations, convergence on the
     rotated residual estimate |g_{j+1}| <= max(reltol*||r0||, abstol), true residual recomputed at every restart.
     IterativeSolvers is not vendored: this follows the published algorithm (Saad & Schultz 1986); the solution is
     checked against scipy's gmres and the direct solve in tests/test_oracle_pins.py.  pg_gmres.hip orthogonalises with
-    classical Gram-Schmidt applied twice instead (one fused multi-dot per pass); counts agree to +-1."""
+    classical Gram-Schmidt applied twice instead (one fused multi-dot per pass); counts agree to +-1.
+
+    weights (the HIP path's acceptance rule, pg_gmres.hip): the Givens estimate only ends a cycle; the solve is accepted at a
+    restart on the true residual in the weighted norm, ||w r|| <= max(reltol ||w b||, abstol), and a cycle that met the
+    estimate but not the weighted test is followed by one with the inner tolerance lowered by the factor still missing
+    (x 1/4).  The third return value is then the weighted residual norm."""
     n = A.shape[0]
     m = max(1, min(restart, n))
     x = np.zeros(n)
@@ -508,6 +513,50 @@ def gmres_ref(A: sp.csr_matrix, b: np.ndarray, reltol: float = 1e-12, abstol: fl
     tol = max(reltol * beta, abstol)
     it = 0
     res = beta
+    if weights is not None:
+        tolw = max(reltol * np.linalg.norm(weights * b), abstol)
+        resw = np.linalg.norm(weights * r)
+        while it < maxiter and resw > tolw and beta > 0.0:
+            V = np.zeros((m + 1, n))
+            H = np.zeros((m + 1, m))
+            cs, sn, g = np.zeros(m), np.zeros(m), np.zeros(m + 1)
+            V[0] = r / beta
+            g[0] = beta
+            J = 0
+            for j in range(m):
+                if it >= maxiter:
+                    break
+                w = A @ V[j]
+                for i in range(j + 1):
+                    H[i, j] = V[i] @ w
+                    w = w - H[i, j] * V[i]
+                hn = np.linalg.norm(w)
+                H[j + 1, j] = hn
+                for i in range(j):
+                    a, c = H[i, j], H[i + 1, j]
+                    H[i, j], H[i + 1, j] = cs[i] * a + sn[i] * c, -sn[i] * a + cs[i] * c
+                d = math.hypot(H[j, j], hn)
+                it += 1
+                if d == 0.0:
+                    break
+                cs[j], sn[j] = H[j, j] / d, hn / d
+                H[j, j], H[j + 1, j] = d, 0.0
+                g[j + 1] = -sn[j] * g[j]
+                g[j] = cs[j] * g[j]
+                J = j + 1
+                if abs(g[j + 1]) <= tol or hn == 0.0:
+                    break
+                V[j + 1] = w / hn
+            if J == 0:
+                break
+            y = np.linalg.solve(np.triu(H[:J, :J]), g[:J])
+            x = x + V[:J].T @ y
+            r = b - A @ x
+            beta = np.linalg.norm(r)
+            resw = np.linalg.norm(weights * r)
+            if resw > tolw and resw > 0.0:
+                tol = min(tol, 0.5 * beta * (tolw / resw))     # (0.25 on the squares, as the device code has it)
+        return x, it, resw
     while it < maxiter:
         if res <= tol or beta == 0.0:
             break

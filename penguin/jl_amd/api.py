@@ -578,6 +578,13 @@ class Solver:
         A = sp.csr_matrix((val[:nnz], col[:nnz], rowptr), shape=(n, n + info.n_ghost))
         return A, b[:n], idx[:n]
 
+    def row_scaling(self, which: int = 0) -> np.ndarray:
+        """S = diag(|a_ii|^-1/2) of system `which` (0 constructor, 1 run): the weights of the convergence test
+        ||S r|| <= reltol ||S b|| every Krylov method of the library is accepted on."""
+        ds = np.empty(max(self.system_info(which).n_own, 1))
+        L.check(L.lib().pg_solver_get_row_scaling(self._h, C.c_int32(which), L.dptr(ds)))
+        return ds[: self.system_info(which).n_own]
+
     def system_info(self, which: int = 0) -> L.pg_system_info:
         info = L.pg_system_info()
         L.check(L.lib().pg_solver_system_info(self._h, C.c_int32(which), C.byref(info)))

@@ -66,11 +66,9 @@ void set_last_error(const std::string& msg);
 struct Config {
   bool debug = false;             // PG_DEBUG: set-up laps and solver diagnostics on stderr
   int alloc_poison = 0;           // PG_ALLOC_POISON=1: every device allocation is filled with a NaN pattern (uninitialised reads show)
-  int async_alloc = 0;            // PG_ASYNC_ALLOC: 1 every allocation from the stream-ordered pool, -1 none
+  int async_alloc = 0;            // PG_ASYNC_ALLOC: 1 every allocation through the library's block cache, -1 none, 0 inside AsyncAllocScopes
   int alloc_guard = 0;            // PG_ALLOC_GUARD=1: guard bands around every device block, checked at free (out-of-bounds writes)
-  int alloc_sync = 0;             // PG_ALLOC_SYNC (experiments): 1 hipDeviceSynchronize before hipFree, 2 stream sync before every
-                                  // hipMalloc, 4 NO stream sync before a hipMalloc that follows pool use (reproduces round 2's corruption)
-  long long pool_limit_mb = 1024; // PG_POOL_LIMIT_MB: requests of this size and more bypass the pool (0: no limit)
+  long long pool_limit_mb = 0;    // PG_POOL_LIMIT_MB: requests of this size and more bypass the block cache (0: no limit)
   // Krylov driver (pg_krylov.hip)
   bool poly = true;               // PG_POLY: polynomial right preconditioner where admissible
   int poly_degree = 6;            // PG_POLY_DEGREE: degree of the first solve on a matrix / of every solve when adaptation is off
@@ -129,14 +127,13 @@ void comm_allreduce_max_f64(double* dev, int count, hipStream_t st);
 void comm_allreduce_sum_u64(unsigned long long* dev, i64 count, hipStream_t st);
 
 // ---- device buffer -------------------------------------------------------------------------
-// Allocation: hipMalloc / hipFree, or the stream-ordered allocator on the compute stream (a pool that is never trimmed).
-// hipMalloc / hipFree synchronise the device, and a caller that rebuilds capacities and systems every time step -- the
-// moving-body solver: ~60 buffers per slab -- pays that ~120 times per step (17 -> 5 ms per slab at 1024²).  The pool serves
-// the allocations (below 1 GiB) made inside an AsyncAllocScope (the moving path's entry points), or everywhere with
-// PG_ASYNC_ALLOC=1 (opt-in); a plain hipMalloc that follows pool use drains the compute stream first (pg_context.hip,
-// pool_limit: the two allocators do not mix otherwise); pointers remember where they came from.
+// Allocation: hipMalloc / hipFree, or -- inside an AsyncAllocScope (the moving path's entry points; everywhere with
+// PG_ASYNC_ALLOC=1) -- the library's own cache of freed blocks, which hands memory out again without synchronising the
+// device: everything of the path is queued on one stream (pg_context.hip "device memory" has the reasoning, and why the
+// runtime's hipMallocAsync pool is not used).  17 -> 5 ms per slab of the moving solver at 1024².
 void* dev_alloc(size_t bytes);   // pg_context.hip
 void dev_free(void* p);
+void dev_cache_release();        // idle cached blocks back to the runtime (one device synchronisation)
 struct AsyncAllocScope {
   AsyncAllocScope();
   ~AsyncAllocScope();

@@ -35,9 +35,8 @@ const Config& config() {
     k.debug = getenv("PG_DEBUG") != nullptr;
     k.alloc_poison = (int)geti("PG_ALLOC_POISON", 0);
     k.async_alloc = (int)geti("PG_ASYNC_ALLOC", 0);
-    k.alloc_sync = (int)geti("PG_ALLOC_SYNC", 0);
     k.alloc_guard = (int)geti("PG_ALLOC_GUARD", 0);
-    k.pool_limit_mb = geti("PG_POOL_LIMIT_MB", 1024);
+    k.pool_limit_mb = geti("PG_POOL_LIMIT_MB", 0);
     k.poly = geti("PG_POLY", 1) != 0;
     k.poly_degree = (int)geti("PG_POLY_DEGREE", 6);
     k.poly_adapt = geti("PG_POLY_ADAPT", getenv("PG_POLY_DEGREE") ? 0 : 1) != 0;
@@ -96,55 +95,117 @@ using namespace pg;
 
 namespace pg {
 namespace {
+// ---- device memory ---------------------------------------------------------------------------------------------------
+// hipMalloc / hipFree synchronise the device, and a caller that rebuilds capacities and systems every time step (the
+// moving-body solver: ~60 buffers per slab) pays that ~120 times per slab.  Inside an AsyncAllocScope the library therefore
+// keeps the blocks it frees in a CACHE of its own and hands them out again without any synchronisation.  That is safe for
+// the same reason a stream-ordered allocator is: every kernel, memset and copy of the path is queued on ONE stream (the
+// context's compute stream), so whatever the next owner queues runs after everything the previous owner queued.
+//
+// Why not the runtime's stream-ordered allocator (hipMallocAsync / hipFreeAsync), which round 2 used: on this runtime
+// (ROCm 7.2, gfx950) live blocks of that pool lose their contents -- whole ranges read back as ZERO -- as soon as plain
+// hipMalloc / hipFree calls are interleaved with it, whatever synchronisation is put around them, and a pool used alone
+// occasionally hands one range to two owners in the first process after a box comes up.  scripts/repro/hip_pool_stress.hip
+// shows both on the bare runtime (no library code; results in profiles/r03_allocator_findings.txt).  That, not the size of
+// the pooled blocks, is what corrupted the 3072² / 4096² slabs of round 2 (its 64 MB limit made every run a mixed one); the
+// library cannot avoid plain allocations altogether (constructors outside a scope, blocks of a GiB and more), so it does
+// not use that allocator at all.
 thread_local int t_async_scope = 0;
-std::mutex g_pool_mutex;
-std::unordered_set<void*> g_pool_ptrs;
-// PG_ALLOC_SYNC bit 32 (debugging): every live block, pooled or plain, with its size: a new block that overlaps a live one is
-// reported (two owners of one piece of memory: an allocator bug, ours or the runtime's)
-std::map<char*, std::pair<size_t, int>> g_live;   // start -> (bytes, 1 pooled / 0 plain)
-void live_insert(void* p, size_t bytes, int pooled) {
-  if (!(config().alloc_sync & 32) || !p) return;
-  std::lock_guard<std::mutex> lk(g_pool_mutex);
-  char* a = static_cast<char*>(p);
-  auto it = g_live.lower_bound(a);
-  auto report = [&](const std::pair<char* const, std::pair<size_t, int>>& o) {
-    fprintf(stderr, "[pg_alloc] OVERLAP: new %s block %p + %zu overlaps live %s block %p + %zu\n", pooled ? "pool" : "plain", p, bytes,
-            o.second.second ? "pool" : "plain", (void*)o.first, o.second.first);
-  };
-  if (it != g_live.end() && it->first < a + bytes) report(*it);
-  if (it != g_live.begin()) {
-    auto pr = std::prev(it);
-    if (pr->first + pr->second.first > a) report(*pr);
+std::mutex g_alloc_mutex;
+struct BlockCache {
+  std::multimap<size_t, void*> free_blocks;        // size -> block, blocks that may be handed out again
+  std::unordered_map<void*, size_t> owned;         // every block this cache has allocated (free or in use) -> its size
+  size_t free_bytes = 0;
+};
+BlockCache g_cache;
+constexpr size_t CACHE_TRIM_BYTES = (size_t)48 << 30;   // more than this idle: give everything idle back (one device sync)
+
+size_t round_block(size_t bytes) {                      // few distinct sizes: 4 KiB steps, 2 MiB steps from 2 MiB on
+  const size_t q = bytes >= ((size_t)2 << 20) ? ((size_t)2 << 20) : 4096;
+  return (bytes + q - 1) / q * q;
+}
+
+bool cache_wanted(const Context& c, size_t bytes) {
+  const int mode = config().async_alloc;             // 1 everywhere, 0 inside an AsyncAllocScope, -1 never
+  if (mode < 0 || !c.inited || !c.stream || c.local) return false;   // (virtual ranks run one stream per host thread)
+  if (!(t_async_scope > 0 || mode > 0)) return false;
+  const long long lim = config().pool_limit_mb;
+  return lim <= 0 || bytes < ((size_t)lim << 20);
+}
+
+// PG_ALLOC_POISON=1 (debugging): every block starts as 0xFF bytes -- NaN as a double, -1 as an int -- on the stream its first
+// user is ordered on.  A buffer that is read before it is written then shows in the results instead of passing by the
+// accident of fresh (zeroed) device pages; cached blocks and fresh ones alike.
+void poison(void* p, size_t bytes) {
+  if (!config().alloc_poison || !p || bytes == 0) return;
+  Context& c = ctx();
+  if (c.inited && c.stream) PG_HIP(hipMemsetAsync(p, 0xFF, bytes, c.stream));
+  else PG_HIP(hipMemset(p, 0xFF, bytes));
+}
+
+void cache_trim_locked() {                              // idle blocks back to the runtime
+  if (g_cache.free_blocks.empty()) return;
+  (void)hipDeviceSynchronize();
+  for (auto& kv : g_cache.free_blocks) {
+    g_cache.owned.erase(kv.second);
+    (void)hipFree(kv.second);
   }
-  g_live[a] = {bytes, pooled};
+  g_cache.free_blocks.clear();
+  g_cache.free_bytes = 0;
 }
-void live_erase(void* p) {
-  if (!(config().alloc_sync & 32) || !p) return;
-  std::lock_guard<std::mutex> lk(g_pool_mutex);
-  g_live.erase(static_cast<char*>(p));
+
+void* dev_alloc_raw(size_t bytes) {
+  void* p = nullptr;
+  Context& c = ctx();
+  if (cache_wanted(c, bytes)) {
+    const size_t want = round_block(bytes);
+    {
+      std::lock_guard<std::mutex> lk(g_alloc_mutex);
+      auto it = g_cache.free_blocks.lower_bound(want);
+      // a block of the size class, or one at most an eighth larger (the per-slab sizes of a moving problem drift by a few
+      // rows from slab to slab)
+      if (it != g_cache.free_blocks.end() && it->first <= want + want / 8) {
+        p = it->second;
+        g_cache.free_bytes -= it->first;
+        g_cache.free_blocks.erase(it);
+      }
+    }
+    if (!p) {
+      if (hipMalloc(&p, want) != hipSuccess || !p) {     // out of memory with idle blocks around: give them back, once
+        (void)hipGetLastError();
+        { std::lock_guard<std::mutex> lk(g_alloc_mutex); cache_trim_locked(); }
+        PG_HIP(hipMalloc(&p, want));
+      }
+      std::lock_guard<std::mutex> lk(g_alloc_mutex);
+      g_cache.owned[p] = want;
+    }
+    poison(p, bytes);
+    return p;
+  }
+  PG_HIP(hipMalloc(&p, bytes));
+  poison(p, bytes);
+  return p;
 }
-int async_mode() { return config().async_alloc; }   // 1 every allocation from the pool, -1 none (not even inside an AsyncAllocScope)
-bool async_everywhere() { return async_mode() > 0; }
-// Requests of this size and more go the ordinary way (PG_POOL_LIMIT_MB, default 1024: a pool request above 2 GiB aborts the
-// process in this runtime).
-// MIXING the two allocators needs care, and that -- not the size of the pooled blocks -- is what corrupted the 3072² / 4096²
-// slabs of round 2 (profiles/r03_pool_experiment.txt): a plain hipMalloc issued while stream-ordered frees are still
-// PENDING on the compute stream may be served with a block that a hipFreeAsync has released in stream order only -- its
-// last kernels have not run yet -- and the new owner's first writes (a memset, an upload) land in the old owner's data.
-// With everything in the pool, or nothing, the same slabs are bitwise identical; with a 64 MB or a 256 MB limit they were
-// wrong (different active sets from run to run), and a stream synchronisation before every plain hipMalloc made them right
-// again.  scripts/repro/hip_pool_then_malloc.hip is the 60-line demonstration on the bare runtime.  Hence: once this process
-// has used the pool, dev_alloc drains the compute stream before a plain hipMalloc (g_pool_used).
-std::atomic<bool> g_pool_used{false};
-size_t pool_limit() {
-  const long long mb = config().pool_limit_mb;
-  return mb > 0 ? (size_t)mb << 20 : ~(size_t)0;
+
+void dev_free_raw(void* p) {
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lk(g_alloc_mutex);
+    auto it = g_cache.owned.find(p);
+    if (it != g_cache.owned.end()) {
+      // back into the cache without synchronisation: the next owner's work is queued behind this owner's on the same stream
+      g_cache.free_blocks.emplace(it->second, p);
+      g_cache.free_bytes += it->second;
+      if (g_cache.free_bytes > CACHE_TRIM_BYTES) cache_trim_locked();
+      return;
+    }
+  }
+  (void)hipFree(p);
 }
-}  // namespace
+
 // PG_ALLOC_GUARD=1 (debugging): every block sits between two 4 KiB guard bands of 0xA5 bytes that are checked when the block
 // is freed -- an out-of-bounds WRITE shows with the size of the block it ran off, the side, the first damaged byte and the
-// call stack that allocated the block.  (Plain hipMalloc blocks are padded to large pages, so an overrun is silent there;
-// pool blocks are packed 256 bytes apart and an overrun lands in another buffer's data.)
+// call stack that allocated the block.  (Plain hipMalloc blocks are padded to large pages, so an overrun is silent there.)
 constexpr size_t GUARD = 4096;
 struct GuardInfo { char* raw; size_t bytes; unsigned long long seq; std::string where; };
 std::unordered_map<void*, GuardInfo> g_guarded;
@@ -171,21 +232,15 @@ std::string call_stack() {
   free(sym);
   return s;
 }
+}  // namespace
+
 AsyncAllocScope::AsyncAllocScope() { ++t_async_scope; }
 AsyncAllocScope::~AsyncAllocScope() { --t_async_scope; }
 
-// PG_ALLOC_POISON=1 (debugging): every block starts as 0xFF bytes -- NaN as a double, -1 as an int -- on the stream its first
-// user is ordered on.  A buffer that is read before it is written then shows in the results instead of passing by the
-// accident of fresh (zeroed) device pages; pool blocks and hipMalloc blocks alike.
-static void poison(void* p, size_t bytes) {
-  if (!config().alloc_poison || !p || bytes == 0) return;
-  Context& c = ctx();
-  if (c.inited && c.stream) PG_HIP(hipMemsetAsync(p, 0xFF, bytes, c.stream));
-  else PG_HIP(hipMemset(p, 0xFF, bytes));
+void dev_cache_release() {
+  std::lock_guard<std::mutex> lk(g_alloc_mutex);
+  cache_trim_locked();
 }
-
-static void* dev_alloc_raw(size_t bytes);
-static void dev_free_raw(void* p);
 
 void* dev_alloc(size_t bytes) {
   if (!config().alloc_guard) return dev_alloc_raw(bytes);
@@ -195,7 +250,7 @@ void* dev_alloc(size_t bytes) {
   PG_HIP(hipMemsetAsync(raw, 0xA5, GUARD, st));
   PG_HIP(hipMemsetAsync(raw + GUARD + bytes, 0xA5, GUARD, st));
   void* user = raw + GUARD;
-  std::lock_guard<std::mutex> lk(g_pool_mutex);
+  std::lock_guard<std::mutex> lk(g_alloc_mutex);
   g_guarded[user] = GuardInfo{raw, bytes, ++g_alloc_seq, call_stack()};
   return user;
 }
@@ -204,12 +259,12 @@ void dev_free(void* p) {
   if (!config().alloc_guard) { dev_free_raw(p); return; }
   GuardInfo gi;
   {
-    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    std::lock_guard<std::mutex> lk(g_alloc_mutex);
     auto it = g_guarded.find(p);
-    if (it == g_guarded.end()) { dev_free_raw(p); return; }
-    gi = it->second;
-    g_guarded.erase(it);
+    if (it == g_guarded.end()) { gi.raw = nullptr; }
+    else { gi = it->second; g_guarded.erase(it); }
   }
+  if (!gi.raw) { dev_free_raw(p); return; }
   (void)hipDeviceSynchronize();
   std::vector<unsigned char> lo(GUARD), hi(GUARD);
   (void)hipMemcpy(lo.data(), gi.raw, GUARD, hipMemcpyDeviceToHost);
@@ -229,63 +284,6 @@ void dev_free(void* p) {
             bl >= 0 ? (long)GUARD - bl : 0, nh, bh >= 0 ? bh : 0, gi.where.c_str());
   }
   dev_free_raw(gi.raw);
-}
-
-static void* dev_alloc_raw(size_t bytes) {
-  void* p = nullptr;
-  Context& c = ctx();
-  if ((t_async_scope > 0 || async_everywhere()) && async_mode() >= 0 && c.inited && c.stream && !c.local && bytes < pool_limit()) {
-    static bool pool_set = false;
-    if (!pool_set) {
-      hipMemPool_t pool;
-      if (hipDeviceGetDefaultMemPool(&pool, c.device) == hipSuccess) {
-        uint64_t keep = ~0ull;     // never hand memory back at synchronisation points
-        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-      }
-      pool_set = true;
-    }
-    if (config().alloc_sync & 8) (void)hipStreamSynchronize(c.stream);
-    if (hipMallocAsync(&p, bytes, c.stream) == hipSuccess && p) {
-      {
-        std::lock_guard<std::mutex> lk(g_pool_mutex);
-        g_pool_ptrs.insert(p);
-      }
-      g_pool_used.store(true, std::memory_order_relaxed);
-      live_insert(p, bytes, 1);
-      poison(p, bytes);
-      return p;
-    }
-    (void)hipGetLastError();
-    p = nullptr;
-  }
-  // (see pool_limit: pending stream-ordered frees and a plain hipMalloc do not mix; PG_ALLOC_SYNC=4 switches the drain off
-  //  to reproduce the failure)
-  if ((g_pool_used.load(std::memory_order_relaxed) && !(config().alloc_sync & 4)) || (config().alloc_sync & 2)) {
-    Context& pc = ctx();
-    if (pc.inited && pc.stream) (void)hipStreamSynchronize(pc.stream);
-  }
-  PG_HIP(hipMalloc(&p, bytes));
-  live_insert(p, bytes, 0);
-  poison(p, bytes);
-  return p;
-}
-
-static void dev_free_raw(void* p) {
-  live_erase(p);
-  bool pooled = false;
-  {
-    std::lock_guard<std::mutex> lk(g_pool_mutex);
-    pooled = g_pool_ptrs.erase(p) > 0;
-  }
-  if (pooled) {
-    Context* c = thread_context();
-    Context& cc = c ? *c : ctx();
-    if (cc.inited && cc.stream && (config().alloc_sync & 16)) (void)hipStreamSynchronize(cc.stream);
-    if (cc.inited && cc.stream && hipFreeAsync(p, cc.stream) == hipSuccess) return;
-    (void)hipGetLastError();
-  }
-  if (config().alloc_sync & 1) (void)hipDeviceSynchronize();
-  (void)hipFree(p);
 }
 }  // namespace pg
 
@@ -346,6 +344,7 @@ int32_t pg_finalize(void) {
     (void)hipDeviceSynchronize();
     if (c.comm_halo) { (void)ncclCommDestroy(c.comm_halo); c.comm_halo = nullptr; }
     if (c.comm) { (void)ncclCommDestroy(c.comm); c.comm = nullptr; }
+    dev_cache_release();
     if (c.stream) { (void)hipStreamDestroy(c.stream); c.stream = nullptr; }
     if (c.comm_stream) { (void)hipStreamDestroy(c.comm_stream); c.comm_stream = nullptr; }
     if (c.ev_fork) { (void)hipEventDestroy(c.ev_fork); c.ev_fork = nullptr; }
@@ -376,11 +375,11 @@ int32_t pg_config_string(char* buf, size_t n) {
            "spmv_variant=%d spmv_xcd=%d spmv_strip=%d spmv_unit_order=%d spmv_march=%d spmv_march_k=%d spmv_minrun=%d spmv_tile_units=%d "
            "spmv_blocks_per_cu=%d halo_overlap=%d poly=%d poly_degree=%d poly_adapt=%d poly_xspace=%d half_test=%d half_batch=%d "
            "krylov_nt=%d poly_margin=%g poly_slack=%g poly_hist=%d poly_maxdeg=%d recovery_horner=%d gamma_elim=%d diag_elim=%d "
-           "async_alloc=%d pool_limit_mb=%lld alloc_poison=%d profile_sample=%d debug=%d",
+           "async_alloc=%d cache_limit_mb=%lld alloc_poison=%d alloc_guard=%d profile_sample=%d debug=%d",
            k.spmv_variant, k.spmv_xcd, k.spmv_strip, k.unit_order, (int)k.spmv_march, k.spmv_march_k, k.spmv_minrun, k.spmv_tile_units,
            k.spmv_blocks_per_cu, (int)k.halo_overlap, (int)k.poly, k.poly_degree, (int)k.poly_adapt, (int)k.poly_xspace, k.half_test,
            (int)k.half_batch, (int)k.krylov_nt, k.poly_margin, k.poly_slack, k.poly_hist, k.poly_maxdeg, (int)k.recovery_horner,
-           (int)k.gamma_elim, (int)k.diag_elim, k.async_alloc, k.pool_limit_mb, k.alloc_poison, k.profile_sample, (int)k.debug);
+           (int)k.gamma_elim, (int)k.diag_elim, k.async_alloc, k.pool_limit_mb, k.alloc_poison, k.alloc_guard, k.profile_sample, (int)k.debug);
   if (buf && n > 0) {
     std::strncpy(buf, tmp, n - 1);
     buf[n - 1] = 0;

@@ -42,8 +42,9 @@ int main(int argc, char** argv) {
   if (policy & 4) CK(hipMemPoolSetAttribute(pool, hipMemPoolReuseFollowEventDependencies, &off));
   int overlaps = 0;
   unsigned long long* bad;
-  CK(hipMalloc(&bad, 24));
-  CK(hipMemset(bad, 0, 24));
+  CK(hipMalloc(&bad, 48));     // [0..2]: pooled blocks, [3..5]: plain blocks
+  CK(hipMemset(bad, 0, 48));
+  const int wa = argc > 6 ? atoi(argv[6]) : 0;
   const double reserve_gb = argc > 5 ? atof(argv[5]) : 0.0;   // > 0: grow the pool ONCE up front and wait for it
   if (reserve_gb > 0) {
     void* r = nullptr;
@@ -66,7 +67,16 @@ int main(int argc, char** argv) {
       const size_t small_sizes[6] = {(size_t)33570824, (size_t)16785416, (size_t)8 << 20, (size_t)1 << 20, (size_t)65536, (size_t)4096};
       const size_t bytes = small ? small_sizes[rnd() % 6] : sizes[rnd() % 6];
       Blk b{nullptr, bytes / 8, next_id++, plain_every > 0 && allocs % plain_every == plain_every - 1};
-      if (b.plain) CK(hipMalloc((void**)&b.p, bytes)); else CK(hipMallocAsync((void**)&b.p, bytes, s));
+      if (b.plain) {
+        // workarounds tried around the plain allocation (6th argument, bits): 1 stream sync before, 2 device sync before,
+        // 4 device sync after, 8 device sync before the matching hipFree
+        if (wa & 1) CK(hipStreamSynchronize(s));
+        if (wa & 2) CK(hipDeviceSynchronize());
+        CK(hipMalloc((void**)&b.p, bytes));
+        if (wa & 4) CK(hipDeviceSynchronize());
+      } else {
+        CK(hipMallocAsync((void**)&b.p, bytes, s));
+      }
       for (auto& o : live)      // two LIVE blocks must never share an address
         if ((char*)o.p < (char*)b.p + bytes && (char*)b.p < (char*)o.p + o.n * 8) ++overlaps;
       hipLaunchKernelGGL(fill, dim3(1024), dim3(256), 0, s, b.p, b.n, b.id);
@@ -78,18 +88,21 @@ int main(int argc, char** argv) {
       Blk b = live[k];
       live[k] = live.back();
       live.pop_back();
-      hipLaunchKernelGGL(check, dim3(1024), dim3(256), 0, s, (const unsigned long long*)b.p, b.n, b.id, bad);
-      if (b.plain) CK(hipFree(b.p)); else CK(hipFreeAsync(b.p, s));
+      hipLaunchKernelGGL(check, dim3(1024), dim3(256), 0, s, (const unsigned long long*)b.p, b.n, b.id, bad + (b.plain ? 3 : 0));
+      if (b.plain) { if (wa & 8) CK(hipDeviceSynchronize()); CK(hipFree(b.p)); } else CK(hipFreeAsync(b.p, s));
       live_bytes -= b.n * 8;
       ++frees;
     }
   }
-  for (auto& b : live) hipLaunchKernelGGL(check, dim3(1024), dim3(256), 0, s, (const unsigned long long*)b.p, b.n, b.id, bad);
+  for (auto& b : live) hipLaunchKernelGGL(check, dim3(1024), dim3(256), 0, s, (const unsigned long long*)b.p, b.n, b.id, bad + (b.plain ? 3 : 0));
   CK(hipStreamSynchronize(s));
-  unsigned long long hh[3] = {0, 0, 0};
-  CK(hipMemcpy(hh, bad, 24, hipMemcpyDeviceToHost));
-  const unsigned long long h = hh[0];
-  printf("policy %d small %d overlapping live blocks %d | max live %.1f GB, plain_every %d: %d allocations, %d frees, %zu blocks live at the end: %llu words did not hold their owner's value (%llu of them zero, %llu foreign), reserve %.1f GB\n",
-         policy, small, overlaps, max_gb, plain_every, allocs, frees, live.size(), h, hh[1], hh[2], reserve_gb);
+  unsigned long long hh[6] = {0, 0, 0, 0, 0, 0};
+  CK(hipMemcpy(hh, bad, 48, hipMemcpyDeviceToHost));
+  const unsigned long long h = hh[0] + hh[3];
+  printf("pooled blocks: %llu wrong words (%llu zero, %llu foreign); plain blocks: %llu wrong words (%llu zero, %llu foreign)\n", hh[0], hh[1],
+         hh[2], hh[3], hh[4], hh[5]);
+  hh[1] += hh[4]; hh[2] += hh[5];
+  printf("policy %d small %d overlapping live blocks %d | max live %.1f GB, plain_every %d: %d allocations, %d frees, %zu blocks live at the end: %llu words did not hold their owner's value (%llu of them zero, %llu foreign), reserve %.1f GB, workaround %d\n",
+         policy, small, overlaps, max_gb, plain_every, allocs, frees, live.size(), h, hh[1], hh[2], reserve_gb, wa);
   return h != 0;
 }

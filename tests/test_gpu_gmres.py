@@ -31,8 +31,9 @@ def test_gmres_heat_monophasic(pj, scheme0, scheme, restart):
     for a, b in zip(s.states, so.states):
         assert rel_l2(a, b) <= TOL_T
     assert all(c["isconverged"] for c in s.ch)
-    # same iteration as the oracle's GMRES (modified Gram-Schmidt there, CGS2 here) on the same system
-    _, it_ref, _ = po.gmres_ref(Ah, bh, reltol=1e-13, restart=restart or 20)
+    # same iteration as the oracle's GMRES (modified Gram-Schmidt there, CGS2 here) on the same system, with the same
+    # acceptance rule: the true residual in the units of x at the restarts (weights = the row scaling S)
+    _, it_ref, _ = po.gmres_ref(Ah, bh, reltol=1e-13, restart=restart or 20, weights=s.row_scaling(0))
     assert abs(s.ch[0]["iters"] - it_ref) <= 2, (s.ch[0]["iters"], it_ref)
 
 
@@ -85,3 +86,29 @@ def test_gmres_steady_poisson(pj):
     pj.solve_DiffusionSteadyMono_b(s, method="gmres", reltol=1e-13, restart=60)
     po.solve_DiffusionSteadyMono(so, method="\\")
     assert rel_l2(s.x, so.x) <= TOL_T
+
+
+def test_gmres_256_cubed_matches_bicgstab(pj):
+    """BASELINE config 3 (256^3 sphere, benchmark/Heat3D.jl shape) with the reference's DEFAULT method (gmres,
+    src/solver/diffusion.jl:268): at this size the rows are 400 apart in scale and the un-weighted Givens estimate would
+    stop two to three digits early in the units of T; accepted on the weighted true residual at the restarts, GMRES(20)
+    ends at the state BiCGStab reaches to the north star's 1e-10."""
+    n = 256
+    mesh = pj.Mesh((n,) * 3, (4.0,) * 3)
+    cap = pj.Capacity(pj.Sphere((2.01,) * 3, 1.0), mesh)
+    keys = ("left", "right", "top", "bottom")
+    dt = 0.75 * (4.0 / n) ** 2
+    states = {}
+    for method in ("gmres", "bicgstab"):
+        ph = pj.Phase(cap, pj.DiffusionOps(cap), 0.0, 1.0)
+        bcb = pj.BorderConditions({k: pj.Dirichlet(1.0) for k in keys})
+        s = pj.DiffusionUnsteadyMono(ph, bcb, pj.Dirichlet(1.0), dt, None, "BE")
+        pj.solve_DiffusionUnsteadyMono_b(s, ph, dt, 1e30, bcb, pj.Dirichlet(1.0), "CN", save_states=False, max_steps=2,
+                                         method=method, reltol=1e-12, log=True)
+        assert s.unconverged == 0
+        assert all(c["isconverged"] for c in s.ch)
+        states[method] = s.x
+        if method == "gmres":
+            assert max(c["iters"] for c in s.ch) > 20                      # several restart cycles: the restart verdicts ran
+    assert float(np.max(states["bicgstab"])) > 0.5
+    assert rel_l2(states["gmres"], states["bicgstab"]) <= TOL_T
