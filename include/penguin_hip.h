@@ -314,6 +314,14 @@ int32_t pg_solver_time_spmv(pg_solver* s, int32_t which, int32_t reps, double* a
 /* host-logic helper (no GPU needed): slab partition of `nplanes` planes with per-plane weights
    (active rows) into nranks contiguous ranges; bounds has nranks+1 entries. */
 int32_t pg_partition_planes(const int64_t* weight, int64_t nplanes, int32_t nranks, int64_t* bounds);
+/* host-logic helper (no GPU needed): the local numbering of the slab that owns planes [p0, p1) of `nplanes` planes of
+   `plane` cells -- segment offsets, ghost segments and the contiguous chunks exchanged with the neighbours (SURVEY 8e;
+   the code path build_numbering on the device ends in).  active: K * Mloc flags, kind-major, over the slab's STORED planes
+   [max(p0 - 3, 0), min(p1 + 3, nplanes)), Mloc = stored planes * plane.  out (2 + 10 K int64): n_own, n_ghost, then K
+   entries each of cnt_own, off_own, cntL, offL, cntU, offU, sendL_off, sendL_cnt, sendU_off, sendU_cnt (offsets into the
+   local vector [owned kinds | lower ghosts | upper ghosts]). */
+int32_t pg_slab_numbering_host(int32_t K, int64_t plane, int64_t nplanes, int64_t p0, int64_t p1, const uint8_t* active,
+                               int64_t* out);
 
 /* ---- diagnostics (not part of the reference-facing boundary) ------------------------------------------------ */
 /* y = A x with two kernel variants (PG_SPMV_VARIANT numbering: 70 stencil slices, 38 chunked CSR, 1 first CSR kernel)

@@ -92,6 +92,43 @@ def declared_symbols() -> list[str]:
 
 
 _lib = None
+hip_runtime_source = "system"      # which libamdhip64 the library is bound to ("system", "torch wheel", "already mapped by torch")
+
+
+def _share_the_hip_runtime_with_torch() -> None:
+    """One HIP runtime per process.  A PyTorch-ROCm wheel ships its own libamdhip64 / libhsa-runtime64 (SONAMEs
+    libamdhip64.so.7, ... -- the system ROCm's SONAMEs) and its libraries ask for them by FILE name (`libamdhip64.so`,
+    RPATH $ORIGIN).  Loaded first, torch's copies satisfy libpenguin_hip.so's NEEDED entries by SONAME: one runtime.  Loaded
+    second, the file-name lookup does not match the system copy we brought in and a second HIP + HSA runtime is mapped into
+    the process.  So when torch is installed but not imported yet, its runtime files are loaded here, before ours resolves
+    its dependencies: whichever side comes first, both end up on the same copies (scripts/which_hip_runtime.py lists them).
+    PG_HIP_RUNTIME=system keeps the system ROCm.
+    (The abort at interpreter exit that round 2 met when torch was imported after the library had another cause -- librccl
+    mapped before torch -- and is gone because RCCL is loaded on first use now: csrc/pg_rccl.h.)"""
+    global hip_runtime_source
+    import sys
+
+    if "torch" in sys.modules:
+        hip_runtime_source = "already mapped by torch"
+        return
+    if os.environ.get("PG_HIP_RUNTIME", "auto") == "system":
+        return
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = Path(list(spec.submodule_search_locations)[0]) / "lib"
+    if not (libdir / "libamdhip64.so").exists():
+        return                                            # a CPU / CUDA build of torch: nothing to share
+    mode = C.RTLD_GLOBAL if hasattr(C, "RTLD_GLOBAL") else 0
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        if (libdir / name).exists():
+            C.CDLL(str(libdir / name), mode=mode)
+    hip_runtime_source = "torch wheel"
 
 
 def lib() -> C.CDLL:
@@ -102,6 +139,7 @@ def lib() -> C.CDLL:
             raise PenguinHipError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  penguin.jl_amd has no CPU fallback.")
+        _share_the_hip_runtime_with_torch()
         _lib = C.CDLL(str(LIB_PATH), mode=C.RTLD_GLOBAL if hasattr(C, "RTLD_GLOBAL") else 0)
         for name in declared_symbols():
             getattr(_lib, name).restype = C.c_int32

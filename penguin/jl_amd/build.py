@@ -68,7 +68,7 @@ def build_library(force: bool = False, verbose: bool = True) -> Path:
                     print(f"[build] compiled {name}", flush=True)
     objs = [str(OBJ / (s.stem + ".o")) for s in sources]
     if jobs or force or not LIB.exists():
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB), *objs, "-L/opt/rocm/lib", "-lrccl"]
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB), *objs, "-ldl"]   # RCCL is dlopen'ed on first use (csrc/pg_rccl.h)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")

@@ -8,6 +8,7 @@
 // One thread per padded cell evaluates its rows from the capacities; a row is kept iff it has a non-zero
 // entry and some row has a non-zero entry in its column (rows ∩ cols, solver.jl:71).  Flags -> exclusive
 // scan -> local numbering; per-row counts -> scan -> rowptr; second evaluation writes col/val.
+#include "pg_host_algos.h"
 #include "pg_scan.h"
 #include "pg_system.h"
 
@@ -222,33 +223,30 @@ void build_numbering(const SysParams& P, const Slab& s, Numbering& nb) {
   };
   const i64 lc_first_end = (s.p0 + 1 - s.s0) * s.plane;   // end of the first owned plane
   const i64 lc_last_begin = (s.p1 - 1 - s.s0) * s.plane;  // start of the last owned plane
-  i64 off = 0;
-  i64 pos_first_end[MAX_KINDS], pos_last_begin[MAX_KINDS];
+  static_assert(pghost::SLAB_MAX_KINDS == MAX_KINDS, "kinds");
+  i64 pos_first_end[MAX_KINDS], pos_last_begin[MAX_KINDS], tot[MAX_KINDS];
   for (int k = 0; k < K; ++k) {
     m.posO[k] = pos_at(k, m.lcO);
     m.posU[k] = pos_at(k, m.lcU);
     pos_first_end[k] = pos_at(k, lc_first_end);
     pos_last_begin[k] = pos_at(k, lc_last_begin);
-    nb.cntL[k] = m.posO[k];
-    nb.cnt_own[k] = m.posU[k] - m.posO[k];
-    nb.cntU[k] = htot[k] - m.posU[k];
-    nb.off_own[k] = off;
-    off += nb.cnt_own[k];
+    tot[k] = htot[k];
   }
-  nb.n_own = off;
-  for (int k = 0; k < K; ++k) { nb.offL[k] = off; off += nb.cntL[k]; }
-  for (int k = 0; k < K; ++k) { nb.offU[k] = off; off += nb.cntU[k]; }
-  nb.n_ghost = off - nb.n_own;
-  PG_REQUIRE(off < (i64)2147483647, "reduced system exceeds int32 indexing");
+  // segment offsets, ghost segments and send chunks: plain host code shared with the CPU suite (pg_host_algos.h)
+  pghost::SlabNumbering sn;
+  pghost::slab_numbering(K, m.posO, m.posU, pos_first_end, pos_last_begin, tot, s.p0 > 0, s.p1 < s.nplanes, sn);
+  nb.n_own = sn.n_own;
+  nb.n_ghost = sn.n_ghost;
+  PG_REQUIRE(sn.n_own + sn.n_ghost < (i64)2147483647, "reduced system exceeds int32 indexing");
   for (int k = 0; k < K; ++k) {
+    nb.cnt_own[k] = sn.cnt_own[k]; nb.off_own[k] = sn.off_own[k];
+    nb.cntL[k] = sn.cntL[k]; nb.offL[k] = sn.offL[k];
+    nb.cntU[k] = sn.cntU[k]; nb.offU[k] = sn.offU[k];
+    nb.sendL_off[k] = sn.sendL_off[k]; nb.sendL_cnt[k] = sn.sendL_cnt[k];
+    nb.sendU_off[k] = sn.sendU_off[k]; nb.sendU_cnt[k] = sn.sendU_cnt[k];
     m.off_own[k] = nb.off_own[k];
     m.offL[k] = nb.offL[k];
     m.offU[k] = nb.offU[k];
-    // owned actives of the first owned plane go to the lower neighbour, of the last to the upper one
-    nb.sendL_off[k] = nb.off_own[k];
-    nb.sendL_cnt[k] = s.p0 > 0 ? pos_first_end[k] - m.posO[k] : 0;
-    nb.sendU_cnt[k] = s.p1 < s.nplanes ? m.posU[k] - pos_last_begin[k] : 0;
-    nb.sendU_off[k] = nb.off_own[k] + nb.cnt_own[k] - nb.sendU_cnt[k];
   }
   nb.red.alloc((i64)K * Mloc);
   nb.row_cell.alloc(nb.n_own > 0 ? nb.n_own : 1);

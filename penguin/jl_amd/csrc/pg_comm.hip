@@ -9,7 +9,10 @@
 //     numbering and every send/recv offset of the multi-GPU path can be verified bit for bit on a 1-GPU box
 //     (pg_debug_run_virtual_ranks, tests/test_gpu_virtual_ranks.py).  Same reduction order as RCCL is NOT
 //     assumed anywhere: results only need to be identical on all ranks, which both backends guarantee.
+#include <dlfcn.h>
 #include <pthread.h>
+
+#include <mutex>
 
 #include "pg_krylov.h"
 
@@ -26,6 +29,43 @@ struct LocalComm {
   ~LocalComm() { pthread_barrier_destroy(&bar); }
   void barrier() { pthread_barrier_wait(&bar); }
 };
+
+namespace rccl {
+namespace {
+Api g_api;
+bool g_loaded = false;
+std::mutex g_load_mutex;
+}  // namespace
+bool loaded() { return g_loaded; }
+const Api& api() {
+  std::lock_guard<std::mutex> lk(g_load_mutex);
+  if (g_loaded) return g_api;
+  void* h = nullptr;
+  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (h) break;
+  }
+  if (!h) throw Error(std::string("penguin_hip: RCCL (librccl.so.1) cannot be loaded -- needed for runs on several GPUs: ") + dlerror());
+  auto need = [&](const char* sym, bool required = true) -> void* {
+    void* p = dlsym(h, sym);
+    if (!p && required) throw Error(std::string("penguin_hip: RCCL lacks ") + sym);
+    return p;
+  };
+  g_api.GetUniqueId = reinterpret_cast<decltype(g_api.GetUniqueId)>(need("ncclGetUniqueId"));
+  g_api.CommInitRank = reinterpret_cast<decltype(g_api.CommInitRank)>(need("ncclCommInitRank"));
+  g_api.CommSplit = reinterpret_cast<decltype(g_api.CommSplit)>(need("ncclCommSplit", false));
+  g_api.CommDestroy = reinterpret_cast<decltype(g_api.CommDestroy)>(need("ncclCommDestroy"));
+  g_api.AllReduce = reinterpret_cast<decltype(g_api.AllReduce)>(need("ncclAllReduce"));
+  g_api.Broadcast = reinterpret_cast<decltype(g_api.Broadcast)>(need("ncclBroadcast"));
+  g_api.Send = reinterpret_cast<decltype(g_api.Send)>(need("ncclSend"));
+  g_api.Recv = reinterpret_cast<decltype(g_api.Recv)>(need("ncclRecv"));
+  g_api.GroupStart = reinterpret_cast<decltype(g_api.GroupStart)>(need("ncclGroupStart"));
+  g_api.GroupEnd = reinterpret_cast<decltype(g_api.GroupEnd)>(need("ncclGroupEnd"));
+  g_api.GetErrorString = reinterpret_cast<decltype(g_api.GetErrorString)>(need("ncclGetErrorString"));
+  g_loaded = true;
+  return g_api;
+}
+}  // namespace rccl
 
 static thread_local Context* tl_ctx = nullptr;
 void set_thread_context(Context* c) { tl_ctx = c; }
@@ -56,21 +96,21 @@ void comm_allreduce_sum_f64(double* dev, int count, hipStream_t st) {
   Context& cx = ctx();
   if (cx.nranks == 1 && !cx.comm) return;
   if (cx.local) local_allreduce<double>(cx.local, cx.rank, cx.local->slot_f64, dev, count, st, false);
-  else PG_NCCL(ncclAllReduce(dev, dev, count, ncclDouble, ncclSum, cx.comm, st));
+  else PG_NCCL(rccl::api().AllReduce(dev, dev, count, ncclDouble, ncclSum, cx.comm, st));
 }
 
 void comm_allreduce_max_f64(double* dev, int count, hipStream_t st) {
   Context& cx = ctx();
   if (cx.nranks == 1 && !cx.comm) return;
   if (cx.local) local_allreduce<double>(cx.local, cx.rank, cx.local->slot_f64, dev, count, st, true);
-  else PG_NCCL(ncclAllReduce(dev, dev, count, ncclDouble, ncclMax, cx.comm, st));
+  else PG_NCCL(rccl::api().AllReduce(dev, dev, count, ncclDouble, ncclMax, cx.comm, st));
 }
 
 void comm_allreduce_sum_u64(unsigned long long* dev, i64 count, hipStream_t st) {
   Context& cx = ctx();
   if (cx.nranks == 1 && !cx.comm) return;
   if (cx.local) local_allreduce<unsigned long long>(cx.local, cx.rank, cx.local->slot_u64, dev, count, st, false);
-  else PG_NCCL(ncclAllReduce(dev, dev, count, ncclUint64, ncclSum, cx.comm, st));
+  else PG_NCCL(rccl::api().AllReduce(dev, dev, count, ncclUint64, ncclSum, cx.comm, st));
 }
 
 static void rccl_halo(const Numbering& nb, const Slab& slab, double* vec, hipStream_t st);
@@ -133,18 +173,19 @@ static void rccl_halo(const Numbering& nb, const Slab& slab, double* vec, hipStr
   Context& cx = ctx();
   const bool has_lo = slab.p0 > 0, has_hi = slab.p1 < slab.nplanes;
   // ranks own increasing plane ranges: the lower neighbour is rank-1, the upper one rank+1
-  PG_NCCL(ncclGroupStart());
+  const rccl::Api& R = rccl::api();
+  PG_NCCL(R.GroupStart());
   for (int k = 0; k < nb.K; ++k) {
     if (has_lo) {
-      if (nb.sendL_cnt[k] > 0) PG_NCCL(ncclSend(vec + nb.sendL_off[k], nb.sendL_cnt[k], ncclDouble, cx.rank - 1, cx.comm_halo, st));
-      if (nb.cntL[k] > 0) PG_NCCL(ncclRecv(vec + nb.offL[k], nb.cntL[k], ncclDouble, cx.rank - 1, cx.comm_halo, st));
+      if (nb.sendL_cnt[k] > 0) PG_NCCL(R.Send(vec + nb.sendL_off[k], nb.sendL_cnt[k], ncclDouble, cx.rank - 1, cx.comm_halo, st));
+      if (nb.cntL[k] > 0) PG_NCCL(R.Recv(vec + nb.offL[k], nb.cntL[k], ncclDouble, cx.rank - 1, cx.comm_halo, st));
     }
     if (has_hi) {
-      if (nb.sendU_cnt[k] > 0) PG_NCCL(ncclSend(vec + nb.sendU_off[k], nb.sendU_cnt[k], ncclDouble, cx.rank + 1, cx.comm_halo, st));
-      if (nb.cntU[k] > 0) PG_NCCL(ncclRecv(vec + nb.offU[k], nb.cntU[k], ncclDouble, cx.rank + 1, cx.comm_halo, st));
+      if (nb.sendU_cnt[k] > 0) PG_NCCL(R.Send(vec + nb.sendU_off[k], nb.sendU_cnt[k], ncclDouble, cx.rank + 1, cx.comm_halo, st));
+      if (nb.cntU[k] > 0) PG_NCCL(R.Recv(vec + nb.offU[k], nb.cntU[k], ncclDouble, cx.rank + 1, cx.comm_halo, st));
     }
   }
-  PG_NCCL(ncclGroupEnd());
+  PG_NCCL(R.GroupEnd());
 }
 
 }  // namespace pg

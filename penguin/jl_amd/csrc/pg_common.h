@@ -1,7 +1,7 @@
 // pg_common.h -- shared internals of libpenguin_hip.so (gfx950 only; no CUDA paths, no shims).
 #pragma once
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include "pg_rccl.h"
 
 #include <chrono>
 #include <cstdint>
@@ -36,7 +36,7 @@ void set_last_error(const std::string& msg);
   do {                                                                                            \
     ncclResult_t _e = (expr);                                                                     \
     if (_e != ncclSuccess)                                                                        \
-      throw pg::Error(std::string("RCCL error: ") + ncclGetErrorString(_e) + " at " + __FILE__ + ":" + \
+      throw pg::Error(std::string("RCCL error: ") + pg::rccl::api().GetErrorString(_e) + " at " + __FILE__ + ":" + \
                       std::to_string(__LINE__) + " (" #expr ")");                                 \
   } while (0)
 

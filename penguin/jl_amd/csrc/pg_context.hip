@@ -310,7 +310,7 @@ int32_t pg_get_unique_id(void* out128) {
   PG_API_BEGIN
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
   ncclUniqueId id;
-  PG_NCCL(ncclGetUniqueId(&id));
+  PG_NCCL(rccl::api().GetUniqueId(&id));
   std::memcpy(out128, &id, sizeof(id));
   PG_API_END
 }
@@ -326,13 +326,29 @@ int32_t pg_init_distributed(int32_t device_id, int32_t rank, int32_t nranks, con
     PG_REQUIRE(unique_id128 != nullptr, "pg_init_distributed: unique id required when nranks > 1");
     ncclUniqueId id;
     std::memcpy(&id, unique_id128, sizeof(id));
-    PG_NCCL(ncclCommInitRank(&c.comm, nranks, id, rank));
+    const rccl::Api& R = rccl::api();
+    PG_NCCL(R.CommInitRank(&c.comm, nranks, id, rank));
     // A communicator of its own for the halos: each communicator is then driven from exactly ONE stream (comm: compute
     // stream, comm_halo: communication stream), so nothing rests on how RCCL orders operations that one communicator
     // receives from two streams.  Both are used by every rank in the same program order, and a halo exchange is never in
     // flight together with a reduction (halo_end joins the compute stream before the launch whose dots are reduced; the
     // next exchange forks off the compute stream after that reduction): no two RCCL kernels can wait for each other.
-    PG_NCCL(ncclCommSplit(c.comm, 0, rank, &c.comm_halo, nullptr));
+    // (an RCCL without ncclCommSplit, or one that refuses it: a second communicator from a second id, which rank 0
+    //  hands round through the first one)
+    bool split_ok = false;
+    if (R.CommSplit) {
+      split_ok = R.CommSplit(c.comm, 0, rank, &c.comm_halo, nullptr) == ncclSuccess && c.comm_halo != nullptr;
+      if (!split_ok) c.comm_halo = nullptr;
+    }
+    if (!split_ok) {
+      ncclUniqueId id2;
+      if (rank == 0) PG_NCCL(R.GetUniqueId(&id2));
+      DevBuf<char> buf((i64)sizeof(id2));
+      if (rank == 0) buf.upload(reinterpret_cast<const char*>(&id2), (i64)sizeof(id2));
+      PG_NCCL(R.Broadcast(buf.p, buf.p, sizeof(id2), ncclChar, 0, c.comm, c.stream));
+      buf.download(reinterpret_cast<char*>(&id2), (i64)sizeof(id2));
+      PG_NCCL(R.CommInitRank(&c.comm_halo, nranks, id2, rank));
+    }
   }
   PG_API_END
 }
@@ -342,8 +358,8 @@ int32_t pg_finalize(void) {
   Context& c = ctx();
   if (c.inited) {
     (void)hipDeviceSynchronize();
-    if (c.comm_halo) { (void)ncclCommDestroy(c.comm_halo); c.comm_halo = nullptr; }
-    if (c.comm) { (void)ncclCommDestroy(c.comm); c.comm = nullptr; }
+    if (c.comm_halo) { (void)rccl::api().CommDestroy(c.comm_halo); c.comm_halo = nullptr; }
+    if (c.comm) { (void)rccl::api().CommDestroy(c.comm); c.comm = nullptr; }
     dev_cache_release();
     if (c.stream) { (void)hipStreamDestroy(c.stream); c.stream = nullptr; }
     if (c.comm_stream) { (void)hipStreamDestroy(c.comm_stream); c.comm_stream = nullptr; }
@@ -479,6 +495,40 @@ int32_t pg_partition_planes(const int64_t* weight, int64_t nplanes, int32_t nran
   PG_REQUIRE(weight && bounds && nplanes >= 1 && nranks >= 1, "pg_partition_planes: bad arguments");
   PG_REQUIRE(nplanes >= nranks, "pg_partition_planes: fewer planes than ranks");
   pghost::partition_planes(weight, nplanes, nranks, bounds);   // pg_host_algos.h (also built with ASan / UBSan for the CPU suite)
+  PG_API_END
+}
+
+int32_t pg_slab_numbering_host(int32_t K, int64_t plane, int64_t nplanes, int64_t p0, int64_t p1, const uint8_t* active,
+                               int64_t* out) {
+  PG_API_BEGIN
+  PG_REQUIRE(K >= 1 && K <= pghost::SLAB_MAX_KINDS && plane >= 1 && nplanes >= 1 && p0 >= 0 && p1 > p0 && p1 <= nplanes && active && out,
+             "pg_slab_numbering_host: bad arguments");
+  const pghost::SlabPlanes g = pghost::slab_planes(p0, p1, nplanes, CAP_HALO);
+  const i64 Mloc = (g.s1 - g.s0) * plane;
+  const i64 lcA0 = (g.a0 - g.s0) * plane, lcA1 = (g.a1 - g.s0) * plane;        // flags count inside the one ghost plane each side
+  const i64 lcO = (p0 - g.s0) * plane, lcU = (p1 - g.s0) * plane, lcFE = (p0 + 1 - g.s0) * plane, lcLB = (p1 - 1 - g.s0) * plane;
+  i64 posO[pghost::SLAB_MAX_KINDS], posU[pghost::SLAB_MAX_KINDS], posFE[pghost::SLAB_MAX_KINDS], posLB[pghost::SLAB_MAX_KINDS],
+      tot[pghost::SLAB_MAX_KINDS];
+  for (int k = 0; k < K; ++k) {
+    i64 c = 0;
+    posO[k] = posU[k] = posFE[k] = posLB[k] = -1;
+    for (i64 lc = 0; lc <= Mloc; ++lc) {
+      if (lc == lcO) posO[k] = c;
+      if (lc == lcU) posU[k] = c;
+      if (lc == lcFE) posFE[k] = c;
+      if (lc == lcLB) posLB[k] = c;
+      if (lc < Mloc && lc >= lcA0 && lc < lcA1 && active[(i64)k * Mloc + lc]) ++c;
+    }
+    tot[k] = c;
+  }
+  pghost::SlabNumbering sn;
+  pghost::slab_numbering(K, posO, posU, posFE, posLB, tot, p0 > 0, p1 < nplanes, sn);
+  i64 q = 0;
+  out[q++] = sn.n_own;
+  out[q++] = sn.n_ghost;
+  const i64* arrays[10] = {sn.cnt_own, sn.off_own, sn.cntL, sn.offL, sn.cntU, sn.offU, sn.sendL_off, sn.sendL_cnt, sn.sendU_off, sn.sendU_cnt};
+  for (const i64* a : arrays)
+    for (int k = 0; k < K; ++k) out[q++] = a[k];
   PG_API_END
 }
 

@@ -27,6 +27,62 @@ inline void partition_planes(const int64_t* weight, int64_t nplanes, int nranks,
   bounds[nranks] = nplanes;
 }
 
+// ---- local numbering of one slab (K10, the layout pg_comm.hip's halo exchange rests on) -----------------------------
+// Local vector layout: [kind 0 owned | kind 1 owned | ... | lower ghosts: kind 0, kind 1, ... | upper ghosts: kind 0, ...].
+// Owned unknowns of a kind are ordered by padded cell index, so the actives of the first / last owned plane are the
+// contiguous chunks at the start / end of each kind's segment: they are what goes to the lower / upper neighbour, and what
+// arrives from a neighbour lands in one contiguous ghost segment per kind -- no pack / unpack kernels.
+// Inputs per kind k: the number of active unknowns of the stored planes that lie BEFORE the first owned plane (posO), before
+// the end of the last owned plane (posU), before the end of the first owned plane (posFE), before the start of the last
+// owned plane (posLB), and in all stored planes (tot); actives outside the one ghost plane each side do not exist (their
+// flags are cleared before the count).  build_numbering (device scans) and pg_slab_numbering_host (CPU prefix sums: the
+// gloo test of the CPU suite) both end here.
+constexpr int SLAB_MAX_KINDS = 4;
+struct SlabNumbering {
+  int K = 0;
+  int64_t n_own = 0, n_ghost = 0;
+  int64_t cnt_own[SLAB_MAX_KINDS], off_own[SLAB_MAX_KINDS], cntL[SLAB_MAX_KINDS], offL[SLAB_MAX_KINDS], cntU[SLAB_MAX_KINDS],
+      offU[SLAB_MAX_KINDS], sendL_off[SLAB_MAX_KINDS], sendL_cnt[SLAB_MAX_KINDS], sendU_off[SLAB_MAX_KINDS], sendU_cnt[SLAB_MAX_KINDS];
+};
+inline void slab_numbering(int K, const int64_t* posO, const int64_t* posU, const int64_t* posFE, const int64_t* posLB,
+                           const int64_t* tot, bool has_lower, bool has_upper, SlabNumbering& out) {
+  out.K = K;
+  int64_t off = 0;
+  for (int k = 0; k < K; ++k) {
+    out.cntL[k] = posO[k];
+    out.cnt_own[k] = posU[k] - posO[k];
+    out.cntU[k] = tot[k] - posU[k];
+    out.off_own[k] = off;
+    off += out.cnt_own[k];
+  }
+  out.n_own = off;
+  for (int k = 0; k < K; ++k) { out.offL[k] = off; off += out.cntL[k]; }
+  for (int k = 0; k < K; ++k) { out.offU[k] = off; off += out.cntU[k]; }
+  out.n_ghost = off - out.n_own;
+  for (int k = 0; k < K; ++k) {
+    // owned actives of the first owned plane go to the lower neighbour, of the last to the upper one
+    out.sendL_off[k] = out.off_own[k];
+    out.sendL_cnt[k] = has_lower ? posFE[k] - posO[k] : 0;
+    out.sendU_cnt[k] = has_upper ? posU[k] - posLB[k] : 0;
+    out.sendU_off[k] = out.off_own[k] + out.cnt_own[k] - out.sendU_cnt[k];
+  }
+  for (int k = K; k < SLAB_MAX_KINDS; ++k)
+    out.cnt_own[k] = out.off_own[k] = out.cntL[k] = out.offL[k] = out.cntU[k] = out.offU[k] = out.sendL_off[k] = out.sendL_cnt[k] =
+        out.sendU_off[k] = out.sendU_cnt[k] = 0;
+}
+
+// stored / exact-flag plane ranges of a slab that owns planes [p0, p1): stored = [p0 - halo, p1 + halo) clipped, flags are
+// exact on [p0 - 1, p1 + 1) clipped (one ghost plane each side)
+struct SlabPlanes { int64_t s0, s1, a0, a1; };
+inline SlabPlanes slab_planes(int64_t p0, int64_t p1, int64_t nplanes, int halo) {
+  SlabPlanes g;
+  g.s0 = p0 - halo < 0 ? 0 : p0 - halo;
+  g.s1 = p1 + halo > nplanes ? nplanes : p1 + halo;
+  g.a0 = p0 - 1 < 0 ? 0 : p0 - 1;
+  g.a1 = p1 + 1 > nplanes ? nplanes : p1 + 1;
+  return g;
+}
+
 struct MRun {
   int r0, len, cnt;   // rows [r0, r0 + len) with one stencil (offsets and values), cnt = 5 / 7 entries
 };

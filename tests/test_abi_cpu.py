@@ -112,3 +112,27 @@ def test_compute_fails_loudly_without_gpu(L):
         pj.Capacity(pj.Sphere((0.5, 0.5), 0.3), mesh)
     with pytest.raises(pj.PenguinHipError):
         pj.Capacity(lambda x, y: x + y, mesh)    # arbitrary callables are refused, never evaluated on the CPU
+
+
+@pytest.mark.parametrize("order", ["lib,torch", "torch,lib"])
+def test_one_hip_runtime_whichever_of_torch_and_the_library_comes_first(order):
+    """A PyTorch-ROCm wheel bundles its own libamdhip64 / libhsa-runtime64 / librccl.  The binding loads torch's HIP runtime
+    first when torch is installed, so both orders map exactly one copy of each; and the library no longer brings librccl
+    into the process at load time (mapped before torch it made the interpreter abort at exit, round 2): both orders exit 0."""
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, str(ROOT / "scripts" / "which_hip_runtime.py"), order], cwd=ROOT, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-1000:])
+    mapped = [l.split("mapped:")[1].strip() for l in r.stdout.splitlines() if "mapped:" in l]
+    for name in ("libamdhip64", "libhsa-runtime64", "librccl"):
+        copies = [m for m in mapped if name in m.rsplit("/", 1)[-1]]
+        assert len(copies) == 1, (name, copies)
+
+
+def test_library_is_not_linked_against_rccl(L):
+    """RCCL is dlopen'ed when the first communicator is created (csrc/pg_rccl.h): a single-GPU host never maps it."""
+    out = subprocess.run(["readelf", "-d", str(L.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    needed = [l for l in out.splitlines() if "NEEDED" in l]
+    assert needed and not any("rccl" in l for l in needed), needed

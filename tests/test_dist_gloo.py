@@ -2,6 +2,10 @@
 system by planes (pg_partition_planes), one ghost chunk per neighbour and SpMV, dot products all-reduced, the collective admission test and the iteration of the
 Neumann right preconditioner --
 restated here with the oracle's matrix in numpy and torch.distributed(gloo) so that it runs without a GPU.
+The LOCAL NUMBERING is the product's own: every rank asks pg_slab_numbering_host (the host code build_numbering ends in,
+pg_host_algos.h) for its segment offsets, ghost segments and send chunks, lays its vectors out accordingly, and the halo is
+the exchange pg_comm.hip makes -- one contiguous send and one contiguous receive per unknown kind and neighbour, straight
+out of / into the vectors (gloo send / recv standing in for ncclSend / ncclRecv).
 The device implementation of the same plan is verified on the GPU box by tests/test_gpu_virtual_ranks.py."""
 import os
 import socket
@@ -46,17 +50,84 @@ WORKER = textwrap.dedent('''
     own = np.flatnonzero((pl >= bounds[rank]) & (pl < bounds[rank + 1]))
     Aloc = A[own, :]
     cols = np.unique(Aloc.indices)
-    ghost = np.setdiff1d(cols, own)
-    # ghosts must live in the single plane adjacent to the slab (one ghost plane per neighbour)
-    assert np.all((pl[ghost] == bounds[rank] - 1) | (pl[ghost] == bounds[rank + 1]))
+    # ---- the product's local numbering of this slab (pg_slab_numbering_host): active flags of the stored planes in, segment
+    # offsets / ghost segments / send chunks out
+    K, nplanes = 2, n + 1
+    p0, p1 = int(bounds[rank]), int(bounds[rank + 1])
+    s0, s1 = max(p0 - 3, 0), min(p1 + 3, nplanes)
+    Mloc = (s1 - s0) * plane
+    kind = idx // M
+    active = np.zeros(K * Mloc, dtype=np.uint8)
+    stored = (pl >= s0) & (pl < s1)
+    active[kind[stored] * Mloc + (cell[stored] - s0 * plane)] = 1
+    out = np.zeros(2 + 10 * K, dtype=np.int64)
+    L.check(L.lib().pg_slab_numbering_host(C.c_int32(K), C.c_int64(plane), C.c_int64(nplanes), C.c_int64(p0), C.c_int64(p1),
+                                           active.ctypes.data_as(C.POINTER(C.c_uint8)), L.iptr(out)))
+    n_own, n_ghost = int(out[0]), int(out[1])
+    names = ("cnt_own", "off_own", "cntL", "offL", "cntU", "offU", "sendL_off", "sendL_cnt", "sendU_off", "sendU_cnt")
+    nb = {nm: out[2 + q * K: 2 + (q + 1) * K].tolist() for q, nm in enumerate(names)}
     nloc = len(own)
+    assert n_own == nloc, (n_own, nloc)
+    # owned: the reference's common_idx order restricted to the slab (kind 0 by cell, then kind 1) -- `own` already is
+    assert [int(np.count_nonzero(kind[own] == k)) for k in range(K)] == nb["cnt_own"]
+    assert nb["off_own"] == [0, nb["cnt_own"][0]]
+    # ghosts in the product's order: lower ghost plane kind 0, kind 1, then upper ghost plane kind 0, kind 1
+    glist = []
+    for side_plane, cnt_key, off_key in ((p0 - 1, "cntL", "offL"), (p1, "cntU", "offU")):
+        for k in range(K):
+            g = np.flatnonzero((pl == side_plane) & (kind == k)) if 0 <= side_plane < nplanes else np.zeros(0, dtype=np.int64)
+            assert len(g) == nb[cnt_key][k], (side_plane, k, len(g), nb[cnt_key][k])
+            assert nb[off_key][k] == nloc + len(glist)
+            glist.extend(g.tolist())
+    ghost = np.array(glist, dtype=np.int64)
+    assert len(ghost) == n_ghost
+    # every column a row of this slab references is owned or sits in one of those ghost segments (one ghost plane per side)
+    assert np.all(np.isin(np.setdiff1d(cols, own), ghost))
+    # the send chunks are the owned actives of the first / last owned plane, contiguous at the start / end of each kind
+    for k in range(K):
+        seg = own[nb["off_own"][k]: nb["off_own"][k] + nb["cnt_own"][k]]
+        if p0 > 0:
+            assert np.array_equal(seg[: nb["sendL_cnt"][k]], np.flatnonzero((pl == p0) & (kind == k)))
+            assert nb["sendL_off"][k] == nb["off_own"][k]
+        else:
+            assert nb["sendL_cnt"][k] == 0
+        if p1 < nplanes:
+            assert np.array_equal(own[nb["sendU_off"][k]: nb["sendU_off"][k] + nb["sendU_cnt"][k]], np.flatnonzero((pl == p1 - 1) & (kind == k)))
+        else:
+            assert nb["sendU_cnt"][k] == 0
     lmap = -np.ones(A.shape[0], dtype=np.int64); lmap[own] = np.arange(nloc); lmap[ghost] = nloc + np.arange(len(ghost))
     Al = sp.csr_matrix((Aloc.data, lmap[Aloc.indices], Aloc.indptr), shape=(nloc, nloc + len(ghost)))
 
     def halo(v):
-        full = torch.zeros(A.shape[0], dtype=torch.float64); full[own] = torch.from_numpy(v[:nloc].copy())
-        dist.all_reduce(full)                      # test harness shortcut for the neighbour send/recv
-        v[nloc:] = full.numpy()[ghost]
+        """pg_comm.hip rccl_halo: per kind, send the chunk of owned values the neighbour needs, receive its chunk straight into
+        the ghost segment -- contiguous slices of v, nothing packed.  (gloo send / recv are blocking: the lower rank of a
+        pair sends first.)"""
+        for k in range(K):
+            for nbr, s_off, s_cnt, r_off, r_cnt in ((rank - 1, nb["sendL_off"][k], nb["sendL_cnt"][k], nb["offL"][k], nb["cntL"][k]),
+                                                    (rank + 1, nb["sendU_off"][k], nb["sendU_cnt"][k], nb["offU"][k], nb["cntU"][k])):
+                if nbr < 0 or nbr >= world:
+                    continue
+                snd = torch.from_numpy(v[s_off: s_off + s_cnt].copy())
+                rcv = torch.zeros(r_cnt, dtype=torch.float64)
+                if rank < nbr:
+                    if s_cnt: dist.send(snd, nbr)
+                    if r_cnt: dist.recv(rcv, nbr)
+                else:
+                    if r_cnt: dist.recv(rcv, nbr)
+                    if s_cnt: dist.send(snd, nbr)
+                v[r_off: r_off + r_cnt] = rcv.numpy()
+    # what I send up is what my upper neighbour's lower ghost segment holds, kind by kind (both sides computed it alone)
+    mine = torch.tensor(nb["sendL_cnt"] + nb["sendU_cnt"] + nb["cntL"] + nb["cntU"], dtype=torch.int64)
+    allc = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allc, mine)
+    for r in range(world - 1):
+        lo, up = allc[r].tolist(), allc[r + 1].tolist()
+        assert lo[K:2 * K] == up[2 * K:3 * K], (lo, up)      # sendU of r == cntL of r + 1
+        assert up[0:K] == lo[3 * K:4 * K], (lo, up)          # sendL of r + 1 == cntU of r
+    # a halo of a vector that holds global numbers: every ghost entry receives the number of the unknown it stands for
+    probe = np.zeros(nloc + len(ghost)); probe[:nloc] = own.astype(np.float64) + 1.0
+    halo(probe)
+    assert np.array_equal(probe[nloc:], ghost.astype(np.float64) + 1.0)
 
     def dot(a, c):
         t = torch.tensor([float(a @ c)], dtype=torch.float64); dist.all_reduce(t); return float(t)

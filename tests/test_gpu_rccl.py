@@ -29,9 +29,10 @@ def _run(cmd, env_extra, timeout=600):
 
 
 def _gpu_count() -> int:
-    """In a child process: importing torch INTO a process that has already initialised libpenguin_hip.so brings a second
-    copy of the HIP runtime (torch bundles its own) whose exit handlers then collide with the first one's -- the test
-    process aborts at interpreter exit with `double free or corruption` after all tests have passed."""
+    """In a child process (it only counts devices; torch is not needed in the test process itself).  Round 2 found that
+    importing torch INTO a process that had already loaded libpenguin_hip.so mapped a second copy of the HIP runtime and
+    aborted at exit; the binding now shares one runtime with torch in either order (penguin/jl_amd/_lib.py,
+    tests/test_abi_cpu.py::test_one_hip_runtime_whichever_of_torch_and_the_library_comes_first)."""
     r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True,
                        timeout=300)
     return int(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else 0
