@@ -5,7 +5,7 @@ All arithmetic runs in libpenguin_hip.so (hand-written HIP kernels, C ABI in inc
 There is no CPU fallback: importing works without a GPU (so the ABI can be inspected), any compute
 call without the shared library or a HIP device raises PenguinHipError.
 """
-from ._lib import PenguinHipError, device_name, finalize, get_unique_id, init, init_distributed, lib  # noqa: F401
+from ._lib import PenguinHipError, config_string, device_name, finalize, get_unique_id, init, init_distributed, lib  # noqa: F401
 from .api import (  # noqa: F401
     AdvectionDiffusionSteadyDiph, AdvectionDiffusionSteadyMono, AdvectionDiffusionUnsteadyDiph,
     AdvectionDiffusionUnsteadyMono, ConvectionOps, solve_AdvectionDiffusionUnsteadyDiph_b,

@@ -201,3 +201,10 @@ def device_name() -> str:
     buf = C.create_string_buffer(256)
     check(lib().pg_device_name(buf, 256))
     return buf.value.decode()
+
+
+def config_string() -> str:
+    """Every PG_* tuning / variant selector this process runs with (read once by the library), as `name=value ...`."""
+    buf = C.create_string_buffer(2048)
+    check(lib().pg_config_string(buf, 2048))
+    return buf.value.decode() + f" hip_runtime={hip_runtime_source}"

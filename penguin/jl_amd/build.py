@@ -25,6 +25,18 @@ ARCH = "gfx950"
 EXTRA = {"pg_capacity.hip": ["-ffp-contract=off"]}
 
 
+def source_hash() -> str:
+    """sha256 (first 16 hex digits) over the sources the library is built from: ties a measurement (bench line, rocprofv3
+    trace, PMC pass under profiles/) to the code that produced it -- the GPU box has no git history to ask."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for p in sorted(CSRC.glob("*.hip")) + sorted(CSRC.glob("*.h")) + [HERE.parent.parent / "include" / "penguin_hip.h"]:
+        h.update(p.name.encode())
+        h.update(p.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def _hipcc() -> str:
     for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):

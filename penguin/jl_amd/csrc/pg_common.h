@@ -95,6 +95,7 @@ struct Config {
   int spmv_tile_units = 0;        // PG_SPMV_TILE_UNITS
   int spmv_blocks_per_cu = 0;     // PG_SPMV_BLOCKS_PER_CU (0: 4 slice kernel / 6 CSR kernels)
   bool halo_overlap = true;       // PG_HALO_OVERLAP
+  bool speculate_product = true;  // PG_SPECULATE: pg_solver_run queues the next step's first product behind a solve's first batch
   int unit_order = 0;             // PG_SPMV_UNIT_ORDER: 0 by first row within (strip, plane); 1 units cut at common planes, window-major
                                   // (a block's four waves on four neighbouring lines; measured 59.0 vs 54.6 us per Horner launch: off)
 };

@@ -1,5 +1,7 @@
 // pg_krylov.h -- K11: Krylov solve of the reduced system on one slab (BiCGStab / CG / GMRES).
 #pragma once
+#include <functional>
+
 #include "pg_system.h"
 
 namespace pg {
@@ -36,6 +38,12 @@ struct KrylovWork {
   // GMRES(m) only, allocated on first use (pg_gmres.hip): m+1 basis vectors, H / rotations / g, per-block partial sums
   DevBuf<double> gm_basis, gm, gm_partials;
   int gm_m = -1;
+  // Set by the caller around one krylov_solve: work to queue right AFTER the first batch of iterations and the copy of the
+  // scalars, BEFORE the host waits for that copy -- the next time step's first product, speculatively: the device then
+  // has something to run while the host wakes up, reads the scalars and queues the next step (the wait is on an event
+  // recorded behind the copy, not on the stream).  Called at most once per solve; reset by krylov_solve.
+  std::function<void()> after_first_batch;
+  hipEvent_t ev_poll = nullptr;
   void init(i64 n_own, i64 n_vec);
   ~KrylovWork();
 };
@@ -51,6 +59,7 @@ struct SolveStats {
   int poly_degree = 0;      // products with Â per application of the preconditioned operator (0: plain iteration)
   int half_exit = 0;        // 1: the solve ended at the half step of its last iteration (counted as an iteration)
   int poly_xspace = 0;      // 1: x-space form of the preconditioned loop (Horner chains, no recovery), pg_krylov.hip
+  int polls = 0;            // host waits of the solve (1: it ended inside the first batch of queued launches)
 };
 
 // halo exchange of the ghost segments of `vec` (no-op on one rank)

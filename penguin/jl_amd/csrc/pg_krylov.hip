@@ -33,6 +33,8 @@
 
 using namespace pg;
 
+namespace pg { extern double g_host_wait_us; }
+
 namespace {
 
 
@@ -390,6 +392,8 @@ struct SpmvTimer {
 
 namespace pg {
 
+double g_host_wait_us = 0.0;
+
 void KrylovWork::init(i64 n_own, i64 n_vec) {
   n = n_own;
   nvec = n_vec;
@@ -406,6 +410,7 @@ void KrylovWork::init(i64 n_own, i64 n_vec) {
 
 KrylovWork::~KrylovWork() {
   if (h_sc) (void)hipHostFree(h_sc);
+  if (ev_poll) (void)hipEventDestroy(ev_poll);
 }
 
 void spmv_halo(const CsrMatrix& A, const Numbering& nb, const Slab& slab, double* x, double* y, hipStream_t st) {
@@ -450,6 +455,7 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
     maxiter = 100000;
   }
   // tolerances -> device scalars (a one-thread kernel: a host-to-device copy out of pageable memory stalls the stream)
+  struct HookReset { KrylovWork& w; ~HookReset() { w.after_first_batch = nullptr; } } hook_reset{w};   // (every exit path)
   const bool p_in_rhat = w.p_in_rhat && preinit && opts.method == PG_METHOD_BICGSTAB;
   w.p_in_rhat = false;
   const bool start_folded = w.start_folded && preinit && opts.method == PG_METHOD_BICGSTAB;
@@ -650,7 +656,22 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
     if (!cg && !mid) finalize(PH_BICG_3, 2, w, st, true, 1);   // the last iteration's (r,r), not yet folded into a next one
     PG_HIP(hipGetLastError());
     PG_HIP(hipMemcpyAsync(w.h_sc, w.sc.p, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, st));
-    PG_HIP(hipStreamSynchronize(st));   // (spinning on hipStreamQuery instead: no measurable difference)
+    const auto t_wait0 = std::chrono::steady_clock::now();
+    struct WaitClock {   // PG_DEBUG: where the host's time goes (pg_solver_run prints the totals)
+      std::chrono::steady_clock::time_point t0;
+      ~WaitClock() { g_host_wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); }
+    } wait_clock{t_wait0};
+    if (w.after_first_batch && polls == 1) {
+      // the caller's speculative work goes behind the copy; the host waits for the COPY only
+      if (!w.ev_poll) PG_HIP(hipEventCreateWithFlags(&w.ev_poll, hipEventDisableTiming));
+      PG_HIP(hipEventRecord(w.ev_poll, st));
+      std::function<void()> hook;
+      hook.swap(w.after_first_batch);
+      hook();
+      PG_HIP(hipEventSynchronize(w.ev_poll));
+    } else {
+      PG_HIP(hipStreamSynchronize(st));   // (spinning on hipStreamQuery instead: no measurable difference)
+    }
     if (w.h_sc[S_DONE] != 0.0 || (launched >= maxiter && !mid)) done = true;
     // safety net of the polynomial preconditioner: its roots assume a (nearly) real spectrum inside the Gershgorin
     // interval; a matrix that defeats that assumption shows as stagnation, and the solve falls back to the plain iteration
@@ -732,6 +753,7 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
             w.h_sc[S_DONE], w.h_sc[S_ITERS], w.h_sc[S_RR0], w.h_sc[S_RR], w.h_sc[S_TOL2], w.h_sc[S_RHO], w.h_sc[S_RHO_OLD], w.h_sc[S_ALPHA],
             w.h_sc[S_OMEGA], w.h_sc[S_BETA], w.h_sc[S_RED0], w.h_sc[S_RED1]);
   stats.iters = (int)w.h_sc[S_ITERS];
+  stats.polls = polls;
   w.last_iters = stats.iters;
   stats.converged = w.h_sc[S_DONE] == 1.0 ? 1 : 0;
   stats.half_exit = w.h_sc[S_HALF] != 0.0 ? 1 : 0;

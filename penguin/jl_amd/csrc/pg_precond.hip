@@ -212,12 +212,18 @@ __global__ void k_blk_table(SysParams P, RowSegs seg, i64 Mloc, i64 n_own, const
       blk_fw[q * MAX_KINDS + a] = a < cb.nk ? cb.bfw[me][a] : 0.0;
       // (B⁻¹ M B)[me][a], M = 1 on the rows whose Crank-Nicolson right-hand side subtracts A x (all rows of a
       // monophasic system, the bulk rows of a diphasic one: diffusion.jl:257-258, 409-416)
+      // Monophasic: M = I, so B⁻¹MB is the identity EXACTLY (the computed product B⁻¹·B is only I + O(eps cond B), and that
+      // error would multiply ŷ).  Diphasic: the table is kept for inspection only -- with M != I the product has entries of
+      // the size of cond(B) and b̂ = (B⁻¹S)c - (B⁻¹MB)ŷ cancels catastrophically in cells with a tiny cut volume (3-D 16^3:
+      // right-hand side wrong by 1e-8, T by 6e-7); the diphasic Crank-Nicolson right-hand side of the block rows is
+      // evaluated matrix-free instead (k_rhs_block_mf, pg_solver.hip).
       double cn = 0.0;
-      if (a < cb.nk)
-        for (int j = 0; j < cb.nk; ++j) {
-          const bool sub = P.nphase == 1 || (cb.kinds[j] & 1) == 0;
-          if (sub) cn += cb.binv[me][j] * cb.bfw[j][a];
-        }
+      if (a < cb.nk) {
+        if (P.nphase == 1) cn = a == me ? 1.0 : 0.0;
+        else
+          for (int j = 0; j < cb.nk; ++j)
+            if ((cb.kinds[j] & 1) == 0) cn += cb.binv[me][j] * cb.bfw[j][a];
+      }
       blk_cn[q * MAX_KINDS + a] = cn;
     }
   }

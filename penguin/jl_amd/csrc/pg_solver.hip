@@ -19,6 +19,8 @@
 
 using namespace pg;
 
+namespace pg { extern double g_host_wait_us; }
+
 struct pg_solver {
   int nphase = 1;
   pg_capacity* cap[2] = {nullptr, nullptr};
@@ -66,6 +68,10 @@ struct pg_solver {
   const CsrMatrix* z_matrix = nullptr;   // the matrix whose S the current z refers to
   DevBuf<double> T0pad;       // K*Mloc, ctor initial condition
   KrylovWork work;
+  // ŷ = Â z of the NEXT step, queued speculatively behind the previous solve's first batch (KrylovWork::after_first_batch):
+  // valid when that solve ended inside the batch (nothing moved z afterwards) and the next step runs on the same matrix
+  bool spec_y_valid = false, spec_pending = false, hint_more_steps = false;
+  const CsrMatrix* spec_matrix = nullptr;
   bool initial_done = false;
   std::vector<DevBuf<double>> states;
   i64 steps_done = 0;
@@ -257,6 +263,43 @@ __global__ void k_rhs_block_c(i64 nblk, int scheme, const int* __restrict__ blk_
     double v = c0[q];
 #pragma unroll
     for (int a = 0; a < MAX_KINDS; ++a) v += wz[q * MAX_KINDS + a] * zz[a] - (scheme == PG_SCHEME_CN ? blk_cn[q * MAX_KINDS + a] * yy[a] : 0.0);
+    b[blk_rows[q]] = v;
+  }
+}
+
+// The same rows of a DIPHASIC system under Crank-Nicolson, matrix-free: b̂_r = Σ_a (B⁻¹S)[r,a] (c_a - M_a (A x)_a), with
+// (A x)_a evaluated from the capacities (eval_row, the row the assembler would store, un-preconditioned) and x = S z.
+// The subtraction happens in the row's own scale and B⁻¹ is applied once -- the table form (B⁻¹S)c - (B⁻¹MB)ŷ loses
+// eps·cond(B) of b̂ there (M = diag(1,0,1,0) inside a cell: the product is no identity), 1e-8 in 3-D cut cells.
+// One thread per block row evaluates the (<= 4) rows of its cell: 4x redundant, on a few thousand rows.
+__global__ void k_rhs_block_mf(SysParams P, RowSegs seg, i64 Mloc, i64 nblk, const int* __restrict__ blk_rows,
+                               const int* __restrict__ blk_idx, const double* __restrict__ blk_coef,
+                               const int* __restrict__ row_cell, const int* __restrict__ red, const double* __restrict__ ds,
+                               const double* __restrict__ z, const double* __restrict__ mass, const double* __restrict__ bconst,
+                               const unsigned char* __restrict__ fixed, double* __restrict__ b) {
+  const CapView& c = P.cap[0];
+  for (i64 q = blockIdx.x * (i64)blockDim.x + threadIdx.x; q < nblk; q += (i64)gridDim.x * blockDim.x) {
+    const i64 lc = row_cell[blk_rows[q]];
+    i64 idx[3];
+    decode_cell(c.N, c.ext, c.plane, c.s0, lc, idx);
+    double v = 0.0;
+    for (int a = 0; a < MAX_KINDS; ++a) {
+      const int j = blk_idx[q * MAX_KINDS + a];
+      if (j < 0) continue;
+      const int k = seg_kind(seg, j);
+      double ca;
+      if (fixed[j]) {
+        ca = bconst[j];                                         // jump rows, border rows: b = data
+      } else {
+        double ax = 0.0;                                        // (A x)_j, x = S z
+        eval_row(P, k, lc, idx, [&](int ck, i64 cl, double val) {
+          const int col = red[(i64)ck * Mloc + cl];
+          if (val != 0.0 && col >= 0) ax += val * (ds[col] * z[col]);
+        });
+        ca = 2.0 * (mass[j] * (ds[j] * z[j])) + bconst[j] - ax;  // CN bulk row: (2 V - A) x + data      diffusion.jl:409-412
+      }
+      v += blk_coef[q * MAX_KINDS + a] * ca;
+    }
     b[blk_rows[q]] = v;
   }
 }
@@ -742,6 +785,7 @@ void ensure_run_matrix(pg_solver* s, int scheme) {
     return;
   }
   const SysParams P = make_params(s, scheme);
+  s->spec_y_valid = false;          // (a product queued ahead with the matrix that is about to be replaced)
   s->elim_run = GammaElim();        // (belongs to the matrix that is about to be replaced)
   s->diag_run = DiagElim();
   if (s->blk_cache_matrix == &s->A_run) s->blk_cache_matrix = nullptr;
@@ -818,6 +862,7 @@ void do_initial(pg_solver* s, const pg_krylov_opts* opts, SolveStats& st) {
   s->x_valid = false;
   s->initial_done = true;
   s->diag_ctor.snapped_version = s->diag_run.snapped_version = -1;   // z was replaced behind the compact path's back
+  s->spec_y_valid = false;
 }
 
 void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& st) {
@@ -846,8 +891,16 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
       hipLaunchKernelGGL(k_rescale_state, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, stream, n, s->z_matrix->ds.p, A.ds.p, s->z.p);
       s->z_matrix = &A;
     }
-    spmv_halo(A, s->nb, s->slab, s->z.p, s->y.p, stream);   // ŷ = Â z = B⁻¹S A x: CN right-hand side and warm-start residual
-    if (A.n_blk > 0) {
+    // ŷ = Â z = B⁻¹S A x: CN right-hand side and warm-start residual -- unless the previous step has queued it already
+    const bool have_y = s->spec_y_valid && s->spec_matrix == &A;
+    s->spec_y_valid = false;
+    if (!have_y) spmv_halo(A, s->nb, s->slab, s->z.p, s->y.p, stream);
+    const bool blk_mf = s->nphase == 2 && scheme == PG_SCHEME_CN;   // (see k_rhs_block_mf)
+    if (A.n_blk > 0 && blk_mf) {
+      hipLaunchKernelGGL(k_rhs_block_mf, dim3(grid_for(A.n_blk, BLOCK)), dim3(BLOCK), 0, stream, make_params(s, scheme), make_segs(s->nb),
+                         s->Mloc, A.n_blk, A.blk_rows.p, A.blk_idx.p, A.blk_coef.p, s->nb.row_cell.p, s->nb.red.p, A.ds.p,
+                         (const double*)s->z.p, s->mass.p, s->bconst.p, s->fixed.p, s->b.p);
+    } else if (A.n_blk > 0) {
       if (s->blk_cache_matrix != &A || s->blk_cache_scheme != scheme || s->blk_cache_version != s->bconst_version) {
         if (s->blk_wz.n != A.n_blk * MAX_KINDS) s->blk_wz.alloc(A.n_blk * MAX_KINDS);   // (time-dependent data: rebuilt every step)
         if (s->blk_c0.n != A.n_blk) s->blk_c0.alloc(A.n_blk);
@@ -886,19 +939,32 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
       w.scatter = DE.rlist.p;
       w.p_in_rhat = true;
       bool solved = false;
+      s->spec_pending = false;
+      if (quiet && s->hint_more_steps && config().speculate_product)
+        w.after_first_batch = [s, &A, stream]() {     // the next step's ŷ = Â z, behind this solve's (expected) last update of z
+          spmv_halo(A, s->nb, s->slab, s->z.p, s->y.p, stream);
+          s->spec_pending = true;
+          s->spec_matrix = &A;
+        };
       try {
         krylov_solve(DE.A, DE.nb, s->slab, nullptr, s->z.p, w, o, st, nullptr, nullptr, true);
       } catch (...) {
         w.scatter = nullptr;
+        w.after_first_batch = nullptr;
         throw;
       }
       w.scatter = nullptr;
+      w.after_first_batch = nullptr;
+      // the speculative product stands when the solve ended inside its first batch (nothing has touched z since)
+      s->spec_y_valid = s->spec_pending && st.polls == 1 && st.converged && st.poly_degree >= 0;
+      s->spec_pending = false;
       solved = st.poly_degree >= 0;            // -1: the polynomial stagnated on the compact system -> the full system below
       // A quiet step rests on "no row alone on its diagonal moves while the data are unchanged"; k_rhs_init_c checks it
       // anyway and the start phase reports it (S_MOVED): the residual the iteration started from then lacked the coupling
       // term, and the step is finished on the full system from the state reached.
       const bool moved_unseen = solved && quiet && w.h_sc[S_MOVED] != 0.0;
       if (!solved || moved_unseen) {
+        s->spec_y_valid = false;
         // z has moved (the rows left out hold their solution, the x-space iteration has updated the rest): the right-hand
         // side b̂ of this step -- written for every row by k_rhs_init_c -- stands, the iteration continues on the full
         // system from the state reached, r = b̂ - Âz
@@ -939,7 +1005,11 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
       }
       hipLaunchKernelGGL(k_rhs, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, stream, n, scheme, s->x.p, s->y.p, A.ds.p, s->mass.p,
                          s->bconst.p, s->fixed.p, s->b.p);
-      if (A.n_blk > 0)
+      if (A.n_blk > 0 && s->nphase == 2 && scheme == PG_SCHEME_CN)
+        hipLaunchKernelGGL(k_rhs_block_mf, dim3(grid_for(A.n_blk, BLOCK)), dim3(BLOCK), 0, stream, make_params(s, scheme), make_segs(s->nb),
+                           s->Mloc, A.n_blk, A.blk_rows.p, A.blk_idx.p, A.blk_coef.p, s->nb.row_cell.p, s->nb.red.p, A.ds.p,
+                           (const double*)s->z.p, s->mass.p, s->bconst.p, s->fixed.p, s->b.p);
+      else if (A.n_blk > 0)
         hipLaunchKernelGGL(k_rhs_block, dim3(grid_for(A.n_blk, BLOCK)), dim3(BLOCK), 0, stream, A.n_blk, scheme, A.blk_rows.p,
                            A.blk_idx.p, A.blk_coef.p, A.blk_cn.p, s->x.p, (const double*)nullptr, s->y.p, s->mass.p,
                            s->bconst.p, s->fixed.p, s->b.p);
@@ -1205,6 +1275,8 @@ int32_t pg_solver_run(pg_solver* s, double Tend, int32_t scheme, const pg_krylov
   PG_REQUIRE(scheme == PG_SCHEME_BE || scheme == PG_SCHEME_CN, "scheme must be BE or CN");
   hipStream_t stream = ctx().stream;
   EventPair ev;                     // destroyed on every exit path (do_step may throw)
+  const auto t_run0 = std::chrono::steady_clock::now();
+  const double wait0 = pg::g_host_wait_us;
   PG_HIP(hipEventRecord(ev.e0, stream));
   SolveStats tot;
   i64 steps = 0, iters = 0, unconverged = 0;
@@ -1227,6 +1299,8 @@ int32_t pg_solver_run(pg_solver* s, double Tend, int32_t scheme, const pg_krylov
   while (s->t < Tend) {             // diffusion.jl:286
     if (max_steps >= 0 && steps >= max_steps) break;
     SolveStats st;
+    s->hint_more_steps = (s->t + s->dt < Tend) && (max_steps < 0 || steps + 1 < max_steps);   // (another step follows this one)
+    struct HintReset { pg_solver* s; ~HintReset() { s->hint_more_steps = false; } } hint_reset{s};
     do_step(s, scheme, opts, st);
     account(st);
     ++steps;
@@ -1236,6 +1310,12 @@ int32_t pg_solver_run(pg_solver* s, double Tend, int32_t scheme, const pg_krylov
   PG_HIP(hipEventSynchronize(ev.e1));
   float ms = 0.f;
   PG_HIP(hipEventElapsedTime(&ms, ev.e0, ev.e1));
+  if (config().debug && steps > 0) {
+    const double wall_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_run0).count();
+    fprintf(stderr, "[pg_solver_run] %lld steps: wall %.1f us per step, of which the host waited %.1f us for the device (the rest: queueing "
+            "launches and bookkeeping); device time by events %.1f us per step\n", (long long)steps, wall_us / steps,
+            (pg::g_host_wait_us - wait0) / steps, ms * 1e3 / steps);
+  }
   if (info) {
     info->steps = steps;
     info->total_iters = iters;
@@ -1443,6 +1523,7 @@ int32_t pg_debug_scale_diagonal_rows(pg_solver* s, double factor) {
   PG_HIP(hipGetLastError());
   PG_HIP(hipStreamSynchronize(ctx().stream));
   s->x_valid = false;
+  s->spec_y_valid = false;
   PG_API_END
 }
 

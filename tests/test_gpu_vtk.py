@@ -67,8 +67,11 @@ def test_diphasic_3d_states_through_write_vtk(pj, tmp_path):
     dt = 0.5 * (Lx / n) ** 2
     s = pj.DiffusionUnsteadyDiph(p1, p2, bcb, ic, dt, u0, "BE")
     so = po.DiffusionUnsteadyDiph(q1, q2, obcb, oic, dt, u0, "BE")
-    pj.solve_DiffusionUnsteadyDiph_b(s, p1, p2, dt, 3 * dt, bcb, ic, "CN", reltol=1e-13)
-    po.solve_DiffusionUnsteadyDiph(so, q1, q2, dt, 3 * dt, obcb, oic, "CN", method="\\")
+    # (backward Euler: under Crank-Nicolson this 3-D problem amplifies a 1e-11 difference between two previous states a
+    #  thousandfold in one step -- tests/test_gpu_parity.py::test_diphasic_cn_3d_step_by_step -- and free-running
+    #  trajectories cannot be compared to 1e-9)
+    pj.solve_DiffusionUnsteadyDiph_b(s, p1, p2, dt, 3 * dt, bcb, ic, "BE", reltol=1e-13)
+    po.solve_DiffusionUnsteadyDiph(so, q1, q2, dt, 3 * dt, obcb, oic, "BE", method="\\")
     pvd = write_vtk(str(tmp_path / "two_phase"), mesh, s)
     files = _collection(pvd)
     assert len(files) == len(so.states) >= 3
@@ -94,8 +97,8 @@ def test_steady_poisson_through_write_vtk(pj, tmp_path):
     f = lambda x, y, z, t=0.0: 4.0
     D = lambda x, y, z: 1.0
     ph, oph = pj.Phase(cap, pj.DiffusionOps(cap), f, D), po.Phase(ocap, po.make_diffusion_ops(ocap), f, D)
-    s = pj.DiffusionSteadyMono(ph, pj.BorderConditions({}), pj.Dirichlet(0.0))
-    so = po.DiffusionSteadyMono(oph, po.BorderConditions({}), po.Dirichlet(0.0))
+    s = pj.DiffusionSteadyMono(ph, pj.BorderConditions({}), pj.Dirichlet(0.5))      # (a non-zero Tγ field to compare)
+    so = po.DiffusionSteadyMono(oph, po.BorderConditions({}), po.Dirichlet(0.5))
     pj.solve_DiffusionSteadyMono_b(s, reltol=1e-13)
     po.solve_DiffusionSteadyMono(so, method="\\")
     path = write_vtk(str(tmp_path / "poisson"), mesh, s)
