@@ -249,6 +249,15 @@ int32_t pg_solver_create_unsteady_diph(pg_capacity* c1, pg_diffops* o1, pg_capac
 /* DiffusionSteadyMono(phase, bc_b, bc_i), diffusion.jl:14-28 (A_mono_stead_diff :30-43, b_mono_stead_diff :45-58):
    the same blocks without V and Δt; source = f(C_ω) (no time).  solve_DiffusionSteadyMono! (:60-71) =
    pg_solver_initial_solve; pg_solver_step / _run refuse a steady solver. */
+/* MovingDiffusionUnsteadyDiph + A_/b_diph_unstead_diff_moving (prescribedmotionsolver/diffusion.jl:272-498): ONE space-time
+   slab of the two-phase moving problem.  c1 / c2: space-time capacities of the body and of its complement on the same slab
+   (pg_capacity_create_spacetime); T_prev: the previous state [Tω¹; Tγ¹; Tω²; Tγ²] (4M, host) or NULL with `previous` = the
+   previous slab's solver (state handed over on the device); f*_n / f*_np1: sources at t and t + Δt evaluated at the
+   space-time centroids (NULL = 0).  Solve with pg_solver_initial_solve; the next slab is a new solver. */
+int32_t pg_solver_create_moving_diph(pg_capacity* c1, pg_diffops* o1, pg_capacity* c2, pg_diffops* o2, const pg_jump_desc* ic,
+                                     const pg_border_desc* borders, int32_t nborders, const double* D1, const double* D2,
+                                     const double* f1_n, const double* f1_np1, const double* f2_n, const double* f2_np1,
+                                     const double* T_prev, pg_solver* previous, int32_t scheme, pg_solver** out);
 int32_t pg_solver_create_steady_mono(pg_capacity* c, pg_diffops* o, const pg_bc_desc* bc_interface,
                                      const pg_border_desc* borders, int32_t nborders, const double* Dcoef,
                                      const double* source, pg_solver** out);

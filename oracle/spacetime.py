@@ -7,6 +7,10 @@
   b_mono_unstead_diff_moving                  .../diffusion.jl:163-225
   MovingDiffusionUnsteadyMono                 .../diffusion.jl:16-35
   solve_MovingDiffusionUnsteadyMono!          .../diffusion.jl:227-268
+  MovingDiffusionUnsteadyDiph                 .../diffusion.jl:272-290
+  A_diph_unstead_diff_moving                  .../diffusion.jl:292-398
+  b_diph_unstead_diff_moving                  .../diffusion.jl:400-498
+  solve_MovingDiffusionUnsteadyDiph!          .../diffusion.jl:501-535
 
 Parity unpinned for the capacities: the reference gets them from libvofi on the (N+1)-D cells (absent here, SURVEY 8c);
 `make_spacetime_capacity` restates their DEFINITION (time integrals of the spatial measures of `oracle/geometry.py`) with
@@ -299,6 +303,126 @@ def solve_MovingDiffusionUnsteadyMono(s: po.Solver, phase: po.Phase, body, dt: f
         s.A = A_mono_unstead_diff_moving(op, cap, phase.Diffusion_coeff, bc, scheme)
         s.b = b_mono_unstead_diff_moving(op, cap, phase.Diffusion_coeff, phase.source, bc, Ti, dt, t, scheme)
         s.A, s.b = po.BC_border_mono(s.A, s.b, bc_b, mesh, t=t)   # :258
+        po.solve_system(s, method=method, **kwargs)
+        s.states.append(s.x)
+        Ti = s.x
+        steps += 1
+    return s
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# two phases                                                                             diffusion.jl:272-535
+# ---------------------------------------------------------------------------------------------------------------
+def _time_faces(op: po.DiffusionOps, cap: po.Capacity):
+    At = cap.A[len(op.size) - 1]                                   # capacite.A[cap_index] (:337-340)
+    return At[: len(At) // 2], At[len(At) // 2:]                   # Vn_1, Vn
+
+
+def A_diph_unstead_diff_moving(op1, op2, cap1, cap2, D1, D2, ic: po.InterfaceConditions, scheme: str) -> sp.csr_matrix:
+    """diffusion.jl:292-398."""
+    jump, flux = ic.scalar, ic.flux
+    Vn1_1, Vn1 = _time_faces(op1, cap1)
+    Vn2_1, Vn2 = _time_faces(op2, cap2)
+    psip = psip_cn if scheme == "CN" else psip_be
+    Psi1 = sp.diags(np.array([psip(a, b) for a, b in zip(Vn1, Vn1_1)]))     # :350
+    Psi2 = sp.diags(np.array([psip(a, b) for a, b in zip(Vn2, Vn2_1)]))
+    n = len(Vn1)
+    Ia1, Ia2 = jump.alpha1 * sp.identity(n), jump.alpha2 * sp.identity(n)
+    Ib1, Ib2 = flux.beta1, flux.beta2
+    W1, G1, H1 = _half(op1.Winv), _half(op1.G), _half(op1.H)                 # :358-364
+    W2, G2, H2 = _half(op2.Winv), _half(op2.G), _half(op2.H)
+    Id1, Id2 = _half(sp.diags(po.build_I_D(op1, D1, cap1))), _half(sp.diags(po.build_I_D(op2, D2, cap2)))
+    G1T, H1T, G2T, H2T = G1.T.tocsr(), H1.T.tocsr(), G2.T.tocsr(), H2.T.tocsr()
+    dV1, dV2 = sp.diags(Vn1_1) - sp.diags(Vn1), sp.diags(Vn2_1) - sp.diags(Vn2)
+    block1 = sp.diags(Vn1_1) + Id1 @ G1T @ W1 @ G1 @ Psi1                    # :374
+    block2 = -dV1 + Id1 @ G1T @ W1 @ H1 @ Psi1
+    block3 = sp.diags(Vn2_1) + Id2 @ G2T @ W2 @ G2 @ Psi2
+    block4 = -dV2 + Id2 @ G2T @ W2 @ H2 @ Psi2
+    block5 = Ib1 * (H1T @ W1 @ G1 @ Psi1)                                    # :379
+    block6 = Ib1 * (H1T @ W1 @ H1 @ Psi1) - dV1
+    block7 = Ib2 * (H2T @ W2 @ G2 @ Psi2)
+    block8 = Ib2 * (H2T @ W2 @ H2 @ Psi2) - dV2
+    Z = sp.csr_matrix((n, n))
+    return sp.bmat([[block1, block2, Z, Z], [Z, Ia1, Z, -Ia2], [Z, Z, block3, block4], [block5, block6, block7, block8]], format="csr")
+
+
+def b_diph_unstead_diff_moving(op1, op2, cap1, cap2, D1, D2, f1, f2, ic: po.InterfaceConditions, Ti, dt, t, scheme) -> np.ndarray:
+    """diffusion.jl:400-498."""
+    jump, flux = ic.scalar, ic.flux
+    f1n, f1n1 = po.build_source(op1, f1, t, cap1), po.build_source(op1, f1, t + dt, cap1)     # :415-418
+    f2n, f2n1 = po.build_source(op2, f2, t, cap2), po.build_source(op2, f2, t + dt, cap2)
+    gg = po.build_g_g(op1, jump, cap1)                                                          # :423-424 (no time argument)
+    hh = po.build_g_g(op2, flux, cap2)
+    Vn1_1, Vn1 = _time_faces(op1, cap1)
+    Vn2_1, Vn2 = _time_faces(op2, cap2)
+    psim = psim_cn if scheme == "CN" else psim_be
+    Psi1 = sp.diags(np.array([psim(a, b) for a, b in zip(Vn1, Vn1_1)]))                         # :439-440
+    Psi2 = sp.diags(np.array([psim(a, b) for a, b in zip(Vn2, Vn2_1)]))
+    q = len(Ti) // 4
+    To1, Tg1, To2, Tg2 = Ti[:q], Ti[q:2 * q], Ti[2 * q:3 * q], Ti[3 * q:]                       # :459-463
+    f1n, f1n1, f2n, f2n1 = _half(f1n), _half(f1n1), _half(f2n), _half(f2n1)
+    gg, hh = _half(gg), _half(hh)
+    Ig2 = _half(sp.diags(cap2.G))
+    Id1, Id2 = _half(sp.diags(po.build_I_D(op1, D1, cap1))), _half(sp.diags(po.build_I_D(op2, D2, cap2)))
+    W1, G1, H1, V1 = _half(op1.Winv), _half(op1.G), _half(op1.H), _half(op1.V)
+    W2, G2, H2, V2 = _half(op2.Winv), _half(op2.G), _half(op2.H), _half(op2.V)
+    G1T, G2T = G1.T.tocsr(), G2.T.tocsr()
+    if scheme == "CN":                                                                          # :487-488
+        b1 = (sp.diags(Vn1) - Id1 @ G1T @ W1 @ G1 @ Psi1) @ To1 - Id1 @ G1T @ W1 @ H1 @ Psi1 @ Tg1 + 0.5 * (V1 @ (f1n + f1n1))
+        b3 = (sp.diags(Vn2) - Id2 @ G2T @ W2 @ G2 @ Psi2) @ To2 - Id2 @ G2T @ W2 @ H2 @ Psi2 @ Tg2 + 0.5 * (V2 @ (f2n + f2n1))
+    else:                                                                                       # :490-491
+        b1 = (sp.diags(Vn1) - Id1 @ G1T @ W1 @ G1 @ Psi1) @ To1 - Id1 @ G1T @ W1 @ H1 @ Psi1 @ Tg1 + V1 @ f1n1
+        b3 = (sp.diags(Vn2) - Id2 @ G2T @ W2 @ G2 @ Psi2) @ To2 - Id2 @ G2T @ W2 @ H2 @ Psi2 @ Tg2 + V2 @ f2n1
+    b2 = gg                                                                                     # :495
+    b4 = Ig2 @ hh                                                                               # :496
+    return np.concatenate([b1, b2, b3, b4])
+
+
+def _border_diph(A, b, bc_b, cap1, cap2, mesh: po.Mesh, t):
+    """BC_border_diph!(s.A, s.b, bc_b, mesh) (:288, :523): the method WITHOUT capacities (src/solver.jl:540-543), so both
+    phases get their border rows whatever the cell types say (the static drivers call the capacity-aware method)."""
+    ps = A.shape[0] // 4
+    return po._apply_border(A, b, bc_b, mesh, t, offsets=(0, 2 * ps), skip=None)
+
+
+def MovingDiffusionUnsteadyDiph(phase1: po.Phase, phase2: po.Phase, bc_b, ic, dt: float, Ti: np.ndarray, mesh: po.Mesh,
+                                scheme: str) -> po.Solver:
+    """diffusion.jl:272-290 (t = 0.0 in b)."""
+    s = po.Solver("Unsteady", "Diphasic", "Diffusion")
+    sch = "CN" if scheme == "CN" else "BE"
+    s.A = A_diph_unstead_diff_moving(phase1.operator, phase2.operator, phase1.capacity, phase2.capacity, phase1.Diffusion_coeff,
+                                     phase2.Diffusion_coeff, ic, sch)
+    s.b = b_diph_unstead_diff_moving(phase1.operator, phase2.operator, phase1.capacity, phase2.capacity, phase1.Diffusion_coeff,
+                                     phase2.Diffusion_coeff, phase1.source, phase2.source, ic, Ti, dt, 0.0, sch)
+    s.A, s.b = _border_diph(s.A, s.b, bc_b, phase1.capacity, phase2.capacity, mesh, None)
+    return s
+
+
+def solve_MovingDiffusionUnsteadyDiph(s: po.Solver, phase1: po.Phase, phase2: po.Phase, body, body_c, dt: float, Te: float, bc_b, ic,
+                                      mesh: po.Mesh, scheme: str, method: str = "\\", capacity_fn: Optional[Callable] = None,
+                                      max_steps: Optional[int] = None, **kwargs):
+    """diffusion.jl:501-535 (the loop starts at t = 0.0, :513).  `capacity_fn(t0, t1)` -> (capacity1, capacity2) replaces the
+    two `Capacity(body, STmesh)` calls (default: make_spacetime_capacity of body and body_c)."""
+    if s.A is None:
+        raise RuntimeError("Solver is not initialized. Call a solver constructor first.")
+    t = 0.0
+    po.solve_system(s, method=method, **kwargs)
+    s.states.append(s.x)
+    Ti = s.x
+    steps = 0
+    while t < Te:
+        if max_steps is not None and steps >= max_steps:
+            break
+        t += dt
+        if capacity_fn:
+            cap1, cap2 = capacity_fn(t, t + dt)
+        else:
+            cap1, cap2 = make_spacetime_capacity(body, mesh, t, t + dt), make_spacetime_capacity(body_c, mesh, t, t + dt)
+        op1, op2 = po.make_diffusion_ops(cap1), po.make_diffusion_ops(cap2)
+        s.A = A_diph_unstead_diff_moving(op1, op2, cap1, cap2, phase1.Diffusion_coeff, phase2.Diffusion_coeff, ic, scheme)
+        s.b = b_diph_unstead_diff_moving(op1, op2, cap1, cap2, phase1.Diffusion_coeff, phase2.Diffusion_coeff, phase1.source,
+                                         phase2.source, ic, Ti, dt, t, scheme)
+        s.A, s.b = _border_diph(s.A, s.b, bc_b, cap1, cap2, mesh, None)
         po.solve_system(s, method=method, **kwargs)
         s.states.append(s.x)
         Ti = s.x

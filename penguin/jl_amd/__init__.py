@@ -23,6 +23,6 @@ from .utils import (  # noqa: F401,E402
 )
 from .vtk import write_vtk  # noqa: F401,E402
 from .moving import (  # noqa: F401,E402
-    MovingCircle, MovingDiffusionUnsteadyMono, MovingHalfSpace, MovingSphere, SpaceTimeCapacity, SpaceTimeMesh,
-    solve_MovingDiffusionUnsteadyMono_b,
+    MovingCircle, MovingDiffusionUnsteadyDiph, MovingDiffusionUnsteadyMono, MovingHalfSpace, MovingSphere, SpaceTimeCapacity,
+    SpaceTimeMesh, solve_MovingDiffusionUnsteadyDiph_b, solve_MovingDiffusionUnsteadyMono_b,
 )

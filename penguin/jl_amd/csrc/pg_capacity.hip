@@ -508,13 +508,27 @@ __global__ void k_st_sections_cut(GeoView g, MotionView mv, const int* __restric
     hi[k] = g.nodes[k][ik + 1];
   }
   double a = 0.0, b = 0.0;
+  const double fm = full_measure(g, d);
+  bool a_full = true, b_full = real;
   for (int k = lane; k < mv.nq; k += 64) {
     const double wq = mv.q[k].w;
-    a += wq * section_measure(mv.bodies[k], d, g.nodes[d][idx[d]], lo, hi, full_measure(g, d));
-    if (real) b += wq * section_measure(mv.bodies[k], d, Cw[d][lc], lo, hi, full_measure(g, d));
+    const double sa = section_measure(mv.bodies[k], d, g.nodes[d][idx[d]], lo, hi, fm);
+    a += wq * sa;
+    a_full = a_full && sa == fm;
+    if (real) {
+      const double sb = section_measure(mv.bodies[k], d, Cw[d][lc], lo, hi, fm);
+      b += wq * sb;
+      b_full = b_full && sb == fm;
+    }
   }
   a = wave_add(a);
   b = wave_add(b);
+  // a section that is full at every time node gets the measure the full cells get, full x Δt, and not the quadrature sum
+  // Σ w_k full, which differs from it in the last bits: A_d - B_d between such a face and a full neighbour is then an EXACT
+  // zero (as in the static kernels) instead of 1e-17 -- a residue that switches the γ unknowns of full cells on with
+  // 1e-34 diagonals and makes their cell blocks singular (the moving two-phase systems met it)
+  if (__all(a_full)) a = fm * (mv.t1 - mv.t0);
+  if (__all(b_full)) b = fm * (mv.t1 - mv.t0);
   if (lane == 0) { A[d][lc] = a; B[d][lc] = b; }
 }
 

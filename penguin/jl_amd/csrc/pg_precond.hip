@@ -296,12 +296,17 @@ __global__ void k_point_scale(SysParams P, int K, i64 Mloc, const int* red, doub
     const i64 lc = q % Mloc;
     i64 idx[3];
     decode_cell(c.N, c.ext, c.plane, c.s0, lc, idx);
-    double diag = 0.0;
+    double diag = 0.0, rowmax = 0.0;
     eval_row(P, k, lc, idx, [&](int ck, i64 cl, double v) {
       if (ck == k && cl == lc) diag = v;
+      rowmax = fmax(rowmax, fabs(v));
     });
+    // A diagonal that is zero -- or zero but for rounding: 1e-33 where time-integrated face capacities of a full cell cancel
+    // to 1e-17 instead of exactly (space-time slabs) -- gives no scale: such rows (flux rows of cells one phase is absent
+    // from, coupled through the jump row) keep S = 1 and are handled by the cell block.  |a_ii|^-1/2 = 2e16 there made the
+    // preconditioned system numerically singular.
     const double a = fabs(diag);
-    ds[r] = (a > 0.0 && a < 1e300) ? 1.0 / sqrt(a) : 1.0;
+    ds[r] = (a > 1e-13 * rowmax && a < 1e300) ? 1.0 / sqrt(a) : 1.0;
   }
 }
 

@@ -79,7 +79,7 @@ struct pg_solver {
   DevBuf<i64> border_cells_lin;  // global linear index of each border cell (mesh order), lazily uploaded
   // moving body (pg_solver_create_moving_mono): one space-time step; Ψn1 = psip.(Vn, Vn_1), Ψn = psim.(Vn, Vn_1)
   bool moving = false;
-  DevBuf<double> psi_p, psi_m;
+  DevBuf<double> psi_p[2], psi_m[2];   // per phase
   pg_solver* init_from = nullptr;   // constructor only: the previous slab's solver whose state is this one's initial state
 };
 
@@ -128,7 +128,7 @@ __global__ void k_row_static(SysParams P, RowSegs seg, i64 n_own, const int* row
         fx = 1;
         bv = (bk == PG_BC_PERIODIC) ? 0.0 : kv.v[key];
       } else {
-        m = P.mv_psi_w ? P.mv_v1[lc] : P.mass * P.cap[ph].V[lc];   // moving: b1 = Vn Tω + ...  (diffusion.jl:214,216)
+        m = P.mv_psi_w[0] ? P.mv_v1[ph][lc] : P.mass * P.cap[ph].V[lc];   // moving: b1 = Vn Tω + ...  (diffusion.jl:214,216)
       }
     } else if (P.nphase == 2) {
       fx = 1;   // jump rows: b2 = g, b4 = Γ₂h for both schemes (diffusion.jl:415-416)
@@ -601,14 +601,18 @@ SysParams make_params(const pg_solver* s, int scheme) {
   }
   for (int k = 0; k < 6; ++k) P.border_kind[k] = s->border_kind[k];
   P.inv_dx = s->inv_dx;
+  P.border_both_phases = (s->moving && s->nphase == 2) ? 1 : 0;
   if (s->moving) {            // Δt lives inside the space-time capacities
     P.theta = 1.0;
     P.gscale = 1.0;
     P.mass = 1.0;
-    P.mv_v0 = s->cap[0]->Vt[0].p;
-    P.mv_v1 = s->cap[0]->Vt[1].p;
-    P.mv_psi_w = s->psi_p.p;
-    P.mv_psi_g = s->psi_p.p;
+    for (int q = 0; q < s->nphase; ++q) {
+      P.mv_v0[q] = s->cap[q]->Vt[0].p;
+      P.mv_v1[q] = s->cap[q]->Vt[1].p;
+      P.mv_psi_w[q] = s->psi_p[q].p;
+      P.mv_psi_g[q] = s->psi_p[q].p;
+    }
+    if (s->nphase == 1) { P.mv_v0[1] = P.mv_v0[0]; P.mv_v1[1] = P.mv_v1[0]; P.mv_psi_w[1] = P.mv_psi_w[0]; P.mv_psi_g[1] = P.mv_psi_g[0]; }
   }
   return P;
 }
@@ -616,8 +620,12 @@ SysParams make_params(const pg_solver* s, int scheme) {
 // the explicit operator of the moving Crank-Nicolson right-hand side (diffusion.jl:214)
 SysParams make_params_moving_explicit(const pg_solver* s) {
   SysParams P = make_params(s, PG_SCHEME_CN);
-  P.mv_psi_w = s->psi_m.p;
-  P.mv_psi_g = nullptr;
+  for (int q = 0; q < 2; ++q) {
+    const int src = q < s->nphase ? q : 0;
+    P.mv_psi_w[q] = s->psi_m[src].p;
+    // mono (:214): the γ term is -½ Id GᵀWꜝH Tγ; diph (:487-488): -Id GᵀWꜝH Ψn Tγ with the same Ψn = psim as the ω term
+    P.mv_psi_g[q] = s->nphase == 2 ? s->psi_m[src].p : nullptr;
+  }
   P.mv_gconst = 0.5;
   P.mv_explicit = 1;
   return P;
@@ -1110,10 +1118,10 @@ static int32_t create_moving(pg_capacity* c, pg_diffops* o, const pg_bc_desc* bc
   s->scheme_ctor = scheme;
   s->bc_i = *bc_interface;
   const i64 Ml = s->slab.Mloc();
-  s->psi_p.alloc(Ml);
-  s->psi_m.alloc(Ml);
+  s->psi_p[0].alloc(Ml);
+  s->psi_m[0].alloc(Ml);
   hipLaunchKernelGGL(k_psi, dim3(grid_for(Ml, BLOCK)), dim3(BLOCK), 0, ctx().stream, Ml, (int)scheme, c->Vt[0].p, c->Vt[1].p,
-                     s->psi_p.p, s->psi_m.p);
+                     s->psi_p[0].p, s->psi_m[0].p);
   PG_HIP(hipGetLastError());
   if (Dcoef) upload_local(s->Id[0], Dcoef, s->slab);
   if (source_np1) upload_local(s->f_np1[0], source_np1, s->slab);
@@ -1124,6 +1132,56 @@ static int32_t create_moving(pg_capacity* c, pg_diffops* o, const pg_bc_desc* bc
   }
   s->bc_i.value_array = nullptr;
   s->init_from = prev;
+  s->A_ctor.want_units = false;
+  setup_common(s, borders, nborders, T_prev);
+  *out = guard.release();
+  PG_API_END
+}
+
+// MovingDiffusionUnsteadyDiph + A_/b_diph_unstead_diff_moving of one slab      prescribedmotionsolver/diffusion.jl:272-498
+int32_t pg_solver_create_moving_diph(pg_capacity* c1, pg_diffops* o1, pg_capacity* c2, pg_diffops* o2, const pg_jump_desc* ic,
+                                     const pg_border_desc* borders, int32_t nborders, const double* D1, const double* D2,
+                                     const double* f1_n, const double* f1_np1, const double* f2_n, const double* f2_np1,
+                                     const double* T_prev, pg_solver* previous, int32_t scheme, pg_solver** out) {
+  PG_API_BEGIN
+  require_init();
+  if (previous) PG_REQUIRE(previous->initial_done, "pg_solver_create_moving_diph: the previous slab has not been solved");
+  AsyncAllocScope pool;   // one solver per time slab: freed blocks are reused without synchronisation (pg_context.hip)
+  PG_REQUIRE(scheme == PG_SCHEME_BE || scheme == PG_SCHEME_CN, "scheme must be BE or CN");
+  PG_REQUIRE(c1 && c2 && o1 && o2 && ic && out, "solver constructor: NULL argument");
+  PG_REQUIRE(o1->cap == c1 && o2->cap == c2, "operators were built from a different capacity");
+  PG_REQUIRE(c1->spacetime && c2->spacetime, "pg_solver_create_moving_diph needs space-time capacities (pg_capacity_create_spacetime)");
+  PG_REQUIRE(c1->mesh == c2->mesh, "Phase capacities must share the same mesh.");
+  PG_REQUIRE(!o1->has_velocity && !o2->has_velocity, "the moving diffusion solver takes no convection operators");
+  PG_REQUIRE(ctx().nranks == 1 && !ctx().comm, "space-time steps are single-rank");
+  auto* s = new pg_solver();
+  std::unique_ptr<pg_solver> guard(s);
+  s->nphase = 2;
+  s->cap[0] = c1; s->ops[0] = o1;
+  s->cap[1] = c2; s->ops[1] = o2;
+  s->slab = c1->slab;
+  s->dt = 1.0;            // Δt is inside the space-time capacities
+  s->moving = true;
+  s->scheme_ctor = scheme;
+  s->ic = *ic;
+  const i64 Ml = s->slab.Mloc();
+  for (int q = 0; q < 2; ++q) {
+    s->psi_p[q].alloc(Ml);
+    s->psi_m[q].alloc(Ml);
+    hipLaunchKernelGGL(k_psi, dim3(grid_for(Ml, BLOCK)), dim3(BLOCK), 0, ctx().stream, Ml, (int)scheme, s->cap[q]->Vt[0].p,
+                       s->cap[q]->Vt[1].p, s->psi_p[q].p, s->psi_m[q].p);
+  }
+  PG_HIP(hipGetLastError());
+  if (D1) upload_local(s->Id[0], D1, s->slab);
+  if (D2) upload_local(s->Id[1], D2, s->slab);
+  if (f1_np1) upload_local(s->f_np1[0], f1_np1, s->slab);
+  if (f2_np1) upload_local(s->f_np1[1], f2_np1, s->slab);
+  if (f1_n) upload_local(s->f_n[0], f1_n, s->slab);
+  if (f2_n) upload_local(s->f_n[1], f2_n, s->slab);
+  if (ic->g_array) upload_local(s->g_arr, ic->g_array, s->slab);
+  if (ic->h_array) upload_local(s->h_arr, ic->h_array, s->slab);
+  s->ic.g_array = s->ic.h_array = nullptr;
+  s->init_from = previous;
   s->A_ctor.want_units = false;
   setup_common(s, borders, nborders, T_prev);
   *out = guard.release();

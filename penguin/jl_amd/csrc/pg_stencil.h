@@ -29,15 +29,19 @@ struct SysParams {
   const double* conv_k[2];      // diagonal of 0.5 * sum(K): added to the ω-ω and ω-γ diagonals of bulk rows
   double mass;           // coefficient of V in the bulk rows: 1 (unsteady), 0 (steady: A_mono_stead_diff, diffusion.jl:30-43)
   int border_kind[6];    // per PG_KEY_*
+  int border_both_phases; // diph: 1 = border rows in both phases whatever the cell type (moving driver), 0 = skipped where the phase is absent
   double inv_dx;         // 1/Δx for the 1-D Neumann border row
   // moving body, mono (prescribedmotionsolver/diffusion.jl:100-160): cap[0] holds SPACE-TIME capacities (Δt is inside
   // them: theta = gscale = 1) and the bulk rows become
   //   [ Vn_1 + Id GᵀWꜝG Ψ ,  -(Vn_1 - Vn) + Id GᵀWꜝH Ψ ]      Ψ = diag(psip.(Vn, Vn_1)) scales COLUMNS
-  // mv_psi_w == nullptr: static problem (everything below unused)
-  const double* mv_v0;     // "Vn_1" = A_t at the lower time face, V(t_n)
-  const double* mv_v1;     // "Vn"   = A_t at the upper time face, V(t_n + Δt)
-  const double* mv_psi_w;  // per cell: scaling of the ω columns
-  const double* mv_psi_g;  // per cell: scaling of the γ columns; nullptr: the constant mv_gconst
+  // moving body, diph (prescribedmotionsolver/diffusion.jl:292-398): the same per phase, and the FLUX row carries the
+  // column scaling and the swept-volume term too:
+  //   [ β₁ H₁ᵀWꜝG₁Ψ₁ , β₁ H₁ᵀWꜝH₁Ψ₁ - (Vn1_1 - Vn1) , β₂ H₂ᵀWꜝG₂Ψ₂ , β₂ H₂ᵀWꜝH₂Ψ₂ - (Vn2_1 - Vn2) ]      (:378-381)
+  // mv_psi_w[0] == nullptr: static problem (everything below unused); index = phase
+  const double* mv_v0[2];     // "Vn_1" = A_t at the lower time face, V(t_n)
+  const double* mv_v1[2];     // "Vn"   = A_t at the upper time face, V(t_n + Δt)
+  const double* mv_psi_w[2];  // per cell: scaling of the ω columns
+  const double* mv_psi_g[2];  // per cell: scaling of the γ columns; nullptr: the constant mv_gconst
   double mv_gconst;
   int mv_explicit;         // 1: the explicit Crank-Nicolson operator [Id GᵀWꜝG Ψn, ½ Id GᵀWꜝH] of :214 -- bulk rows only, no
                            // volume terms; interface rows are empty (b2 = Γ g carries no T term there)
@@ -94,7 +98,10 @@ __device__ inline int border_row_kind(const SysParams& P, int ph, i64 lc, const 
   if (key < 0) return PG_BC_NONE;
   const int kind = P.border_kind[key];
   if (kind == PG_BC_NONE) return PG_BC_NONE;
-  if (P.nphase == 2 && P.ct[ph][lc] == 0.0) return PG_BC_NONE;  // solver.jl:574-575
+  // solver.jl:574-575 -- the capacity-aware method the static drivers call; the moving diphasic driver calls
+  // BC_border_diph!(A, b, bc_b, mesh) (prescribedmotionsolver/diffusion.jl:288,523), the method WITHOUT capacities
+  // (solver.jl:540-543): both phases get their border rows wherever the mesh has a border cell
+  if (P.nphase == 2 && !P.border_both_phases && P.ct[ph][lc] == 0.0) return PG_BC_NONE;
   if (kind == PG_BC_PERIODIC) {
     // needs the opposite key present (solver.jl:461) and is 2-D only (:512-519)
     const int opp = key ^ 1;
@@ -112,7 +119,7 @@ __device__ inline void eval_row(const SysParams& P, int kind, i64 lc, const i64*
   const bool bulk = (kind & 1) == 0;  // ω row / γ row
   const CapView& c0 = P.cap[0];
   const int N = c0.N;
-  const bool mv = P.mv_psi_w != nullptr;
+  const bool mv = P.mv_psi_w[0] != nullptr;
   if (mv && P.mv_explicit && !bulk) return;
 
   if (bulk) {
@@ -182,12 +189,12 @@ __device__ inline void eval_row(const SysParams& P, int kind, i64 lc, const i64*
           }
           if (mv) {       // column scaling Ψ (no convection in the moving solver)
             if (L.has_p) {
-              emit(kw, lc + st, scale * (L.gl_p * L.w_p * L.gd_p) * P.mv_psi_w[lc + st]);
-              emit(kg, lc + st, scale * (L.gl_p * L.w_p * L.hd_p) * (P.mv_psi_g ? P.mv_psi_g[lc + st] : P.mv_gconst));
+              emit(kw, lc + st, scale * (L.gl_p * L.w_p * L.gd_p) * P.mv_psi_w[q][lc + st]);
+              emit(kg, lc + st, scale * (L.gl_p * L.w_p * L.hd_p) * (P.mv_psi_g[q] ? P.mv_psi_g[q][lc + st] : P.mv_gconst));
             }
             if (L.has_m) {
-              emit(kw, lc - st, scale * (L.gd_j * L.w_j * L.gl_j) * P.mv_psi_w[lc - st]);
-              emit(kg, lc - st, scale * (L.gd_j * L.w_j * L.hl_j) * (P.mv_psi_g ? P.mv_psi_g[lc - st] : P.mv_gconst));
+              emit(kw, lc - st, scale * (L.gd_j * L.w_j * L.gl_j) * P.mv_psi_w[q][lc - st]);
+              emit(kg, lc - st, scale * (L.gd_j * L.w_j * L.hl_j) * (P.mv_psi_g[q] ? P.mv_psi_g[q][lc - st] : P.mv_gconst));
             }
             continue;
           }
@@ -203,6 +210,18 @@ __device__ inline void eval_row(const SysParams& P, int kind, i64 lc, const i64*
           // HᵀWꜝG and HᵀWꜝH rows
           dW += L.hd_j * L.w_j * L.gd_j + L.hl_p * L.w_p * L.gl_p;
           dG += L.hd_j * L.hd_j * L.w_j + L.hl_p * L.hl_p * L.w_p;
+          if (mv && P.nphase == 2) {      // moving flux row: columns scaled by Ψ_q (:378-381)
+            const double* pw = P.mv_psi_w[q];
+            if (L.has_p) {
+              emit(kw, lc + st, scale * (L.hl_p * L.w_p * L.gd_p) * pw[lc + st]);
+              emit(kg, lc + st, scale * (L.hl_p * L.w_p * L.hd_p) * pw[lc + st]);
+            }
+            if (L.has_m) {
+              emit(kw, lc - st, scale * (L.hd_j * L.w_j * L.gl_j) * pw[lc - st]);
+              emit(kg, lc - st, scale * (L.hd_j * L.w_j * L.hl_j) * pw[lc - st]);
+            }
+            continue;
+          }
           if (L.has_p) {
             emit(kw, lc + st, scale * (L.hl_p * L.w_p * L.gd_p));
             emit(kg, lc + st, scale * (L.hl_p * L.w_p * L.hd_p));
@@ -215,8 +234,8 @@ __device__ inline void eval_row(const SysParams& P, int kind, i64 lc, const i64*
       }
     }
     if (bulk && mv) {
-      const double pw = P.mv_psi_w[lc], pg = P.mv_psi_g ? P.mv_psi_g[lc] : P.mv_gconst;
-      const double v0 = P.mv_explicit ? 0.0 : P.mv_v0[lc], v1 = P.mv_explicit ? 0.0 : P.mv_v1[lc];
+      const double pw = P.mv_psi_w[q][lc], pg = P.mv_psi_g[q] ? P.mv_psi_g[q][lc] : P.mv_gconst;
+      const double v0 = P.mv_explicit ? 0.0 : P.mv_v0[q][lc], v1 = P.mv_explicit ? 0.0 : P.mv_v1[q][lc];
       emit(kw, lc, v0 + scale * dW * pw);               // Vn_1 + (Id GᵀWꜝG Ψ)_jj
       emit(kg, lc, -(v0 - v1) + scale * dG * pg);       // -(Vn_1 - Vn) + (Id GᵀWꜝH Ψ)_jj
     } else if (bulk) {
@@ -226,6 +245,10 @@ __device__ inline void eval_row(const SysParams& P, int kind, i64 lc, const i64*
     } else if (P.nphase == 1) {
       emit(kw, lc, scale * dW);
       emit(kg, lc, scale * dG + P.gscale * (P.Ia * c.G[lc]));   // + (Δt/2)·Iₐ·Γ
+    } else if (mv) {                    // moving flux row: β_q (HᵀWꜝG Ψ)_jj, β_q (HᵀWꜝH Ψ)_jj - (Vn_1 - Vn)   (:378-381)
+      const double pw = P.mv_psi_w[q][lc];
+      emit(kw, lc, scale * dW * pw);
+      emit(kg, lc, scale * dG * pw - (P.mv_v0[q][lc] - P.mv_v1[q][lc]));
     } else {
       emit(kw, lc, scale * dW);
       emit(kg, lc, scale * dG);

@@ -312,3 +312,117 @@ def solve_MovingDiffusionUnsteadyMono_b(s: api.Solver, phase: api.Phase, body, Î
         s.x = s._fetch_state(-1)
         s.states.append(s.x)
     return s
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# two phases                                                          prescribedmotionsolver/diffusion.jl:272-535
+# ---------------------------------------------------------------------------------------------------------------------
+def _create_step_diph(s: api.Solver, phase1: api.Phase, phase2: api.Phase, bc_b, ic, Î”t: float, Táµ¢: Optional[np.ndarray],
+                      mesh: api.Mesh, scheme: str, t: float, from_previous: bool = False):
+    """A_/b_diph_unstead_diff_moving + BC_border_diph!(A, b, bc_b, mesh) of one slab (diffusion.jl:281-288, 519-523)."""
+    cap1, cap2 = phase1.capacity, phase2.capacity
+    for cap in (cap1, cap2):
+        if not isinstance(cap, SpaceTimeCapacity):
+            raise PenguinHipError("the moving solver needs space-time capacities: Capacity(body, SpaceTimeMesh(mesh, [t, t+Î”t]))")
+        if cap.mesh is not mesh and tuple(cap.mesh.dims) != tuple(mesh.dims):
+            raise ValueError("mesh does not match the capacity's space mesh")
+    M = int(np.prod(mesh.ext))
+    sch = "CN" if scheme == "CN" else "BE"
+    jump, flux = ic.scalar, ic.flux
+    # build_g_g(operator, jump, capacity): value(C_Î³...) at the space-time interface centroids, no time argument (:423-424)
+    g = api._eval(jump.value, cap1._cg, None, 3) if callable(jump.value) else float(jump.value)
+    h = api._eval(flux.value, cap2._cg, None, 3) if callable(flux.value) else float(flux.value)
+    g_arr = None if isinstance(g, float) else api._padded_field(g, M)
+    h_arr = None if isinstance(h, float) else api._padded_field(h, M)
+    p = lambda a: L.dptr(a) if a is not None else None
+    desc = L.pg_jump_desc(float(jump.Î±1), float(jump.Î±2), g if isinstance(g, float) else 0.0, float(flux.Î²1), float(flux.Î²2),
+                          h if isinstance(h, float) else 0.0, p(g_arr), p(h_arr))
+    D1, D2 = api._dcoef(phase1, M), api._dcoef(phase2, M)
+    fs = []
+    for ph in (phase1, phase2):
+        f1 = api._padded_field(api._eval(ph.source, ph.capacity._cw, float(t + Î”t), 3), M)       # f(C_Ï‰..., t+Î”t)   :416,418
+        f0 = api._padded_field(api._eval(ph.source, ph.capacity._cw, float(t), 3), M) if sch == "CN" else None
+        if sch == "CN" and f1 is not None and f0 is None:
+            f0 = np.zeros(M)
+        fs.append((f0, f1))
+    borders, nb, bvals = api._border_descs(bc_b, mesh, None)       # BC_border_diph!(s.A, s.b, bc_b, mesh): no t (:288, :523)
+    old, new = s._h, C.c_void_p()
+    L.check(L.lib().pg_solver_create_moving_diph(
+        cap1._h, phase1.operator._h, cap2._h, phase2.operator._h, C.byref(desc), borders, C.c_int32(nb), p(D1), p(D2),
+        p(fs[0][0]), p(fs[0][1]), p(fs[1][0]), p(fs[1][1]),
+        None if from_previous else (L.dptr(Táµ¢) if Táµ¢ is not None else None), old if from_previous else None,
+        C.c_int32(L.PG_SCHEME[sch]), C.byref(new)))
+    s._h = new
+    if old:
+        L.check(L.lib().pg_solver_destroy(old))
+    if bvals is not None:
+        L.check(L.lib().pg_solver_set_border_values(s._h, L.dptr(bvals)))
+    s._keep = (cap1, cap2, phase1.operator, phase2.operator)
+    s._initial_done = False
+
+
+def MovingDiffusionUnsteadyDiph(phase1: api.Phase, phase2: api.Phase, bc_b, ic, Î”t: float, Táµ¢: np.ndarray, mesh: api.Mesh,
+                                scheme: str, verbose: bool = False) -> api.Solver:
+    """MovingDiffusionUnsteadyDiph(phase1, phase2, bc_b, ic, Î”t, Táµ¢, mesh, scheme) -- prescribedmotionsolver/diffusion.jl:272-290."""
+    if verbose:
+        print("Solver Creation:\n- Moving problem\n- Diphasic problem\n- Unsteady problem\n- Diffusion problem")
+    s = api.Solver("Unsteady", "Diphasic", "Diffusion")
+    M = int(np.prod(mesh.ext))
+    s._nunk = 4 * M
+    if Táµ¢ is not None:
+        Táµ¢ = np.ascontiguousarray(Táµ¢, dtype=np.float64)
+        if Táµ¢.shape != (4 * M,):
+            raise ValueError(f"Táµ¢ must have length 4*prod(n+1) = {4 * M}")
+    s._ctx = dict(dt=float(Î”t), M=M)
+    _create_step_diph(s, phase1, phase2, bc_b, ic, float(Î”t), Táµ¢, mesh, scheme, 0.0)      # t = 0.0 in b (:282, :285)
+    return s
+
+
+def solve_MovingDiffusionUnsteadyDiph_b(s: api.Solver, phase1: api.Phase, phase2: api.Phase, body, body_c, Î”t: float, Tâ‚‘: float,
+                                        bc_b, ic, mesh: api.Mesh, scheme: str, method="gmres", algorithm=None, verbose: bool = False,
+                                        max_steps: Optional[int] = None, time_panels: int = 16, time_order: int = 4,
+                                        save_states: bool = True, **kwargs):
+    """solve_MovingDiffusionUnsteadyDiph!(s, phase1, phase2, body, body_c, Î”t, Tâ‚‘, bc_b, ic, mesh, scheme; method, ...) --
+    prescribedmotionsolver/diffusion.jl:501-535: the constructor's system first (states[1]); then from t = 0.0 `while t < Tâ‚‘`:
+    t += Î”t, the two capacities of the slab [t, t+Î”t], new blocks and border rows, solve, push."""
+    if s is None or not s._h:
+        raise PenguinHipError("Solver is not initialized. Call a solver constructor first.")
+    opts = api._krylov_opts(method, kwargs)
+    sch = "CN" if scheme == "CN" else "BE"
+
+    def solve_current(what):
+        info = L.pg_step_info()
+        L.check(L.lib().pg_solver_initial_solve(s._h, C.byref(opts), C.byref(info)))
+        api._step_info_check(s, info, what)
+        s._initial_done = True
+        s.ch.append(info)
+        if save_states:
+            s.x = s._fetch_state(-1)
+            s.states.append(s.x)
+        if verbose:
+            print("Solver Extremum : ", float(info.extremum))
+
+    t = 0.0                                        # :513
+    if verbose:
+        print(f"Time : {t}")
+    solve_current("the first solve")
+    Táµ¢ = s.x
+    steps = 0
+    while t < Tâ‚‘:
+        if max_steps is not None and steps >= max_steps:
+            break
+        t += Î”t
+        if verbose:
+            print(f"Time : {t}")
+        caps = [api.Capacity(b, SpaceTimeMesh(mesh, [t, t + Î”t]), time_panels=time_panels, time_order=time_order,
+                             compute_centroids=True) for b in (body, body_c)]
+        ph1 = api.Phase(caps[0], api.DiffusionOps(caps[0]), phase1.source, phase1.Diffusion_coeff)
+        ph2 = api.Phase(caps[1], api.DiffusionOps(caps[1]), phase2.source, phase2.Diffusion_coeff)
+        _create_step_diph(s, ph1, ph2, bc_b, ic, float(Î”t), Táµ¢, mesh, sch, t, from_previous=not save_states)
+        solve_current(f"the solve of the slab starting at t = {t}")
+        Táµ¢ = s.x
+        steps += 1
+    if not save_states:
+        s.x = s._fetch_state(-1)
+        s.states.append(s.x)
+    return s

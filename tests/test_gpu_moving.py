@@ -373,3 +373,86 @@ def test_moving_random_problems(pj, seed):
             berr = np.abs(A @ xr - bb) / (abs(A) @ np.abs(xr) + np.abs(bb) + 1e-300)
             assert berr.max() <= 1e-9, f"state {k}: backward error {berr.max():.2e}"
             break
+
+
+# ------------------------------------------------------------------------------------------------ two phases
+def _diph_bodies(pj, name):
+    """(body, complement) on the product's side and on the oracle's, for the moving two-phase cases."""
+    if name == "1d":
+        pos, dpos = (lambda t: 0.21 + 0.9 * t + 0.5 * t * t), (lambda t: 0.9 + t)
+        return ((pj.MovingHalfSpace(0, pos, 1.0, dposition=dpos), pj.MovingHalfSpace(0, pos, 1.0, complement=True, dposition=dpos)),
+                (ost.MovingHalfSpace(0, pos, 1.0, dposition=dpos), ost.MovingHalfSpace(0, pos, 1.0, complement=True, dposition=dpos)))
+    cen, dcen = (lambda t: (2.01 + 0.8 * t, 1.97 - 0.5 * t)), (lambda t: (0.8, -0.5))
+    rad, drad = (lambda t: 1.0 + 0.4 * t), (lambda t: 0.4)
+    return ((pj.MovingSphere(cen, rad, False, dcenter=dcen, dradius=drad), pj.MovingSphere(cen, rad, True, dcenter=dcen, dradius=drad)),
+            (ost.MovingBall(cen, rad, False, dcenter=dcen, dradius=drad), ost.MovingBall(cen, rad, True, dcenter=dcen, dradius=drad)))
+
+
+@pytest.mark.parametrize("name,scheme", [("1d", "BE"), ("1d", "CN"), ("2d", "BE"), ("2d", "CN")])
+def test_moving_diphasic_steps_match_oracle(pj, name, scheme):
+    """MovingDiffusionUnsteadyDiph + solve_MovingDiffusionUnsteadyDiph! (prescribedmotionsolver/diffusion.jl:272-535): 1 + 4
+    slabs of a body and its complement that move through the mesh (cells change phase: fresh and dead cells on both sides),
+    sources, two diffusivities, jump data that vary along the interface, border rows in BOTH phases (the driver calls
+    BC_border_diph! without capacities).  The oracle assembles the literal (N+1)-D blocks from the capacities the HIP path
+    computed and solves directly; the bar is 1e-10 wherever the oracle's own direct solution is determined that well
+    (`sens`: how far it moves under a one-ulp perturbation of its matrix -- the small-cell problem of moving cut cells)."""
+    import scipy.sparse.linalg as spla
+
+    mesh, omesh, _, dt = _cases(pj)[name]
+    (body, body_c), (obody, obody_c) = _diph_bodies(pj, name)
+    N, M = omesh.N, int(np.prod(omesh.ext))
+    f1 = lambda x, y, z, t: 0.3 + 0.2 * x + 0.5 * t
+    f2 = lambda x, y, z, t: 0.1 - 0.1 * x + 0.2 * t
+    D1 = lambda x, y, z: 1.0 + 0.1 * x
+    D2 = lambda x, y, z: 2.0
+    gj = lambda x, y, z=0.0: 0.2 + 0.1 * x                         # jump data at the space-time interface centroids
+    hj = lambda x, y, z=0.0: 0.5 - 0.05 * x
+    ic = pj.InterfaceConditions(pj.ScalarJump(1.0, 0.5, gj), pj.FluxJump(1.0, 2.0, hj))
+    oic = po.InterfaceConditions(po.ScalarJump(1.0, 0.5, gj), po.FluxJump(1.0, 2.0, hj))
+    keys = ("bottom", "top") if N == 1 else ("left", "right", "top", "bottom")
+    bcb = pj.BorderConditions({k: pj.Dirichlet(0.3) for k in keys})
+    obcb = po.BorderConditions({k: po.Dirichlet(0.3) for k in keys})
+    T0 = np.random.default_rng(11).random(4 * M)
+
+    def hip_caps(t0, t1):
+        return pj.Capacity(body, pj.SpaceTimeMesh(mesh, [t0, t1])), pj.Capacity(body_c, pj.SpaceTimeMesh(mesh, [t0, t1]))
+
+    c1, c2 = hip_caps(0.0, dt)
+    p1, p2 = pj.Phase(c1, pj.DiffusionOps(c1), f1, D1), pj.Phase(c2, pj.DiffusionOps(c2), f2, D2)
+    s = pj.MovingDiffusionUnsteadyDiph(p1, p2, bcb, ic, dt, T0, mesh, scheme)
+    pj.solve_MovingDiffusionUnsteadyDiph_b(s, p1, p2, body, body_c, dt, 3.5 * dt, bcb, ic, mesh, scheme, method="bicgstab", reltol=1e-14)
+    assert s.unconverged == 0 and len(s.states) == 5
+    # the oracle, slab by slab, on the HIP capacities
+    oc1, oc2 = _oracle_cap(c1, omesh, 0.0, dt, obody), _oracle_cap(c2, omesh, 0.0, dt, obody_c)
+    q1, q2 = po.Phase(oc1, po.make_diffusion_ops(oc1), f1, D1), po.Phase(oc2, po.make_diffusion_ops(oc2), f2, D2)
+    so = ost.MovingDiffusionUnsteadyDiph(q1, q2, obcb, oic, dt, T0, omesh, scheme)
+    sens = []
+
+    def solve_and_probe():
+        po.solve_system(so)
+        so.states.append(so.x)
+        A, b = so.last_A_reduced, so.last_b_reduced
+        Ap = A.copy()
+        Ap.data = Ap.data * (1.0 + 2.2e-16 * np.random.default_rng(1).standard_normal(len(Ap.data)))
+        sens.append(rel_l2(spla.spsolve(Ap.tocsc(), b), spla.spsolve(A.tocsc(), b)))
+
+    solve_and_probe()
+    t = 0.0
+    while t < 3.5 * dt:
+        t += dt
+        h1, h2 = hip_caps(t, t + dt)
+        k1, k2 = _oracle_cap(h1, omesh, t, t + dt, obody), _oracle_cap(h2, omesh, t, t + dt, obody_c)
+        o1, o2 = po.make_diffusion_ops(k1), po.make_diffusion_ops(k2)
+        so.A = ost.A_diph_unstead_diff_moving(o1, o2, k1, k2, D1, D2, oic, scheme)
+        # (previous state: the HIP one -- every slab is compared on identical inputs, as the step-by-step diphasic test does)
+        so.b = ost.b_diph_unstead_diff_moving(o1, o2, k1, k2, D1, D2, f1, f2, oic, s.states[len(so.states) - 1], dt, t, scheme)
+        so.A, so.b = ost._border_diph(so.A, so.b, obcb, k1, k2, omesh, None)
+        solve_and_probe()
+    assert len(so.states) == 5
+    nact = set()
+    for k, (x, xo) in enumerate(zip(s.states, so.states)):
+        assert np.array_equal(np.flatnonzero(x != 0.0), np.flatnonzero(xo != 0.0)), f"active set of state {k}"
+        tol = max(TOL_T, 50.0 * sens[k])
+        assert rel_l2(x, xo) <= tol, f"state {k}: {rel_l2(x, xo):.2e} (bar {tol:.1e}, sensitivity {sens[k]:.1e})"
+        nact.add(int(np.count_nonzero(xo)))
+    assert len(nact) > 1          # cells did change phase from slab to slab
