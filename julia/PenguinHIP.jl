@@ -21,7 +21,7 @@ export Mesh, nC, Capacity, capacity_from_arrays, Sphere, MultiSphere, HalfSpace,
        solve_AdvectionDiffusionSteadyDiph!, AdvectionDiffusionUnsteadyMono, solve_AdvectionDiffusionUnsteadyMono!,
        AdvectionDiffusionUnsteadyDiph, solve_AdvectionDiffusionUnsteadyDiph!,
        SpaceTimeMesh, MovingSphere, MovingHalfSpace, SpaceTimeCapacity, MovingDiffusionUnsteadyMono,
-       solve_MovingDiffusionUnsteadyMono!,
+       solve_MovingDiffusionUnsteadyMono!, MovingDiffusionUnsteadyDiph, solve_MovingDiffusionUnsteadyDiph!, config_string,
        ∇, ∇₋, gmres, bicgstabl, cg
 
 const libpg = get(ENV, "PENGUIN_HIP_LIB", joinpath(@__DIR__, "..", "penguin", "jl_amd", "lib", "libpenguin_hip.so"))
@@ -834,6 +834,86 @@ function solve_MovingDiffusionUnsteadyMono!(s::Solver, phase::Phase, body::Funct
         Tᵢ = s.x
     end
     s
+end
+
+# ---- two phases: MovingDiffusionUnsteadyDiph (:272-290), A_/b_diph_unstead_diff_moving (:292-498),
+# solve_MovingDiffusionUnsteadyDiph! (:501-535) -----------------------------------------------------------------------------------
+function _moving_step_diph!(s::Solver, phase1::Phase, phase2::Phase, bc_b::BorderConditions, ic::InterfaceConditions, Δt::Float64,
+                            Tᵢ::Vector{Float64}, mesh::Mesh, scheme::String, t::Float64)
+    c1, c2 = phase1.capacity, phase2.capacity
+    (c1 isa SpaceTimeCapacity && c2 isa SpaceTimeCapacity) ||
+        error("the moving solver needs space-time capacities: Capacity(body, SpaceTimeMesh(mesh, [t, t+Δt]))")
+    Cω1, Cω2 = _st_coords(c1.C_ω, c1.Ct_ω), _st_coords(c2.C_ω, c2.Ct_ω)
+    # build_g_g(operator, jump, capacity): value(C_γ...) at the space-time interface centroids, no time argument (:423-424)
+    g = ic.scalar.value isa Function ? Float64[Float64(ic.scalar.value(c...)) for c in _st_coords(c1.C_γ, c1.Ct_γ)] : Float64[]
+    hh = ic.flux.value isa Function ? Float64[Float64(ic.flux.value(c...)) for c in _st_coords(c2.C_γ, c2.Ct_γ)] : Float64[]
+    D1 = Float64[Float64(phase1.Diffusion_coeff(c...)) for c in Cω1]
+    D2 = Float64[Float64(phase2.Diffusion_coeff(c...)) for c in Cω2]
+    f1n1 = Float64[Float64(phase1.source(c..., t + Δt)) for c in Cω1]                                       # :416
+    f2n1 = Float64[Float64(phase2.source(c..., t + Δt)) for c in Cω2]                                       # :418
+    f1n = Float64[Float64(phase1.source(c..., t)) for c in Cω1]                                             # :415
+    f2n = Float64[Float64(phase2.source(c..., t)) for c in Cω2]                                             # :417
+    borders = _border_descs(bc_b)
+    s.handle != C_NULL && ccall((:pg_solver_destroy, libpg), Int32, (Ptr{Cvoid},), s.handle)
+    s.handle = C_NULL
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve g hh D1 D2 f1n f2n f1n1 f2n1 Tᵢ borders begin
+        desc = Ref(_jump_desc(ic, c1, c2, g, hh))
+        check(ccall((:pg_solver_create_moving_diph, libpg), Int32,
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{pg_jump_desc}, Ptr{pg_border_desc}, Int32, Ptr{Float64}, Ptr{Float64},
+                     Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}, Int32, Ptr{Ptr{Cvoid}}),
+                    c1.handle, phase1.operator.handle, c2.handle, phase2.operator.handle, desc, borders, length(borders), D1, D2,
+                    f1n, f1n1, f2n, f2n1, Tᵢ, C_NULL, _scheme(scheme), h))
+    end
+    s.handle = h[]
+    _has_border_functions(bc_b) && _set_border_values!(s, bc_b, mesh, nothing)   # BC_border_diph!(s.A, s.b, bc_b, mesh): no t (:288, :523)
+    s.A = (c1, c2, phase1.operator, phase2.operator)     # keeps the device capacities alive as long as this slab's solver
+    s
+end
+
+function MovingDiffusionUnsteadyDiph(phase1::Phase, phase2::Phase, bc_b::BorderConditions, ic::InterfaceConditions, Δt::Float64,
+                                     Tᵢ::Vector{Float64}, mesh::AbstractMesh, scheme::String)
+    println("Solver Creation:"); println("- Moving problem"); println("- Diphasic problem"); println("- Unsteady problem"); println("- Diffusion problem")
+    s = _new_solver(:Unsteady, :Diphasic, :Diffusion, Ptr{Cvoid}(C_NULL), length(Tᵢ))
+    _moving_step_diph!(s, phase1, phase2, bc_b, ic, Δt, Tᵢ, mesh, scheme, 0.0)          # t = 0.0 in b (:282, :285)
+end
+
+function solve_MovingDiffusionUnsteadyDiph!(s::Solver, phase1::Phase, phase2::Phase, body::Function, body_c::Function, Δt::Float64,
+                                            Tₑ::Float64, bc_b::BorderConditions, ic::InterfaceConditions, mesh::AbstractMesh,
+                                            scheme::String; method::Function=gmres, algorithm=nothing, kwargs...)
+    (s.handle == C_NULL) && error("Solver is not initialized. Call a solver constructor first.")
+    kw = Dict{Symbol, Any}(kwargs)
+    log = get(kw, :log, false)
+    opts = Ref(_opts(method, kw))
+    info = pg_step_info()
+    function solve!()
+        check(ccall((:pg_solver_initial_solve, libpg), Int32, (Ptr{Cvoid}, Ptr{pg_krylov_opts}, Ref{pg_step_info}), s.handle, opts, info))
+        _record!(s, info, log)
+        println("Solver Extremum : ", maximum(abs.(s.x)))
+    end
+    t = 0.0                                                                  # :513
+    println("Time : $(t)")
+    solve!()
+    Tᵢ = s.x
+    while t < Tₑ                                                             # :517
+        t += Δt
+        println("Time : $(t)")
+        STmesh = SpaceTimeMesh(mesh, [t, t + Δt], tag=mesh.tag)
+        capacity1, capacity2 = Capacity(body, STmesh), Capacity(body_c, STmesh)
+        ph1 = Phase(capacity1, DiffusionOps(capacity1), phase1.source, phase1.Diffusion_coeff)
+        ph2 = Phase(capacity2, DiffusionOps(capacity2), phase2.source, phase2.Diffusion_coeff)
+        _moving_step_diph!(s, ph1, ph2, bc_b, ic, Δt, Tᵢ, mesh, scheme, t)   # A, b, BC_border_diph!(A, b, bc_b, mesh)   :519-523
+        solve!()
+        Tᵢ = s.x
+    end
+    s
+end
+
+"Every PG_* tuning / variant selector the library runs with (`pg_config_string`)."
+function config_string()
+    buf = Vector{UInt8}(undef, 2048)
+    check(ccall((:pg_config_string, libpg), Int32, (Ptr{UInt8}, Csize_t), buf, length(buf)))
+    unsafe_string(pointer(buf))
 end
 
 end # module

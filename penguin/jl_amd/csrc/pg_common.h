@@ -77,6 +77,7 @@ struct Config {
   int half_test = -1;             // PG_HALF_TEST: -1 automatic (degree >= 3), 0 off, 1 on
   bool half_batch = true;         // PG_HALF_BATCH
   bool krylov_nt = true;          // PG_KRYLOV_NT: stream hints on the dead vectors of the vector kernels
+  bool fuse_half_update = true;   // PG_FUSE_HALF: x-space loop: x += α M⁻¹p inside the s kernel (k_bicg_s_x) instead of k_bicg_half
   double poly_margin = 1.0;       // PG_POLY_MARGIN
   double poly_slack = -1.0;       // PG_POLY_SLACK (< 0: 0.3 products in the x-space form, 0 otherwise)
   int poly_hist = 3;              // PG_POLY_HIST

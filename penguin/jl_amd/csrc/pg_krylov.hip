@@ -120,6 +120,81 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_s(i64 n, double* __restrict__ sc
   }
 }
 
+// k_bicg_s and the x update of the first half in ONE pass (x-space form of the preconditioned loop): s = r - αv over r with its
+// dots and the half-step test, and x += α M⁻¹p through the index map of a compact system.  BiCGStab adds α M⁻¹p to x in every
+// iteration whether or not it ends at the half step (x_{i+1} = x_i + α p̂ + ω ŝ, and nothing reads x in between), so the
+// update does not wait for the verdict of the test: k_bicg_half -- a second pass over p̂ and x, and a launch -- is not
+// needed, and k_bicg_xrp of a solve that goes on adds ω ŝ only (`alpha_done`).  Two rows per lane (16-byte accesses).
+template <bool NTV>
+__global__ __launch_bounds__(BLOCK) void k_bicg_s_x(i64 n, double* __restrict__ sc, const double* __restrict__ v,
+                                                    const double* __restrict__ rhat, double* __restrict__ r,
+                                                    double* __restrict__ partials, const double* __restrict__ ds,
+                                                    unsigned* __restrict__ ticket, int r_in_rhat, const double* __restrict__ phat,
+                                                    double* __restrict__ x, const int* __restrict__ map) {
+  __shared__ double s_red[BLOCK / 64];
+  if (sc[S_DONE] != 0.0) return;
+  const double alpha = sc[S_ALPHA];
+  const bool rrhat = r_in_rhat != 0 && sc[S_ITERS] == 0.0;   // first iteration of a start that left r = r̂ unwritten
+  const double* __restrict__ rsrc = rrhat ? rhat : r;
+  double a0 = 0.0, a1 = 0.0, aw = 0.0;
+  typedef double dd2 __attribute__((ext_vector_type(2)));
+  const i64 npair = n / 2;
+  for (i64 q = blockIdx.x * (i64)BLOCK + threadIdx.x; q < npair; q += (i64)gridDim.x * BLOCK) {
+    const i64 i = 2 * q;
+    const dd2 rh = *reinterpret_cast<const dd2*>(rhat + i);
+    const dd2 rr = rrhat ? rh : *reinterpret_cast<const dd2*>(rsrc + i);
+    const dd2 vv = NTV ? __builtin_nontemporal_load(reinterpret_cast<const dd2*>(v + i)) : *reinterpret_cast<const dd2*>(v + i);
+    const dd2 dw = *reinterpret_cast<const dd2*>(ds + i);
+    const dd2 ph = NTV ? __builtin_nontemporal_load(reinterpret_cast<const dd2*>(phat + i)) : *reinterpret_cast<const dd2*>(phat + i);
+    dd2 si;
+    si.x = rr.x - alpha * vv.x;
+    si.y = rr.y - alpha * vv.y;
+    *reinterpret_cast<dd2*>(r + i) = si;
+    if (map) {
+      const int j0 = map[i], j1 = map[i + 1];
+      x[j0] += alpha * ph.x;
+      x[j1] += alpha * ph.y;
+    } else {
+      dd2 xx = *reinterpret_cast<dd2*>(x + i);
+      xx.x += alpha * ph.x;
+      xx.y += alpha * ph.y;
+      *reinterpret_cast<dd2*>(x + i) = xx;
+    }
+    a0 += rh.x * si.x + rh.y * si.y;
+    a1 += si.x * si.x + si.y * si.y;
+    const double w0 = dw.x * si.x, w1 = dw.y * si.y;
+    aw += w0 * w0 + w1 * w1;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {   // the odd last row
+    const i64 i = n - 1;
+    const double rh = rhat[i], si = rsrc[i] - alpha * v[i];
+    r[i] = si;
+    x[map ? map[i] : i] += alpha * phat[i];
+    a0 += rh * si;
+    a1 += si * si;
+    aw += (ds[i] * si) * (ds[i] * si);
+  }
+  const double t0 = block_sum(a0, s_red);
+  if (threadIdx.x == 0) partials[2 * (size_t)gridDim.x + blockIdx.x] = t0;
+  const double t1 = block_sum(a1, s_red);
+  if (threadIdx.x == 0) partials[3 * (size_t)gridDim.x + blockIdx.x] = t1;
+  const double tw = block_sum(aw, s_red);
+  if (!ticket) {
+    if (threadIdx.x == 0) partials[4 * (size_t)gridDim.x + blockIdx.x] = tw;
+    return;
+  }
+  double* slot4 = partials + 4 * (size_t)gridDim.x;
+  if (threadIdx.x == 0) store_partial(slot4 + blockIdx.x, tw);
+  if (!last_block_arrives(ticket, gridDim.x, s_red)) return;
+  double a = 0.0;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += BLOCK) a += load_partial(slot4 + i);
+  const double t = block_sum(a, s_red);
+  if (threadIdx.x == 0) {
+    sc[S_RED0 + 4] = t;
+    derive(PH_BICG_S, sc);
+  }
+}
+
 // the half step accepted (PH_BICG_S: derive has set S_DONE and S_HALF = this iteration's number): x += αp; r = s stands
 // fresh != 0: x is the accumulated solution of the preconditioned system, which starts at zero and has not been written yet
 // in the first iteration -- assigned instead of read (its memset and its first read are saved)
@@ -149,7 +224,7 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_xrp(i64 n, double* sc, const dou
                                                     double* __restrict__ rhat, double* __restrict__ partials,
                                                     const double* __restrict__ ds, int fresh, int p_in_rhat,
                                                     const double* __restrict__ phat, const double* __restrict__ shat,
-                                                    const int* __restrict__ map) {
+                                                    const int* __restrict__ map, int alpha_done) {
   __shared__ double s_red[BLOCK / 64];
   if (sc[S_DONE] != 0.0) return;
   const double alpha = sc[S_ALPHA], omega = sc[S_OMEGA], beta = sc[S_BETA];
@@ -162,7 +237,9 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_xrp(i64 n, double* sc, const dou
     if (phat) {
       // x-space form: x += α M⁻¹p + ω M⁻¹s with the two preconditioned vectors the applications of the operator left
       const i64 j = map ? map[i] : i;
-      x[j] += alpha * (NTV ? __builtin_nontemporal_load(phat + i) : phat[i]) + omega * (NTV ? __builtin_nontemporal_load(shat + i) : shat[i]);
+      // (alpha_done: the first half has added α M⁻¹p already, k_bicg_s_x)
+      const double ap = alpha_done ? 0.0 : alpha * (NTV ? __builtin_nontemporal_load(phat + i) : phat[i]);
+      x[j] += ap + omega * (NTV ? __builtin_nontemporal_load(shat + i) : shat[i]);
     } else {
       const double xi = (first ? 0.0 : (NTV ? __builtin_nontemporal_load(x + i) : x[i])) + alpha * pi + omega * si;
       if (NTV) __builtin_nontemporal_store(xi, x + i); else x[i] = xi;
@@ -512,6 +589,8 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
   // costs two small launches); PG_HALF_TEST=0/1 forces it off / on
   const int half_env = cfg.half_test;
   const bool half_test = !cg && (half_env < 0 ? m >= 3 : half_env != 0);
+  // x-space: the first half's update of x rides with k_bicg_s (k_bicg_s_x): one pass and one launch less per iteration
+  const bool fused_x = xspace && cfg.fuse_half_update;
   PG_REQUIRE(!preinit || !cg, "preinit is a BiCGStab path");
   if (!cg) {
     if (!preinit)
@@ -602,6 +681,14 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
     apply(pvec, w.v.p, PH_BICG_1, 3, itn);     // v = C p, (r̂,v); previous iteration's (r,r): convergence / restart; then α
     const bool half_test = test;
     unsigned* tk = (half_test && derive_here) ? w.ticket.p : nullptr;   // the half-step test inside k_bicg_s
+    if (fused_x) {
+      // s, its dots, the half-step test AND x += α M⁻¹p in one pass; without the test in this iteration the sums of slot 4
+      // are simply not looked at
+      if (ntv) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_s_x<true>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p, (const double*)A.ds.p, tk, p_in_rhat ? 1 : 0, (const double*)w.ya.p, xit, xmap);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_s_x<false>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p, (const double*)A.ds.p, tk, p_in_rhat ? 1 : 0, (const double*)w.ya.p, xit, xmap);
+      if (half_test && !tk) finalize(PH_BICG_S, 1, w, st, true, 4);
+      return;
+    }
     if (ntv) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_s<true>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p, (const double*)A.ds.p, tk, p_in_rhat ? 1 : 0);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_s<false>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p, (const double*)A.ds.p, tk, p_in_rhat ? 1 : 0);
     if (half_test) {   // does s already meet the tolerance?  then x += αp and stop: the second half is 1 + m launches
@@ -614,10 +701,10 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
     apply(w.r.p, w.t.p, PH_BICG_2, 5, itn);     // t = C s (r holds s), (t,s), (t,t), (r̂,t); then ω, ρ, β / restart
     if (ntv) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_xrp<true>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.t.p, w.v.p, xit, w.r.p,
                                 w.p.p, w.rhat.p, w.partials.p, (const double*)A.ds.p, (poly && !xspace) ? 1 : 0, p_in_rhat ? 1 : 0,
-                                xspace ? (const double*)w.ya.p : nullptr, xspace ? (const double*)w.yb.p : nullptr, xmap);
+                                xspace ? (const double*)w.ya.p : nullptr, xspace ? (const double*)w.yb.p : nullptr, xmap, fused_x ? 1 : 0);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_xrp<false>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.t.p, w.v.p, xit, w.r.p,
                             w.p.p, w.rhat.p, w.partials.p, (const double*)A.ds.p, (poly && !xspace) ? 1 : 0, p_in_rhat ? 1 : 0,
-                                xspace ? (const double*)w.ya.p : nullptr, xspace ? (const double*)w.yb.p : nullptr, xmap);
+                                xspace ? (const double*)w.ya.p : nullptr, xspace ? (const double*)w.yb.p : nullptr, xmap, fused_x ? 1 : 0);
   };
   const bool half_batches = cfg.half_batch;   // (0: whole iterations, for A/B runs)
   while (!done) {
