@@ -265,6 +265,9 @@ def main() -> None:
             "rows_global": n_rows_g, "nnz_global": nnz_g, "rows_rank0": n_rows, "nnz_rank0": nnz,
             "krylov_iters_per_step": iters, "krylov_iters_per_step_counting_half_steps_as_half": iters_eff,
             "polynomial_preconditioner_degree": m,
+            "products_per_step_in_the_solves": getattr(run, "products", 0) / max(run.steps, 1),
+            "start_of_each_solve": "the previous state, extrapolated from older states where a least-squares fit says it pays "
+                                   "(PG_GUESS_STATES, pg_solver_guess_info): same stopping test, fewer products",
             "spmv_timed_per_step": (run.spmv_launches + run.spmv_lean_launches) / max(run.steps, 1),
             "timed_window": f"steps {args.warmup + 1}..{args.warmup + args.steps} after the BE solve (iterations per step fall as the field settles)",
             "parallelism": (f"slab-z x{world}: " + ("one ghost plane per neighbour per SpMV (RCCL send/recv, overlapped) + " if halo else
@@ -341,13 +344,25 @@ def main() -> None:
     #       the second application of an iteration); k_bicg_xrp additionally reads the two preconditioned vectors and the index
     #       map of the compact system (11.5 x 8 n); the half-step update x += alpha M^-1 p (28 n) once per solve that ends there;
     #       no recovery.
+    # degree of the preconditioner polynomial: the LAST solve's in `m`; the window's mean from the products counted (the
+    # extrapolated start lowers it from step to step)
+    apps = 2.0 * run.total_iters - run.half_exits            # applications of the preconditioned operator in the window
+    m_mean = (run.products / apps) if (m >= 2 and apps > 0 and getattr(run, "products", 0) > 0) else float(m)
+    # extrapolated start of the quiet steps (pg_solver_guess_info): per older state read, two more vector reads of the step's
+    # first kernel (full-system length), and the new state written out of place (one more write) whenever the feature is on
+    guess_reads = getattr(run, "guess_states_read", 0) / max(run.steps, 1)
+    guess_on = "guess_states=0" not in pj.config_string()
+    guess_bytes = (16.0 * guess_reads + (8.0 if guess_on else 0.0)) * n_full
     if xspace:
         half_per_step = run.half_exits / max(run.steps, 1)
+        mm = m_mean
+        b_chain_mean = b_fmt + 8.0 * n_rows * (mm - 2) / (mm - 1)
         # (compact loop system: the start writes r-hat only -- r = p = r-hat are read from it in the first iteration, whose
         #  k_bicg_s therefore reads one vector less)
         start_bytes = (54.0 * n_full + 8.0 * n_rows - 8.0 * n_rows) if reduced else 74.0 * n_full
-        step_bytes = (2.0 * iters_eff) * ((m - 1) * b_chain + b_fmt + 8.0 * n_rows) + (iters - half_per_step) * 8.0 * n_rows \
-            + iters * 40.0 * n_rows + (iters - half_per_step) * 92.0 * n_rows + half_per_step * 28.0 * n_rows + b_fmt_full + start_bytes
+        step_bytes = (2.0 * iters_eff) * ((mm - 1) * b_chain_mean + b_fmt + 8.0 * n_rows) + (iters - half_per_step) * 8.0 * n_rows \
+            + iters * 40.0 * n_rows + (iters - half_per_step) * 92.0 * n_rows + half_per_step * 28.0 * n_rows + b_fmt_full + start_bytes \
+            + guess_bytes
     elif m >= 2:
         per_apply = (m - 1) * b_fmt + (b_fmt + 16.0 * n_rows)
         start_bytes = (54.0 * n_full + 16.0 * n_rows - 8.0 * n_rows) if reduced else (74.0 * n_full + 8.0 * n_rows)
@@ -359,7 +374,8 @@ def main() -> None:
     out["step_roofline"] = {
         "what": "one CN time step of the loop on rank 0: every launch's operand vectors once and the matrix in the streamed "
                 "format (formula in bench.py), over the wall time per step",
-        "polynomial_preconditioner_degree": m, "gershgorin_radius": float(sysinfo.gershgorin),
+        "polynomial_preconditioner_degree": m, "polynomial_preconditioner_degree_mean": m_mean,
+        "older_states_read_per_step": guess_reads, "gershgorin_radius": float(sysinfo.gershgorin),
         "bound": "hbm", "bytes_per_step": step_bytes, "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": step_gbs / HBM_PEAK_GBS,
         "survey_8d_bytes_per_step": iters * (2.0 * b_csr + 168.0 * n_rows) + 48.0 * n_rows + 16.0 * n_rows,

@@ -121,6 +121,10 @@ typedef struct {
   int64_t poly_xspace;       /* 1: the last solve ran the x-space form of the preconditioned loop: the m - 1 launches of a chain
                                 are Horner steps (x, the chain's input and the matrix in, one vector out; the first of a chain
                                 reads one vector), no recovery; 0: y-space form (lean chains + recovery) or plain iteration       */
+  int64_t products;          /* products with the system matrix inside the run's solves (the one product per step that builds the
+                                right-hand side and the start residual not counted)                                             */
+  int64_t guess_states_read; /* older states read by the extrapolated starts of the run's quiet steps (pg_solver_guess_info):
+                                each is two more vector reads of the step's first kernel                                        */
 } pg_run_info;
 
 typedef struct {
@@ -360,6 +364,13 @@ int32_t pg_debug_virtual_rank_info(int32_t rank, int64_t* full_rows, int64_t* lo
 /* test hook: multiply the state at every row that is alone on its diagonal by `factor` WITHOUT telling the time loop --
    the next quiet step must notice (S_MOVED) and still end at the right state */
 int32_t pg_debug_scale_diagonal_rows(pg_solver* s, double factor);
+
+/* The extrapolated start of the time loop's quiet steps (constant data, one rank; no reference counterpart: the reference
+   starts every Krylov solve from zero, solver.jl:158-181): `kept` older states are held; the next step starts from
+   z^n + sum_j coef[j] (z^(n-offsets[j]) - z^n), j < nstates <= 4, chosen by a least-squares fit of this step's plain start
+   residual (sampled weighted squares: rr_plain without, rr_taken with this step's extrapolation).  PG_GUESS_STATES=0: off. */
+int32_t pg_solver_guess_info(pg_solver* s, int32_t* kept, int32_t* nstates, int32_t* offsets /* [4] */, double* coef /* [4] */,
+                             double* rr_plain, double* rr_taken);
 
 #ifdef __cplusplus
 }

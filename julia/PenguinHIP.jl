@@ -73,7 +73,8 @@ mutable struct pg_run_info
     steps::Int64; total_iters::Int64; t_final::Float64; extremum::Float64; solve_ms::Float64
     spmv_ms_total::Float64; spmv_launches::Int64; unconverged_steps::Int64; worst_relres::Float64
     spmv_lean_ms_total::Float64; spmv_lean_launches::Int64; poly_degree::Int64; half_exits::Int64; poly_xspace::Int64
-    pg_run_info() = new(0, 0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0.0, 0.0, 0, 0, 0, 0)
+    products::Int64; guess_states_read::Int64
+    pg_run_info() = new(0, 0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0.0, 0.0, 0, 0, 0, 0, 0, 0)
 end
 # kwargs... of solve_system! (src/solver.jl:158-188) -> the options of the device Krylov solve.  reltol defaults to 1e-12,
 # not IterativeSolvers' sqrt(eps): the parity target is the direct-solve path; warm_start and precond are not in the

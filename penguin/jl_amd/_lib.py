@@ -73,7 +73,7 @@ class pg_run_info(C.Structure):
                 ("solve_ms", C.c_double), ("spmv_ms_total", C.c_double), ("spmv_launches", C.c_int64),
                 ("unconverged_steps", C.c_int64), ("worst_relres", C.c_double), ("spmv_lean_ms_total", C.c_double),
                 ("spmv_lean_launches", C.c_int64), ("poly_degree", C.c_int64), ("half_exits", C.c_int64),
-                ("poly_xspace", C.c_int64)]
+                ("poly_xspace", C.c_int64), ("products", C.c_int64), ("guess_states_read", C.c_int64)]
 
 
 class pg_system_info(C.Structure):

@@ -585,6 +585,17 @@ class Solver:
         L.check(L.lib().pg_solver_get_row_scaling(self._h, C.c_int32(which), L.dptr(ds)))
         return ds[: self.system_info(which).n_own]
 
+    def guess_info(self) -> dict:
+        """The extrapolated start of the loop's quiet steps (pg_solver_guess_info): older states kept, the ones the next
+        step reads with their coefficients, and the sampled start residual without / with this step's extrapolation."""
+        kept, ns = C.c_int32(0), C.c_int32(0)
+        off = (C.c_int32 * 4)()
+        cf = (C.c_double * 4)()
+        ru, rw = C.c_double(0.0), C.c_double(0.0)
+        L.check(L.lib().pg_solver_guess_info(self._h, C.byref(kept), C.byref(ns), off, cf, C.byref(ru), C.byref(rw)))
+        return {"kept": kept.value, "offsets": list(off[: ns.value]), "coef": list(cf[: ns.value]), "rr_plain": ru.value,
+                "rr_taken": rw.value}
+
     def system_info(self, which: int = 0) -> L.pg_system_info:
         info = L.pg_system_info()
         L.check(L.lib().pg_solver_system_info(self._h, C.c_int32(which), C.byref(info)))

@@ -96,6 +96,13 @@ struct Config {
   int spmv_tile_units = 0;        // PG_SPMV_TILE_UNITS
   int spmv_blocks_per_cu = 0;     // PG_SPMV_BLOCKS_PER_CU (0: 4 slice kernel / 6 CSR kernels)
   bool halo_overlap = true;       // PG_HALO_OVERLAP
+  // the start of a quiet time step extrapolated from older states (pg_solver.hip, GuessArgs / k_guess_fit):
+  int guess_n = 4;                // PG_GUESS_STATES: older states read at most (0: off, <= 4)
+  int guess_depth = 7;            // PG_GUESS_DEPTH: older states kept to choose from (<= 7)
+  int guess_monitor = 256;        // PG_GUESS_MONITOR: the fit samples every n-th chunk of 256 rows
+  double guess_pass_cost = 0.34;  // PG_GUESS_PASS_COST: one more vector read of k_rhs_init_c, in products of the loop
+  double guess_gain = 0.8;        // PG_GUESS_GAIN: products saved per product the fit predicts (what is left after the
+                                  // extrapolation sits where the polynomial is weakest)
   bool speculate_product = true;  // PG_SPECULATE: pg_solver_run queues the next step's first product behind a solve's first batch
   int unit_order = 0;             // PG_SPMV_UNIT_ORDER: 0 by first row within (strip, plane); 1 units cut at common planes, window-major
                                   // (a block's four waves on four neighbouring lines; measured 59.0 vs 54.6 us per Horner launch: off)

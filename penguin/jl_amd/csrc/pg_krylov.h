@@ -14,6 +14,7 @@ struct KrylovWork {
   double* h_sc = nullptr;               // pinned host mirror of sc
   int grid = 1;
   DevBuf<unsigned> ticket;              // arrival counter of the in-launch scalar phases (pg_spmv.h)
+  double last_rate2 = 0.0;              // what one product took off log (r,r)_W in the previous polynomial solve (0: unknown)
   int last_iters = 0;                   // iterations of the previous solve (sizes the first launch batch)
   // degree of the preconditioner polynomial chosen from the previous solve on the same matrix (auto mode, pg_krylov.hip):
   // adapt_m products per application, adapt_h applications expected
@@ -59,6 +60,7 @@ struct SolveStats {
   int poly_degree = 0;      // products with Â per application of the preconditioned operator (0: plain iteration)
   int half_exit = 0;        // 1: the solve ended at the half step of its last iteration (counted as an iteration)
   int poly_xspace = 0;      // 1: x-space form of the preconditioned loop (Horner chains, no recovery), pg_krylov.hip
+  i64 products = 0;         // products with Â inside the solve (the caller's start product not counted)
   int polls = 0;            // host waits of the solve (1: it ended inside the first batch of queued launches)
 };
 

@@ -858,11 +858,13 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
   // test -- a Chebyshev step with BiCGStab's α, its residual test and, if the estimate was short, its continuation
   // (444 -> 546 steps/s at 512^3 against 3 x 9 in the same form).  No safety margin: a miss costs one more application
   // once, and the next estimate is made from that solve.
+  stats.products = (i64)(2 * stats.iters - stats.half_exit) * (m >= 2 ? m : 1);
   w.adapt_matrix = nullptr;
   if (adaptive && stats.converged && stats.iters > 0) {
     const double rr0 = w.h_sc[S_RR0], rr = w.h_sc[S_HALF] != 0.0 ? w.h_sc[S_RED4] : w.h_sc[S_RR], tol2 = w.h_sc[S_TOL2];
     const double P = (2.0 * stats.iters - stats.half_exit) * m;
     if (rr0 > tol2 && rr > 0.0 && rr < rr0 && tol2 > 0.0) {
+      w.last_rate2 = std::log(rr0 / rr) / P;
       const double margin = cfg.poly_margin;
       // x-space: a third of a product of slack -- with ONE application per solve a miss costs a whole second one, and the
       // estimate moves by a few tenths from step to step (200 steps at 512^3: 7 % of the solves missed without it, 548 steps/s;

@@ -72,6 +72,12 @@ struct pg_solver {
   // valid when that solve ended inside the batch (nothing moved z afterwards) and the next step runs on the same matrix
   bool spec_y_valid = false, spec_pending = false, hint_more_steps = false;
   const CsrMatrix* spec_matrix = nullptr;
+  // the last states z^{n-1}.. and their products ŷ^{n-1}.. = Â z^{n-1}.. (same-size buffers that trade places with z / y):
+  // the extrapolated start of a quiet step (GuessArgs).  hist_cnt of them are valid, all for the matrix of hist_de.
+  DevBuf<double> zh[8], yh[8], guess_coef, guess_partials;
+  DevBuf<unsigned> guess_ticket;
+  int hist_cnt = 0, hist_k = 0;     // (hist_k: the ring's depth the count refers to)
+  const void* hist_de = nullptr;
   bool initial_done = false;
   std::vector<DevBuf<double>> states;
   i64 steps_done = 0;
@@ -384,9 +390,35 @@ __global__ __launch_bounds__(BLOCK) void k_rhs_init(i64 n, i64 nvec, int scheme,
   if (threadIdx.x == 0) partials[2 * (size_t)gridDim.x + blockIdx.x] = tw;
 }
 
+// The start of a quiet step extrapolated from older states.  The solver keeps the last R states z^{n-1} .. z^{n-R} and their
+// products ŷ^{n-o} = Â z^{n-o} (ring buffers; no extra store: the buffers trade places with z / ŷ).  For a choice of
+// offsets o_j, d_j = z^{n-o_j} - z^n and q_j = Â d_j = ŷ^{n-o_j} - ŷ^n cost two reads each, and
+//   z_g = z^n + Σ c_j d_j   has the residual   r̂ = (b̂ - ŷ^n) - Σ c_j q_j   exactly (linearity; no product).
+// Which (at most KH) offsets and which c_j: the weighted least-squares fit of the PREVIOUS step's plain residual on its
+// q_j over a sample of the rows (k_guess_fit, which also weighs the products saved against the reads) -- a second pass for
+// this step's own fit would cost what the fit saves, and the c_j move slowly from step to step.  Crank-Nicolson's
+// alternating component makes the states of the SAME parity (offsets 1, 3, 5, 7) the useful ones, backward Euler the
+// nearest ones; the fit finds that out.  Only the start changes: the iteration and its stopping test see r̂ as ever.
+struct GuessArgs {
+  const double* zr[8];      // z^{n-1} .. z^{n-R}   (the last one is also znew: a lane reads its element before writing it)
+  const double* yr[8];      // ŷ^{n-1} ..
+  double* znew;             // z^{n+1}'s buffer: z_g for the rows of the loop, the solved value for a row alone on its diagonal
+  double* coef;             // [0..3] c_j, [4] how many, [5..8] their ring indices o_j - 1   (k_guess_fit); [13] += the number of
+                            // older states this launch read (a running total for the bench's byte count)
+};
+
+__device__ inline const double* ring_pick(const double* const (&r)[8], int i) {
+  const double* p = r[0];
+#pragma unroll
+  for (int q = 1; q < 8; ++q) p = i == q ? r[q] : p;   // (uniform: scalar selects, no private-memory copy of the argument)
+  return p;
+}
+
 // k_rhs_init for a COMPACT loop system (pg_reduce.hip, DiagElim): cmap[i] >= 0: the row stays, r = r̂ = p go to that index of
 // the compact vectors and count in the start sums; cmap[i] = -1 - e: the row is alone on its diagonal (entry e of gdiag /
 // delta): solved on the spot, left out of the sums.  b̂ is written for every row, (b̂,b̂)_W sums over all of them.
+// KH > 0: the extrapolated start above (out of place: the state written is g.znew), up to KH older states.
+template <int KH>
 __global__ __launch_bounds__(BLOCK) void k_rhs_init_c(i64 n, int scheme, const double* z,
                                                       const double* __restrict__ yhat, const double* __restrict__ ds,
                                                       const double* __restrict__ mass, const double* __restrict__ bconst,
@@ -396,19 +428,45 @@ __global__ __launch_bounds__(BLOCK) void k_rhs_init_c(i64 n, int scheme, const d
                                                       double* __restrict__ delta, int* __restrict__ flag, int stamp,
                                                       double* __restrict__ rhat, double* __restrict__ partials,
                                                       unsigned* __restrict__ ticket, double* __restrict__ sc, double reltol2,
-                                                      double abstol2) {
+                                                      double abstol2, GuessArgs g) {
   // (p = r = r̂ are NOT written: the first iteration reads r̂ for them, KrylovWork::p_in_rhat)
   // ticket != NULL: the solver's start phase (scalar reset, start sums, PH_INIT) by the last block of this launch -- the
   // caller knows that nothing will touch the start sums afterwards (no diagonal row can move: diag_fix is not launched)
   __shared__ double s_red[BLOCK / 64];
   double acc = 0.0, accb = 0.0, accw = 0.0;
+  double cj[KH > 0 ? KH : 1];
+  const double* zo[KH > 0 ? KH : 1];
+  const double* yo[KH > 0 ? KH : 1];
+  int ku = 0;
+  if (KH > 0) {
+    ku = min(KH, (int)g.coef[4]);
+#pragma unroll
+    for (int j = 0; j < KH; ++j) {
+      const int sel = j < ku ? (int)g.coef[5 + j] : 0;
+      cj[j] = j < ku ? g.coef[j] : 0.0;
+      zo[j] = ring_pick(g.zr, sel);
+      yo[j] = ring_pick(g.yr, sel);
+    }
+  }
   int moved = 0;
-  double* zw = const_cast<double*>(z);   // (a lane writes only elements it has read itself)
-  auto one = [&](i64 i, double zi, double yh, double d, double ms, double bc, bool fx, bool blk, double bold, int c, double& bi) {
+  double* zw = KH > 0 ? g.znew : const_cast<double*>(z);   // (in place: a lane writes only elements it has read itself)
+  // zh / yv: the row's entries of the chosen older states and products
+  auto one = [&](i64 i, double zi, double yh, double d, double ms, double bc, bool fx, bool blk, double bold, int c, double& bi,
+                 const double* zh, const double* yv) {
     double ri;
     rhs_init_one(scheme, zi, yh, d, ms, bc, fx, blk, bold, bi, ri);
     accb += (d * bi) * (d * bi);
     if (c >= 0) {
+      if (KH > 0) {
+        double zg = zi, corr = 0.0;
+#pragma unroll
+        for (int j = 0; j < KH; ++j) {
+          corr += cj[j] * (yv[j] - yh);      // (cj = 0, yv = yh, zh = zi beyond ku)
+          zg += cj[j] * (zh[j] - zi);
+        }
+        ri -= corr;
+        zw[i] = zg;
+      }
       rhat[c] = ri;
       acc += ri * ri;
       accw += (d * ri) * (d * ri);
@@ -418,7 +476,7 @@ __global__ __launch_bounds__(BLOCK) void k_rhs_init_c(i64 n, int scheme, const d
       const int e = -1 - c;
       const double dl = ri / gdiag[e];
       delta[e] = dl;
-      if (dl != 0.0) zw[i] = zi + dl;
+      if (KH > 0 || dl != 0.0) zw[i] = zi + dl;
       if (fabs(dl) > 1e-12 * fabs(zi)) moved = 1;
     }
   };
@@ -426,6 +484,7 @@ __global__ __launch_bounds__(BLOCK) void k_rhs_init_c(i64 n, int scheme, const d
   const i64 npair = (n + 1) / 2;
   for (i64 q = blockIdx.x * (i64)BLOCK + threadIdx.x; q < npair; q += (i64)gridDim.x * BLOCK) {
     const i64 i = 2 * q;
+    double zh0[KH > 0 ? KH : 1], zh1[KH > 0 ? KH : 1], yv0[KH > 0 ? KH : 1], yv1[KH > 0 ? KH : 1];
     if (i + 1 < n) {
       const rd2_t yh = __builtin_nontemporal_load(reinterpret_cast<const rd2_t*>(yhat + i));
       const rd2_t d = __builtin_nontemporal_load(reinterpret_cast<const rd2_t*>(ds + i));
@@ -435,18 +494,37 @@ __global__ __launch_bounds__(BLOCK) void k_rhs_init_c(i64 n, int scheme, const d
       const ruc2_t fx = *reinterpret_cast<const ruc2_t*>(fixed + i);
       const ruc2_t bk = *reinterpret_cast<const ruc2_t*>(isblk + i);
       const int c0 = cmap[i], c1 = cmap[i + 1];
+      if (KH > 0) {
+#pragma unroll
+        for (int j = 0; j < KH; ++j) {
+          rd2_t a = zz, y2 = yh;
+          if (j < ku) {
+            a = *reinterpret_cast<const rd2_t*>(zo[j] + i);
+            y2 = *reinterpret_cast<const rd2_t*>(yo[j] + i);
+          }
+          zh0[j] = a.x; zh1[j] = a.y; yv0[j] = y2.x; yv1[j] = y2.y;
+        }
+      }
       rd2_t bold;
       bold.x = 0.0; bold.y = 0.0;
       if (bk.x | bk.y) bold = *reinterpret_cast<const rd2_t*>(b + i);
       rd2_t bi;
       double b0, b1;
-      one(i, zz.x, yh.x, d.x, ms.x, bc.x, fx.x != 0, bk.x != 0, bold.x, c0, b0);
-      one(i + 1, zz.y, yh.y, d.y, ms.y, bc.y, fx.y != 0, bk.y != 0, bold.y, c1, b1);
+      one(i, zz.x, yh.x, d.x, ms.x, bc.x, fx.x != 0, bk.x != 0, bold.x, c0, b0, zh0, yv0);
+      one(i + 1, zz.y, yh.y, d.y, ms.y, bc.y, fx.y != 0, bk.y != 0, bold.y, c1, b1, zh1, yv1);
       bi.x = b0; bi.y = b1;
       __builtin_nontemporal_store(bi, reinterpret_cast<rd2_t*>(b + i));
     } else if (i < n) {
+      const double zi = z[i], yh = yhat[i];
+      if (KH > 0) {
+#pragma unroll
+        for (int j = 0; j < KH; ++j) {
+          zh0[j] = j < ku ? zo[j][i] : zi;
+          yv0[j] = j < ku ? yo[j][i] : yh;
+        }
+      }
       double b0;
-      one(i, z[i], yhat[i], ds[i], mass[i], bconst[i], fixed[i] != 0, isblk[i] != 0, isblk[i] ? b[i] : 0.0, cmap[i], b0);
+      one(i, zi, yh, ds[i], mass[i], bconst[i], fixed[i] != 0, isblk[i] != 0, isblk[i] ? b[i] : 0.0, cmap[i], b0, zh0, yv0);
       b[i] = b0;
     }
   }
@@ -481,6 +559,192 @@ __global__ __launch_bounds__(BLOCK) void k_rhs_init_c(i64 n, int scheme, const d
     pg::derive(pg::PH_INIT, sc);
     // (every block's atomicMax on the flag was drained before it drew its ticket)
     sc[pg::S_MOVED] = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == stamp ? 1.0 : 0.0;
+    if (KH > 0) g.coef[13] += (double)ku;
+  }
+}
+
+// The fit behind the extrapolated start (GuessArgs): over every `stride`-th chunk of BLOCK rows (a few hundred blocks share
+// them), the normal equations of
+//   min || r_u - Σ c_j q_j ||_W ,  r_u = b̂ - ŷ^n (the plain start residual), q_j = ŷ^{n-j-1} - ŷ^n, j < avail <= RM
+// (Gram matrix, right-hand side, (r_u,r_u)_W and (r,r)_W of the start actually taken).  The last block then tries every
+// subset of at most kmax of the avail older states -- one thread each, a Cholesky factorisation of at most 4 x 4 -- and
+// keeps the one whose saving,  gain · log((r_u,r_u) / (left,left)) / rate2  products, exceeds its reads (2 passes per
+// state, pass_cost products each) by most: offsets and coefficients for the NEXT step.
+constexpr int GUESS_RM = 7;
+constexpr int GUESS_NS = GUESS_RM * (GUESS_RM + 1) / 2 + GUESS_RM + 2;
+struct GuessFit {
+  const double* yr[8];
+  double* partials;       // GUESS_NS * grid
+  unsigned* ticket;
+  double* coef;           // [0..3] c_j, [4] how many, [5..8] ring indices, [9] (r_u,r_u)_W, [10] (r,r)_W, [11] the fit's left-over
+  int stride, avail, kmax;
+  double rate2, pass_cost, gain;
+};
+
+__device__ inline int guess_tri(int j, int l) { return j * GUESS_RM - j * (j - 1) / 2 + (l - j); }   // l >= j
+
+__global__ __launch_bounds__(BLOCK) void k_guess_fit(i64 n, const int* __restrict__ cmap, const double* __restrict__ ds,
+                                                     const double* __restrict__ b, const double* __restrict__ yn,
+                                                     const double* __restrict__ rhat, GuessFit f) {
+  constexpr int RM = GUESS_RM, NS = GUESS_NS;
+  __shared__ double s_red[BLOCK / 64];
+  __shared__ double s_g[NS];
+  __shared__ double s_left[128], s_net[128];
+  __shared__ double s_c[128][4];
+  double gs[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) gs[j] = 0.0;
+  const i64 nchunk = (n + BLOCK - 1) / BLOCK;
+  for (i64 ch = (i64)blockIdx.x * f.stride; ch < nchunk; ch += (i64)gridDim.x * f.stride) {
+    const i64 i = ch * BLOCK + threadIdx.x;
+    const int c = i < n ? cmap[i] : -1;
+    if (c < 0) continue;
+    const double d = ds[i], w = d * d, y0 = yn[i], ru = b[i] - y0, ra = rhat[c];
+    double q[RM];
+#pragma unroll
+    for (int j = 0; j < RM; ++j) q[j] = j < f.avail ? f.yr[j][i] - y0 : 0.0;
+    int t = 0;
+#pragma unroll
+    for (int j = 0; j < RM; ++j)
+#pragma unroll
+      for (int l = j; l < RM; ++l) gs[t++] += w * q[j] * q[l];
+#pragma unroll
+    for (int j = 0; j < RM; ++j) gs[t++] += w * q[j] * ru;
+    gs[t++] += w * ru * ru;
+    gs[t] += w * ra * ra;
+  }
+  {
+    __shared__ double s_w[BLOCK / 64][NS];     // all the sums through one barrier
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (the shuffle tree level by level over all the sums: NS independent shuffles in flight instead of one chain each)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int j = 0; j < NS; ++j) gs[j] += __shfl_down(gs[j], off, 64);
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < NS; ++j) s_w[wave][j] = gs[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < NS) {
+      double a = 0.0;
+#pragma unroll
+      for (int q = 0; q < BLOCK / 64; ++q) a += s_w[q][threadIdx.x];
+      pg::store_partial(f.partials + (size_t)threadIdx.x * gridDim.x + blockIdx.x, a);
+    }
+  }
+  if (!pg::last_block_arrives(f.ticket, gridDim.x, s_red)) return;
+  // the blocks' partial sums, in a fixed order: a wave per sum, a lane per block (at most 128 blocks), shuffle tree -- every
+  // load of a wave in flight before the first is used, the trees level by level
+  {
+    constexpr int PW = (NS + BLOCK / 64 - 1) / (BLOCK / 64);   // sums per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, G = (int)gridDim.x;
+    double a0[PW], a1[PW];
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+      const int sl = wave + k * (BLOCK / 64);
+      a0[k] = (sl < NS && lane < G) ? pg::load_partial(f.partials + (size_t)sl * G + lane) : 0.0;
+      a1[k] = (sl < NS && lane + 64 < G) ? pg::load_partial(f.partials + (size_t)sl * G + lane + 64) : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < PW; ++k) a0[k] += a1[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int k = 0; k < PW; ++k) a0[k] += __shfl_down(a0[k], off, 64);
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < PW; ++k) {
+        const int sl = wave + k * (BLOCK / 64);
+        if (sl < NS) s_g[sl] = a0[k];
+      }
+    }
+  }
+  __syncthreads();
+  const double ru = s_g[NS - 2], rw = s_g[NS - 1];
+  // one subset of the older states per thread: bit j of the thread number = state j
+  if (threadIdx.x < 128) {
+    const int mask = threadIdx.x, m = __popc(mask);
+    double left = ru, cc[4] = {0.0, 0.0, 0.0, 0.0};
+    if (mask != 0 && m <= f.kmax && m <= 4 && (mask >> f.avail) == 0 && ru > 0.0) {
+      int idx[4] = {0, 0, 0, 0};
+      for (int j = 0, a = 0; j < RM; ++j) if (mask >> j & 1) { if (a < 4) idx[a] = j; ++a; }
+      double L[4][4], wv[4];
+      bool ok = true;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        wv[a] = 0.0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) L[a][e] = 0.0;
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        if (a >= m || !ok) continue;
+        const double g0 = s_g[guess_tri(idx[a], idx[a])];
+        double dj = g0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (e < a) dj -= L[a][e] * L[a][e];
+        if (!(g0 > 0.0) || !(dj > 1e-12 * g0)) { ok = false; continue; }   // (collinear with the ones before it)
+        const double lj = sqrt(dj);
+        L[a][a] = lj;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+          if (l <= a || l >= m) continue;
+          double v = s_g[guess_tri(idx[a], idx[l])];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (e < a) v -= L[l][e] * L[a][e];
+          L[l][a] = v / lj;
+        }
+        double v = s_g[RM * (RM + 1) / 2 + idx[a]];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (e < a) v -= L[a][e] * wv[e];
+        wv[a] = v / lj;
+        left -= wv[a] * wv[a];
+      }
+      if (ok) {
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa) {            // Lᵀ c = w
+          const int a = 3 - aa;
+          if (a >= m) continue;
+          double v = wv[a];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (e > a && e < m) v -= L[e][a] * cc[e];
+          cc[a] = v / L[a][a];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) ok = ok && isfinite(cc[a]) && fabs(cc[a]) < 256.0;
+      }
+      if (!ok) { left = ru; cc[0] = cc[1] = cc[2] = cc[3] = 0.0; }
+      if (!(left > 1e-30 * ru)) left = 1e-30 * ru;
+    }
+    s_left[threadIdx.x] = left;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) s_c[threadIdx.x][a] = cc[a];
+    // what the subset nets: the products its fit saves less its reads (a start that the extrapolation made worse: none
+    // next time)
+    const bool live = ru > 0.0 && f.rate2 > 0.0 && rw <= ru * (1.0 + 1e-12) && left < ru;
+    s_net[threadIdx.x] = live ? f.gain * log(ru / left) / f.rate2 - 2.0 * m * f.pass_cost : 0.0;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    // the subset that nets most (ties: the lower number), by the first wave
+    int pick = threadIdx.x;
+    double best = s_net[pick];
+    if (s_net[pick + 64] > best) { best = s_net[pick + 64]; pick += 64; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ob = __shfl_down(best, off, 64);
+      const int op = __shfl_down(pick, off, 64);
+      if (ob > best || (ob == best && op < pick)) { best = ob; pick = op; }
+    }
+    if (!(best > 0.0)) pick = 0;
+    if (threadIdx.x != 0) return;
+    int a = 0;
+    for (int j = 0; j < RM; ++j)
+      if (pick >> j & 1) { f.coef[a] = s_c[pick][a]; f.coef[5 + a] = (double)j; ++a; }
+    f.coef[4] = (double)a;
+    for (; a < 4; ++a) { f.coef[a] = 0.0; f.coef[5 + a] = 0.0; }
+    f.coef[9] = ru; f.coef[10] = rw; f.coef[11] = pick ? s_left[pick] : ru;
   }
 }
 
@@ -936,10 +1200,69 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
       const bool single = ctx().nranks == 1 && !ctx().comm;
       const bool same_data = DE.snapped_version == s->bconst_version;
       const bool quiet = same_data && single;
-      hipLaunchKernelGGL(k_rhs_init_c, dim3(w.grid), dim3(BLOCK), 0, stream, n, scheme, s->z.p, s->y.p, A.ds.p, s->mass.p, s->bconst.p,
-                         s->fixed.p, A.isblk.p, DE.cmap.p, s->b.p, (const double*)DE.gdiag.p, DE.delta.p, DE.flag.p, stamp, w.rhat.p, w.partials.p,
-                         quiet ? w.ticket.p : nullptr, w.sc.p, o.reltol * o.reltol, o.abstol * o.abstol);
+      // extrapolated start (GuessArgs): quiet steps only -- the rows alone on their diagonal rest, so the differences of the
+      // kept states are differences of the loop's rows alone and the products ŷ^{n-o} combine linearly
+      const Config& cfg = config();
+      const int KH = quiet ? cfg.guess_n : 0;                      // older states read at most
+      const int R = KH > 0 ? cfg.guess_depth : 0;                  // older states kept
+      const int hist_had = (s->hist_de == &DE && s->hist_k == R) ? s->hist_cnt : 0;
+      s->hist_cnt = 0;    // (stands again below once this step has gone the quiet way to its end)
+      GuessArgs ga{};
+      if (KH > 0) {
+        const i64 nva = s->z.n;
+        if (s->guess_coef.n == 0) { s->guess_coef.alloc(16); s->guess_coef.zero(); s->guess_ticket.alloc(1); s->guess_ticket.zero(); }
+        for (int j = 0; j < R; ++j) {
+          if (s->zh[j].n != nva) { s->zh[j].alloc(nva); s->zh[j].zero(); }
+          if (s->yh[j].n != nva) { s->yh[j].alloc(nva); s->yh[j].zero(); }
+        }
+        if (hist_had == 0) PG_HIP(hipMemsetAsync(s->guess_coef.p, 0, 12 * sizeof(double), stream));   // (the counters stay)
+        for (int j = 0; j < 8; ++j) { ga.zr[j] = s->zh[std::min(j, R - 1)].p; ga.yr[j] = s->yh[std::min(j, R - 1)].p; }
+        ga.znew = s->zh[R - 1].p;
+        ga.coef = s->guess_coef.p;
+      }
+#define PG_RHS_INIT_C(KHV)                                                                                                        \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rhs_init_c<KHV>), dim3(w.grid), dim3(BLOCK), 0, stream, n, scheme, s->z.p, s->y.p, A.ds.p,   \
+                     s->mass.p, s->bconst.p, s->fixed.p, A.isblk.p, DE.cmap.p, s->b.p, (const double*)DE.gdiag.p, DE.delta.p,     \
+                     DE.flag.p, stamp, w.rhat.p, w.partials.p, quiet ? w.ticket.p : nullptr, w.sc.p, o.reltol * o.reltol,          \
+                     o.abstol * o.abstol, ga)
+      switch (KH) {
+        case 1: PG_RHS_INIT_C(1); break;
+        case 2: PG_RHS_INIT_C(2); break;
+        case 3: PG_RHS_INIT_C(3); break;
+        case 4: PG_RHS_INIT_C(4); break;
+        default: PG_RHS_INIT_C(0); break;
+      }
+#undef PG_RHS_INIT_C
       PG_HIP(hipGetLastError());
+      if (KH > 0) {
+        if (hist_had > 0) {
+          // next step's offsets and coefficients, from this step's plain residual (k_guess_fit)
+          GuessFit gf{};
+          for (int j = 0; j < 8; ++j) gf.yr[j] = s->yh[std::min(j, R - 1)].p;
+          const i64 nchunk = (n + BLOCK - 1) / BLOCK;
+          gf.stride = (int)std::max<i64>(1, std::min<i64>(cfg.guess_monitor, nchunk / 128));   // (small systems: every chunk)
+          const int gfit = (int)std::min<i64>(128, (nchunk + gf.stride - 1) / gf.stride);
+          if (s->guess_partials.n != (i64)GUESS_NS * gfit) s->guess_partials.alloc((i64)GUESS_NS * gfit);
+          gf.partials = s->guess_partials.p;
+          gf.ticket = s->guess_ticket.p;
+          gf.coef = s->guess_coef.p;
+          gf.avail = std::min(hist_had, GUESS_RM);
+          gf.kmax = KH;
+          gf.rate2 = w.last_rate2;
+          gf.pass_cost = cfg.guess_pass_cost;
+          gf.gain = cfg.guess_gain;
+          hipLaunchKernelGGL(k_guess_fit, dim3(gfit), dim3(BLOCK), 0, stream, n, (const int*)DE.cmap.p, (const double*)A.ds.p,
+                             (const double*)s->b.p, (const double*)s->y.p, (const double*)w.rhat.p, gf);
+          PG_HIP(hipGetLastError());
+        }
+        // the buffers trade places (stream order keeps the kernels above ahead of whatever writes them next): the state
+        // written becomes z, z and ŷ become the newest kept pair, the oldest ŷ is the next product's output
+        double* znew = s->zh[R - 1].p;
+        double* yspare = s->yh[R - 1].p;
+        for (int j = R - 1; j > 0; --j) { s->zh[j].p = s->zh[j - 1].p; s->yh[j].p = s->yh[j - 1].p; }
+        s->zh[0].p = s->z.p; s->z.p = znew;
+        s->yh[0].p = s->y.p; s->y.p = yspare;
+      }
       if (!same_data) diag_fix(DE, s->nb, s->slab, stamp, !single, w.rhat.p, w.partials.p, w.grid, stream);
       w.start_folded = quiet;
       DE.snapped_version = s->bconst_version;
@@ -984,6 +1307,20 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
         krylov_solve(A, s->nb, s->slab, s->b.p, s->ysol.p, w, o, st, s->z.p, s->y.p, false);
         std::swap(s->z.p, s->ysol.p);
         st.iters += first.iters;
+        st.products += first.products;
+      }
+      else if (KH > 0) {
+        if (config().debug) {
+          double hc[16];
+          s->guess_coef.download(hc, 16);
+          fprintf(stderr, "[pg_solver] extrapolated start: %d older states kept; sampled (r,r)_W plain %.3e, taken %.3e; next step: %d states",
+                  hist_had, hc[9], hc[10], (int)hc[4]);
+          for (int j = 0; j < (int)hc[4]; ++j) fprintf(stderr, " z(n-%d)*%.4f", (int)hc[5 + j] + 1, hc[j]);
+          fprintf(stderr, ", fit leaves %.3e\n", hc[11]);
+        }
+        s->hist_cnt = std::min(hist_had + 1, R);
+        s->hist_k = R;
+        s->hist_de = &DE;
       }
       s->x_valid = false;
       s->steps_done += 1;
@@ -1336,6 +1673,8 @@ int32_t pg_solver_run(pg_solver* s, double Tend, int32_t scheme, const pg_krylov
   const auto t_run0 = std::chrono::steady_clock::now();
   const double wait0 = pg::g_host_wait_us;
   PG_HIP(hipEventRecord(ev.e0, stream));
+  double used0 = 0.0;               // older states read by the extrapolated starts so far (device counter, GuessArgs)
+  if (s->guess_coef.n >= 16) s->guess_coef.download(&used0, 1, 13);
   SolveStats tot;
   i64 steps = 0, iters = 0, unconverged = 0;
   double worst = 0.0;
@@ -1345,6 +1684,7 @@ int32_t pg_solver_run(pg_solver* s, double Tend, int32_t scheme, const pg_krylov
     tot.poly_degree = st.poly_degree;
     tot.poly_xspace = st.poly_xspace;
     tot.half_exit += st.half_exit;
+    tot.products += st.products;
     if (!st.converged) ++unconverged;
     if (st.bnorm > 0.0) worst = std::max(worst, st.resnorm / st.bnorm);
   };
@@ -1389,6 +1729,13 @@ int32_t pg_solver_run(pg_solver* s, double Tend, int32_t scheme, const pg_krylov
     info->poly_degree = tot.poly_degree;
     info->poly_xspace = tot.poly_xspace;
     info->half_exits = tot.half_exit;
+    info->products = tot.products;
+    info->guess_states_read = 0;
+    if (s->guess_coef.n >= 16) {
+      double hc[16];
+      s->guess_coef.download(hc, 16);
+      info->guess_states_read = (int64_t)(hc[13] - used0);
+    }
   }
   PG_API_END
 }
@@ -1582,6 +1929,26 @@ int32_t pg_debug_scale_diagonal_rows(pg_solver* s, double factor) {
   PG_HIP(hipStreamSynchronize(ctx().stream));
   s->x_valid = false;
   s->spec_y_valid = false;
+  PG_API_END
+}
+
+int32_t pg_solver_guess_info(pg_solver* s, int32_t* kept, int32_t* nstates, int32_t* offsets, double* coef, double* rr_plain,
+                             double* rr_taken) {
+  PG_API_BEGIN
+  require_init();
+  PG_REQUIRE(s && kept && nstates && offsets && coef && rr_plain && rr_taken, "pg_solver_guess_info: NULL argument");
+  *kept = s->hist_cnt;
+  *nstates = 0;
+  *rr_plain = *rr_taken = 0.0;
+  for (int j = 0; j < 4; ++j) { offsets[j] = 0; coef[j] = 0.0; }
+  if (s->guess_coef.n >= 16 && s->hist_cnt > 0) {
+    double hc[16];
+    s->guess_coef.download(hc, 16);
+    *nstates = (int32_t)hc[4];
+    for (int j = 0; j < *nstates && j < 4; ++j) { offsets[j] = (int32_t)hc[5 + j] + 1; coef[j] = hc[j]; }
+    *rr_plain = hc[9];
+    *rr_taken = hc[10];
+  }
   PG_API_END
 }
 

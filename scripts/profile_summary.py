@@ -12,6 +12,7 @@ the median of the launches that did work."""
 import collections
 import csv
 import glob
+import pathlib
 import json
 import re
 import shutil
@@ -83,7 +84,8 @@ except Exception as e:
 # ---- PMC passes: per kernel medians; HBM bytes of the chain launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB; the guide's gfx950
 # correction: FETCH_SIZE tallies 128-byte requests as 64)
 pm = collections.defaultdict(dict)
-for i, d in enumerate(sorted(glob.glob(str(out / f"pmc_{tag}_*/"))), start=1):
+pmc_dirs = sorted(d for d in glob.glob(str(out / f"pmc_{tag}_*/")) if re.fullmatch(rf"pmc_{re.escape(tag)}_\d+", pathlib.Path(d).name))
+for i, d in enumerate(pmc_dirs, start=1):
     lines = []
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         by = collections.defaultdict(lambda: collections.defaultdict(list))

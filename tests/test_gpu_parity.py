@@ -889,6 +889,37 @@ def test_forms_of_the_preconditioned_loop_match_the_oracle(env):
     assert r.returncode == 0 and "forms ok" in r.stdout, (env, r.stdout[-2000:], r.stderr[-4000:])
 
 
+@pytest.mark.parametrize("scheme", ["CN", "BE"])
+def test_extrapolated_start_of_quiet_steps_keeps_the_solution(pj, scheme):
+    """A long run with constant data: from the third quiet step on the loop starts each solve from an extrapolation of older
+    states (pg_solver.hip, GuessArgs / k_guess_fit).  Only the start changes -- every state still matches the oracle's
+    direct solves at the north-star tolerance -- and the fit does what it is there for: the start residual taken is far
+    below the plain one."""
+    n, steps = 24, 26
+    M = (n + 1) ** 3
+    dt = 0.75 * (4.0 / n) ** 2
+    mesh, omesh = pj.Mesh((n,) * 3, (4.0,) * 3), po.Mesh((n,) * 3, (4.0,) * 3)
+    cap = pj.Capacity(pj.Sphere((2.01, 2.01, 2.01), 1.0), mesh)
+    ocap = oracle_capacity_from_product(cap, omesh)
+    ph = pj.Phase(cap, pj.DiffusionOps(cap), 0.0, 1.0)       # constant data: the loop's quiet steps
+    oph = po.Phase(ocap, po.make_diffusion_ops(ocap), lambda x, y, z, t: 0.0, lambda x, y, z: 1.0)
+    bcb, obcb = pj.BorderConditions({k: pj.Dirichlet(1.0) for k in HEAT_BORDERS}), po.BorderConditions({k: po.Dirichlet(1.0) for k in HEAT_BORDERS})
+    bci, obci = pj.Dirichlet(1.0), po.Dirichlet(1.0)
+    s = pj.DiffusionUnsteadyMono(ph, bcb, bci, dt, np.zeros(2 * M), "BE")
+    so = po.DiffusionUnsteadyMono(oph, obcb, obci, dt, np.zeros(2 * M), "BE")
+    pj.solve_DiffusionUnsteadyMono_b(s, ph, dt, steps * dt, bcb, bci, scheme, reltol=1e-13)
+    po.solve_DiffusionUnsteadyMono(so, oph, dt, steps * dt, obcb, obci, scheme, method="\\")
+    assert len(s.states) == len(so.states) >= steps
+    worst = max(rel_l2(a, b) for a, b in zip(s.states, so.states))
+    assert worst <= TOL_T, worst
+    g = s.guess_info()
+    if pj.config_string().find("guess_states=0") >= 0:
+        pytest.skip("extrapolated start switched off (PG_GUESS_STATES=0)")
+    assert g["kept"] >= 4 and len(g["offsets"]) >= 2, g
+    assert g["rr_taken"] < 1e-2 * g["rr_plain"], g
+    assert g["offsets"][0] == 1 and all(1 <= o <= 7 for o in g["offsets"]), g
+
+
 # ------------------------------------------------------------------------------------ steady diffusion (SURVEY §8f.1)
 def test_steady_monophasic_reference_test(pj):
     """test/solver/diffusion_test.jl:5-26: 20^2, circle r=0.5 at (0.5,0.5), Dirichlet(1) everywhere, f = 0."""
