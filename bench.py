@@ -265,6 +265,7 @@ def main() -> None:
             "rows_global": n_rows_g, "nnz_global": nnz_g, "rows_rank0": n_rows, "nnz_rank0": nnz,
             "krylov_iters_per_step": iters, "krylov_iters_per_step_counting_half_steps_as_half": iters_eff,
             "polynomial_preconditioner_degree": m,
+            "solves_that_needed_a_second_application": int(2 * run.total_iters - run.half_exits - run.steps),
             "products_per_step_in_the_solves": getattr(run, "products", 0) / max(run.steps, 1),
             "start_of_each_solve": "the previous state, extrapolated from older states where a least-squares fit says it pays "
                                    "(PG_GUESS_STATES, pg_solver_guess_info): same stopping test, fewer products",

@@ -81,6 +81,7 @@ struct Config {
   double poly_margin = 1.0;       // PG_POLY_MARGIN
   double poly_slack = -1.0;       // PG_POLY_SLACK (< 0: 0.3 products in the x-space form, 0 otherwise)
   int poly_hist = 3;              // PG_POLY_HIST
+  bool poly_trend = true;         // PG_POLY_TREND: the degree estimate follows the trend of the last estimates
   int poly_maxdeg = 0;            // PG_POLY_MAXDEG (0: 32 x-space / 10 y-space)
   bool recovery_horner = true;    // PG_RECOVERY_HORNER (y-space form)
   int profile_sample = 3;         // PG_PROFILE_SAMPLE

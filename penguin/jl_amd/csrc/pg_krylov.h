@@ -22,6 +22,10 @@ struct KrylovWork {
   int adapt_m = 0, adapt_h = 0;
   const void* need_matrix = nullptr;    // the last estimates of the products a solve on that matrix needs (newest first)
   double need_hist[3] = {0.0, 0.0, 0.0};
+  const void* fail_matrix = nullptr;    // x-space, one application per solve: the last degree that fell short (with the
+  int fail_deg = 0, good_deg = 0;       // log of start residual / tolerance it fell short at) and the last that sufficed
+  double fail_L = 0.0;
+  int fail_wait = 0, fail_backoff = 1;  // solves left before that degree may be tried again; doubles when it falls short again
   // set by the caller around one krylov_solve: the system is a compact image of the caller's (pg_reduce.hip, DiagElim) and
   // x is the caller's FULL vector -- the solution update x += q(Â)y lands at x[scatter[i]].  Needs the polynomial path.
   const int* scatter = nullptr;

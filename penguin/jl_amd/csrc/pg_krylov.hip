@@ -878,7 +878,16 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
       if (w.need_matrix != &A) { w.need_matrix = &A; w.need_hist[0] = w.need_hist[1] = w.need_hist[2] = 0.0; }
       w.need_hist[2] = w.need_hist[1]; w.need_hist[1] = w.need_hist[0]; w.need_hist[0] = need_now;
       double need = need_now;
-      if (xspace) for (int q = 1; q < hist_n; ++q) need = std::max(need, std::min(w.need_hist[q], need_now + 0.6));   // (wobble, not trend)
+      // The estimates of a run move along a trend (the start residual falls from step to step -- by a third of a product per
+      // step while the extrapolated start of pg_solver.hip settles in) with a wobble of a few tenths on top.  Trend: half the
+      // change over the last two steps; the older estimates are carried along it before the largest is taken (the wobble
+      // guard), and the next solve gets the value the trend predicts for it.  (Without the trend the guard alone kept the
+      // degree 0.6 + a step's change above what was needed all the way down: one product per step in the bench window.)
+      double trend = 0.0;
+      if (xspace && cfg.poly_trend && hist_n >= 3 && w.need_hist[2] > 0.0) trend = std::max(-0.5, std::min(0.2, 0.5 * (need_now - w.need_hist[2])));
+      if (xspace) for (int q = 1; q < hist_n; ++q)
+        if (w.need_hist[q] > 0.0) need = std::max(need, std::min(w.need_hist[q] + q * trend, need_now + 0.6));   // (wobble, not trend)
+      need += trend;
       double best = 1e300;
       for (int h = 1; h <= 16; ++h) {
         const int mm = (int)std::ceil(need / h);
@@ -890,6 +899,31 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
         if (cost < best) { best = cost; w.adapt_m = mm; w.adapt_h = h; }
       }
       if (best < 1e300) w.adapt_matrix = &A;
+      // One application per solve (x-space): what a degree achieves is not monotone in the degree -- the residual polynomial
+      // at the few eigenvalues that carry an extrapolated start's residual goes like |cos(m θ)| on top of the Chebyshev
+      // bound, so the estimate made at a lucky degree can undershoot by a product (512^3, step 96: 12, 11, 10 all reached
+      // the same residual, 9 fell short; the loop then cycled 11, 11, 10, 9+9).  A degree that fell short is therefore not
+      // tried again for a while -- twice what the miss cost, in steps (a miss costs about m + 3 products, a degree less saves
+      // one per step), doubled each time the same degree falls short again -- unless the problem has become easier by a
+      // product's worth per degree first; and the solve after a miss goes back to the degree that last sufficed.
+      if (xspace && stats.iters == 1) {
+        const double Lnow = std::log(rr0 / tol2);
+        if (w.fail_matrix != &A) { w.fail_matrix = &A; w.fail_deg = 0; w.good_deg = 0; w.fail_wait = 0; w.fail_backoff = 1; }
+        if (w.fail_wait > 0) --w.fail_wait;
+        if (stats.half_exit) w.good_deg = m;
+        else {
+          w.fail_backoff = (m == w.fail_deg) ? std::min(w.fail_backoff * 2, 64) : 1;
+          w.fail_deg = m; w.fail_L = Lnow;
+          w.fail_wait = 2 * w.fail_backoff * (m + 3);
+        }
+        if (best < 1e300 && w.adapt_h == 1) {
+          if (!stats.half_exit && w.good_deg > m) w.adapt_m = std::max(m + 1, std::min(w.adapt_m, w.good_deg));
+          const double per_product = std::max(1.0, w.last_rate2);
+          if (w.fail_deg > 0 && w.fail_wait > 0 && w.adapt_m <= w.fail_deg &&
+              Lnow > w.fail_L - per_product * (w.fail_deg - w.adapt_m + 1))
+            w.adapt_m = w.fail_deg + 1;
+        }
+      }
       if (cfg.debug) fprintf(stderr, "[pg_krylov] degree %d used %g products, needed %.1f -> next: %d applications of degree %d\n", m, P, need, w.adapt_h, w.adapt_m);
     }
   }
