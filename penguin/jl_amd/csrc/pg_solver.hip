@@ -537,6 +537,7 @@ __global__ __launch_bounds__(BLOCK) void k_rhs_init_c(i64 n, int scheme, const d
       partials[blockIdx.x] = t;
       partials[gridDim.x + blockIdx.x] = tb;
       partials[2 * (size_t)gridDim.x + blockIdx.x] = tw;
+      if (KH > 0 && blockIdx.x == 0) g.coef[13] += (double)ku;
     }
     return;
   }
@@ -579,88 +580,16 @@ struct GuessFit {
   double* coef;           // [0..3] c_j, [4] how many, [5..8] ring indices, [9] (r_u,r_u)_W, [10] (r,r)_W, [11] the fit's left-over
   int stride, avail, kmax;
   double rate2, pass_cost, gain;
+  double* sums;           // several ranks: where the GUESS_NS local sums go (NULL: one rank, the launch decides itself)
 };
 
 __device__ inline int guess_tri(int j, int l) { return j * GUESS_RM - j * (j - 1) / 2 + (l - j); }   // l >= j
 
-__global__ __launch_bounds__(BLOCK) void k_guess_fit(i64 n, const int* __restrict__ cmap, const double* __restrict__ ds,
-                                                     const double* __restrict__ b, const double* __restrict__ yn,
-                                                     const double* __restrict__ rhat, GuessFit f) {
+// the choice among the subsets (k_guess_fit's doc), from the sums s_g (GUESS_NS of them, in LDS), by the whole block
+__device__ inline void guess_decide(const double* s_g, const GuessFit& f) {
   constexpr int RM = GUESS_RM, NS = GUESS_NS;
-  __shared__ double s_red[BLOCK / 64];
-  __shared__ double s_g[NS];
   __shared__ double s_left[128], s_net[128];
   __shared__ double s_c[128][4];
-  double gs[NS];
-#pragma unroll
-  for (int j = 0; j < NS; ++j) gs[j] = 0.0;
-  const i64 nchunk = (n + BLOCK - 1) / BLOCK;
-  for (i64 ch = (i64)blockIdx.x * f.stride; ch < nchunk; ch += (i64)gridDim.x * f.stride) {
-    const i64 i = ch * BLOCK + threadIdx.x;
-    const int c = i < n ? cmap[i] : -1;
-    if (c < 0) continue;
-    const double d = ds[i], w = d * d, y0 = yn[i], ru = b[i] - y0, ra = rhat[c];
-    double q[RM];
-#pragma unroll
-    for (int j = 0; j < RM; ++j) q[j] = j < f.avail ? f.yr[j][i] - y0 : 0.0;
-    int t = 0;
-#pragma unroll
-    for (int j = 0; j < RM; ++j)
-#pragma unroll
-      for (int l = j; l < RM; ++l) gs[t++] += w * q[j] * q[l];
-#pragma unroll
-    for (int j = 0; j < RM; ++j) gs[t++] += w * q[j] * ru;
-    gs[t++] += w * ru * ru;
-    gs[t] += w * ra * ra;
-  }
-  {
-    __shared__ double s_w[BLOCK / 64][NS];     // all the sums through one barrier
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // (the shuffle tree level by level over all the sums: NS independent shuffles in flight instead of one chain each)
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-      for (int j = 0; j < NS; ++j) gs[j] += __shfl_down(gs[j], off, 64);
-    if (lane == 0) {
-#pragma unroll
-      for (int j = 0; j < NS; ++j) s_w[wave][j] = gs[j];
-    }
-    __syncthreads();
-    if (threadIdx.x < NS) {
-      double a = 0.0;
-#pragma unroll
-      for (int q = 0; q < BLOCK / 64; ++q) a += s_w[q][threadIdx.x];
-      pg::store_partial(f.partials + (size_t)threadIdx.x * gridDim.x + blockIdx.x, a);
-    }
-  }
-  if (!pg::last_block_arrives(f.ticket, gridDim.x, s_red)) return;
-  // the blocks' partial sums, in a fixed order: a wave per sum, a lane per block (at most 128 blocks), shuffle tree -- every
-  // load of a wave in flight before the first is used, the trees level by level
-  {
-    constexpr int PW = (NS + BLOCK / 64 - 1) / (BLOCK / 64);   // sums per wave
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, G = (int)gridDim.x;
-    double a0[PW], a1[PW];
-#pragma unroll
-    for (int k = 0; k < PW; ++k) {
-      const int sl = wave + k * (BLOCK / 64);
-      a0[k] = (sl < NS && lane < G) ? pg::load_partial(f.partials + (size_t)sl * G + lane) : 0.0;
-      a1[k] = (sl < NS && lane + 64 < G) ? pg::load_partial(f.partials + (size_t)sl * G + lane + 64) : 0.0;
-    }
-#pragma unroll
-    for (int k = 0; k < PW; ++k) a0[k] += a1[k];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-      for (int k = 0; k < PW; ++k) a0[k] += __shfl_down(a0[k], off, 64);
-    if (lane == 0) {
-#pragma unroll
-      for (int k = 0; k < PW; ++k) {
-        const int sl = wave + k * (BLOCK / 64);
-        if (sl < NS) s_g[sl] = a0[k];
-      }
-    }
-  }
-  __syncthreads();
   const double ru = s_g[NS - 2], rw = s_g[NS - 1];
   // one subset of the older states per thread: bit j of the thread number = state j
   if (threadIdx.x < 128) {
@@ -746,6 +675,96 @@ __global__ __launch_bounds__(BLOCK) void k_guess_fit(i64 n, const int* __restric
     for (; a < 4; ++a) { f.coef[a] = 0.0; f.coef[5 + a] = 0.0; }
     f.coef[9] = ru; f.coef[10] = rw; f.coef[11] = pick ? s_left[pick] : ru;
   }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_guess_fit(i64 n, const int* __restrict__ cmap, const double* __restrict__ ds,
+                                                     const double* __restrict__ b, const double* __restrict__ yn,
+                                                     const double* __restrict__ rhat, GuessFit f) {
+  constexpr int RM = GUESS_RM, NS = GUESS_NS;
+  __shared__ double s_red[BLOCK / 64];
+  __shared__ double s_g[NS];
+  double gs[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) gs[j] = 0.0;
+  const i64 nchunk = (n + BLOCK - 1) / BLOCK;
+  for (i64 ch = (i64)blockIdx.x * f.stride; ch < nchunk; ch += (i64)gridDim.x * f.stride) {
+    const i64 i = ch * BLOCK + threadIdx.x;
+    const int c = i < n ? cmap[i] : -1;
+    if (c < 0) continue;
+    const double d = ds[i], w = d * d, y0 = yn[i], ru = b[i] - y0, ra = rhat[c];
+    double q[RM];
+#pragma unroll
+    for (int j = 0; j < RM; ++j) q[j] = j < f.avail ? f.yr[j][i] - y0 : 0.0;
+    int t = 0;
+#pragma unroll
+    for (int j = 0; j < RM; ++j)
+#pragma unroll
+      for (int l = j; l < RM; ++l) gs[t++] += w * q[j] * q[l];
+#pragma unroll
+    for (int j = 0; j < RM; ++j) gs[t++] += w * q[j] * ru;
+    gs[t++] += w * ru * ru;
+    gs[t] += w * ra * ra;
+  }
+  {
+    __shared__ double s_w[BLOCK / 64][NS];     // all the sums through one barrier
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (the shuffle tree level by level over all the sums: NS independent shuffles in flight instead of one chain each)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int j = 0; j < NS; ++j) gs[j] += __shfl_down(gs[j], off, 64);
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < NS; ++j) s_w[wave][j] = gs[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < NS) {
+      double a = 0.0;
+#pragma unroll
+      for (int q = 0; q < BLOCK / 64; ++q) a += s_w[q][threadIdx.x];
+      pg::store_partial(f.partials + (size_t)threadIdx.x * gridDim.x + blockIdx.x, a);
+    }
+  }
+  if (!pg::last_block_arrives(f.ticket, gridDim.x, s_red)) return;
+  // the blocks' partial sums, in a fixed order: a wave per sum, a lane per block (at most 128 blocks), shuffle tree -- every
+  // load of a wave in flight before the first is used, the trees level by level
+  {
+    constexpr int PW = (NS + BLOCK / 64 - 1) / (BLOCK / 64);   // sums per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, G = (int)gridDim.x;
+    double a0[PW], a1[PW];
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+      const int sl = wave + k * (BLOCK / 64);
+      a0[k] = (sl < NS && lane < G) ? pg::load_partial(f.partials + (size_t)sl * G + lane) : 0.0;
+      a1[k] = (sl < NS && lane + 64 < G) ? pg::load_partial(f.partials + (size_t)sl * G + lane + 64) : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < PW; ++k) a0[k] += a1[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int k = 0; k < PW; ++k) a0[k] += __shfl_down(a0[k], off, 64);
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < PW; ++k) {
+        const int sl = wave + k * (BLOCK / 64);
+        if (sl < NS) s_g[sl] = a0[k];
+      }
+    }
+  }
+  __syncthreads();
+  if (f.sums) {                     // several ranks: the sums go through an all-reduce, k_guess_decide follows
+    if (threadIdx.x < NS) f.sums[threadIdx.x] = s_g[threadIdx.x];
+    return;
+  }
+  guess_decide(s_g, f);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_guess_decide(GuessFit f) {
+  __shared__ double s_g[GUESS_NS];
+  if (threadIdx.x < GUESS_NS) s_g[threadIdx.x] = f.sums[threadIdx.x];
+  __syncthreads();
+  guess_decide(s_g, f);
 }
 
 // z refers to S_old: re-express it with S_new (x = S_old z = S_new z')
@@ -1200,17 +1219,19 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
       const bool single = ctx().nranks == 1 && !ctx().comm;
       const bool same_data = DE.snapped_version == s->bconst_version;
       const bool quiet = same_data && single;
-      // extrapolated start (GuessArgs): quiet steps only -- the rows alone on their diagonal rest, so the differences of the
-      // kept states are differences of the loop's rows alone and the products ŷ^{n-o} combine linearly
+      // extrapolated start (GuessArgs): steps with unchanged data only -- the rows alone on their diagonal rest, so the
+      // differences of the kept states are differences of the loop's rows alone and the products ŷ^{n-o} combine linearly.
+      // Several ranks: "unchanged data" is the same verdict everywhere, the fit's sums go through an all-reduce and every rank
+      // takes the same decision.
       const Config& cfg = config();
-      const int KH = quiet ? cfg.guess_n : 0;                      // older states read at most
+      const int KH = same_data ? cfg.guess_n : 0;                  // older states read at most
       const int R = KH > 0 ? cfg.guess_depth : 0;                  // older states kept
       const int hist_had = (s->hist_de == &DE && s->hist_k == R) ? s->hist_cnt : 0;
       s->hist_cnt = 0;    // (stands again below once this step has gone the quiet way to its end)
       GuessArgs ga{};
       if (KH > 0) {
         const i64 nva = s->z.n;
-        if (s->guess_coef.n == 0) { s->guess_coef.alloc(16); s->guess_coef.zero(); s->guess_ticket.alloc(1); s->guess_ticket.zero(); }
+        if (s->guess_coef.n == 0) { s->guess_coef.alloc(16 + GUESS_NS); s->guess_coef.zero(); s->guess_ticket.alloc(1); s->guess_ticket.zero(); }
         for (int j = 0; j < R; ++j) {
           if (s->zh[j].n != nva) { s->zh[j].alloc(nva); s->zh[j].zero(); }
           if (s->yh[j].n != nva) { s->yh[j].alloc(nva); s->yh[j].zero(); }
@@ -1242,7 +1263,7 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
           const i64 nchunk = (n + BLOCK - 1) / BLOCK;
           gf.stride = (int)std::max<i64>(1, std::min<i64>(cfg.guess_monitor, nchunk / 128));   // (small systems: every chunk)
           const int gfit = (int)std::min<i64>(128, (nchunk + gf.stride - 1) / gf.stride);
-          if (s->guess_partials.n != (i64)GUESS_NS * gfit) s->guess_partials.alloc((i64)GUESS_NS * gfit);
+          if (s->guess_partials.n != (i64)GUESS_NS * std::max(gfit, 1)) s->guess_partials.alloc((i64)GUESS_NS * std::max(gfit, 1));
           gf.partials = s->guess_partials.p;
           gf.ticket = s->guess_ticket.p;
           gf.coef = s->guess_coef.p;
@@ -1251,8 +1272,13 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
           gf.rate2 = w.last_rate2;
           gf.pass_cost = cfg.guess_pass_cost;
           gf.gain = cfg.guess_gain;
-          hipLaunchKernelGGL(k_guess_fit, dim3(gfit), dim3(BLOCK), 0, stream, n, (const int*)DE.cmap.p, (const double*)A.ds.p,
+          gf.sums = single ? nullptr : s->guess_coef.p + 16;
+          hipLaunchKernelGGL(k_guess_fit, dim3(std::max(gfit, 1)), dim3(BLOCK), 0, stream, n, (const int*)DE.cmap.p, (const double*)A.ds.p,
                              (const double*)s->b.p, (const double*)s->y.p, (const double*)w.rhat.p, gf);
+          if (!single) {
+            comm_allreduce_sum_f64(gf.sums, GUESS_NS, stream);
+            hipLaunchKernelGGL(k_guess_decide, dim3(1), dim3(BLOCK), 0, stream, gf);
+          }
           PG_HIP(hipGetLastError());
         }
         // the buffers trade places (stream order keeps the kernels above ahead of whatever writes them next): the state
