@@ -5,7 +5,7 @@ Krylov scalars), for tests/test_gpu_rccl.py.
     PG_TEST_RCCL=1 python scripts/dist_check.py OUT.npz [n=48]          1 rank behind a 1-rank RCCL communicator
     python -m torch.distributed.run --nproc-per-node 2 ... scripts/dist_check.py OUT.npz [n=48]   2 ranks, 2 GPUs
 
-Every rank writes OUT.rank<r>.npz: its owned planes of the state after 1 BE + 3 CN steps (zeros elsewhere), iteration
+Every rank writes OUT.rank<r>.npz: its owned planes of the state after 1 BE + 8 CN steps (the later ones start from an extrapolation of older states whose fit goes through an all-reduce) (zeros elsewhere), iteration
 counts and sizes.  The ranks' arrays add up to the global state.
 """
 import ctypes as C
@@ -44,7 +44,7 @@ bcb = pj.BorderConditions({k: pj.Dirichlet(1.0) for k in ("left", "right", "top"
 ph = pj.Phase(cap, pj.DiffusionOps(cap), 0.0, 1.0)
 dt = 0.75 * (4.0 / n) ** 2
 s = pj.DiffusionUnsteadyMono(ph, bcb, pj.Dirichlet(1.0), dt, None, "BE")
-pj.solve_DiffusionUnsteadyMono_b(s, ph, dt, 1e30, bcb, pj.Dirichlet(1.0), "CN", save_states=False, max_steps=3, reltol=1e-13)
+pj.solve_DiffusionUnsteadyMono_b(s, ph, dt, 1e30, bcb, pj.Dirichlet(1.0), "CN", save_states=False, max_steps=8, reltol=1e-13)
 info = s.system_info(3)
 np.savez(f"{out}.rank{rank}.npz", x=s.x, iters=int(s.last_run.total_iters), n_own=int(info.n_own), n_ghost=int(info.n_ghost),
          unconverged=int(s.unconverged), degree=int(s.last_run.poly_degree))

@@ -871,11 +871,13 @@ def test_spmv_work_item_orders_bitwise_equal_csr_kernels(env):
 
 
 @pytest.mark.parametrize("env", [{"PG_POLY_XSPACE": "0"}, {"PG_POLY_MAXDEG": "7"}, {"PG_POLY_XSPACE": "0", "PG_DIAG_ELIM": "0"},
-                                 {"PG_DIAG_ELIM": "0", "PG_GAMMA_ELIM": "0"}])
+                                 {"PG_DIAG_ELIM": "0", "PG_GAMMA_ELIM": "0"}, {"PG_GUESS_STATES": "0"},
+                                 {"PG_GUESS_STATES": "2", "PG_GUESS_DEPTH": "3", "PG_POLY_TREND": "0"}])
 def test_forms_of_the_preconditioned_loop_match_the_oracle(env):
     """The loop's variants -- y-space form (lean chains + recovery), low degree cap (several applications per solve), the
-    Dirichlet-interface reduction without the compact system, the full system -- are selected by environment variables read
-    once per process: parity tests against the oracle's direct solve in a child process per setting."""
+    Dirichlet-interface reduction without the compact system, the full system, the start of the quiet steps without / with a
+    shallower extrapolation -- are selected by environment variables read once per process: parity tests against the oracle's
+    direct solve in a child process per setting."""
     import subprocess
     root = pathlib.Path(__file__).resolve().parents[1]
     code = ("import sys; sys.path.insert(0, '.'); import penguin.jl_amd as pj; pj.init(0); import tests.test_gpu_parity as t\n"
@@ -884,6 +886,7 @@ def test_forms_of_the_preconditioned_loop_match_the_oracle(env):
             "t.test_heat_monophasic_reference_test(pj, 'BE', 'CN')\n"
             "t.test_full_size_properties_256(pj)\n"
             "t.test_time_loop_is_bitwise_reproducible(pj)\n"
+            "t.test_extrapolated_start_of_quiet_steps_keeps_the_solution(pj, 'CN')\n"
             "print('forms ok')\n")
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env={**os.environ, **env}, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "forms ok" in r.stdout, (env, r.stdout[-2000:], r.stderr[-4000:])
@@ -913,11 +916,14 @@ def test_extrapolated_start_of_quiet_steps_keeps_the_solution(pj, scheme):
     worst = max(rel_l2(a, b) for a, b in zip(s.states, so.states))
     assert worst <= TOL_T, worst
     g = s.guess_info()
-    if pj.config_string().find("guess_states=0") >= 0:
-        pytest.skip("extrapolated start switched off (PG_GUESS_STATES=0)")
-    assert g["kept"] >= 4 and len(g["offsets"]) >= 2, g
+    cfg = dict(kv.split("=", 1) for kv in pj.config_string().split() if "=" in kv)
+    states, depth = int(cfg["guess_states"]), int(cfg["guess_depth"])
+    if states == 0:
+        assert g["kept"] == 0 and not g["offsets"]          # switched off (PG_GUESS_STATES=0): nothing kept, nothing read
+        return
+    assert g["kept"] == depth and 2 <= len(g["offsets"]) <= states, g
     assert g["rr_taken"] < 1e-2 * g["rr_plain"], g
-    assert all(1 <= o <= 7 for o in g["offsets"]) and sorted(set(g["offsets"])) == g["offsets"], g
+    assert all(1 <= o <= depth for o in g["offsets"]) and sorted(set(g["offsets"])) == g["offsets"], g
 
 
 # ------------------------------------------------------------------------------------ steady diffusion
