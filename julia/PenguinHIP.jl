@@ -21,7 +21,7 @@ export Mesh, nC, Capacity, capacity_from_arrays, Sphere, MultiSphere, HalfSpace,
        solve_AdvectionDiffusionSteadyDiph!, AdvectionDiffusionUnsteadyMono, solve_AdvectionDiffusionUnsteadyMono!,
        AdvectionDiffusionUnsteadyDiph, solve_AdvectionDiffusionUnsteadyDiph!,
        SpaceTimeMesh, MovingSphere, MovingHalfSpace, SpaceTimeCapacity, MovingDiffusionUnsteadyMono,
-       solve_MovingDiffusionUnsteadyMono!, MovingDiffusionUnsteadyDiph, solve_MovingDiffusionUnsteadyDiph!, config_string,
+       solve_MovingDiffusionUnsteadyMono!, MovingDiffusionUnsteadyDiph, solve_MovingDiffusionUnsteadyDiph!, config_string, guess_info,
        ∇, ∇₋, gmres, bicgstabl, cg
 
 const libpg = get(ENV, "PENGUIN_HIP_LIB", joinpath(@__DIR__, "..", "penguin", "jl_amd", "lib", "libpenguin_hip.so"))
@@ -915,6 +915,19 @@ function config_string()
     buf = Vector{UInt8}(undef, 2048)
     check(ccall((:pg_config_string, libpg), Int32, (Ptr{UInt8}, Csize_t), buf, length(buf)))
     unsafe_string(pointer(buf))
+end
+
+"""
+What the extrapolated start of the time loop's quiet steps is doing (`pg_solver_guess_info`): older states kept, the offsets
+and coefficients the next step starts from, the sampled start residual without / with this step's extrapolation.
+"""
+function guess_info(s)
+    kept = Ref{Int32}(0); ns = Ref{Int32}(0); ru = Ref{Float64}(0.0); rw = Ref{Float64}(0.0)
+    off = zeros(Int32, 4); cf = zeros(Float64, 4)
+    check(ccall((:pg_solver_guess_info, libpg), Int32,
+                (Ptr{Cvoid}, Ref{Int32}, Ref{Int32}, Ptr{Int32}, Ptr{Float64}, Ref{Float64}, Ref{Float64}),
+                s.handle, kept, ns, off, cf, ru, rw))
+    (kept = Int(kept[]), offsets = Int.(off[1:ns[]]), coef = cf[1:ns[]], rr_plain = ru[], rr_taken = rw[])
 end
 
 end # module
