@@ -87,6 +87,9 @@ struct Config {
   int profile_sample = 3;         // PG_PROFILE_SAMPLE
   bool gamma_elim = true;         // PG_GAMMA_ELIM
   bool diag_elim = true;          // PG_DIAG_ELIM
+  double diag_elim_frac = 0.0005; // PG_DIAG_ELIM_FRAC: the compact loop system is built when at least this share of the rows is alone on its
+                                  // diagonal (it was 2 %: 2-D problems, whose share is below that, then never reached the quiet steps'
+                                  // folded start and extrapolated start -- 2048^2: 3420 -> 5370 (BE) / 3450 -> 4440 (CN) steps/s)
   // SpMV (pg_spmv.hip)
   int spmv_variant = 70;          // PG_SPMV_VARIANT
   int spmv_xcd = 1;               // PG_SPMV_XCD (bits 8..: diagnostics that give WRONG products, in the diagnostic build of the kernel only)
@@ -100,6 +103,9 @@ struct Config {
   // the start of a quiet time step extrapolated from older states (pg_solver.hip, GuessArgs / k_guess_fit):
   int guess_n = 4;                // PG_GUESS_STATES: older states read at most (0: off, <= 4)
   int guess_depth = 7;            // PG_GUESS_DEPTH: older states kept to choose from (<= 7)
+  bool guess_always = false;      // PG_GUESS_ALWAYS=1: also where the fit's launch is not expected to pay (small, easy systems)
+  bool guess_async = false;       // PG_GUESS_ASYNC=1: one rank: the fit runs on a stream of its own beside the solve (measured: the
+                                  // Horner launches beside it slow down by more than the 21 us it takes off the stream: 586 vs 592 steps/s)
   int guess_monitor = 256;        // PG_GUESS_MONITOR: the fit samples every n-th chunk of 256 rows
   double guess_pass_cost = 0.34;  // PG_GUESS_PASS_COST: one more vector read of k_rhs_init_c, in products of the loop
   double guess_gain = 0.8;        // PG_GUESS_GAIN: products saved per product the fit predicts (what is left after the

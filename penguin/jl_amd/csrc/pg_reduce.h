@@ -39,6 +39,10 @@ struct DiagElim {
   i64 n_wg = 0;             // coupling block: full row wg_rows[q], entries wg_ptr[q] .. , columns = position in elist (owned) or n_e + ghost number
   DevBuf<int> wg_rows, wg_ptr, wg_col;
   DevBuf<double> wg_val;
+  // the extrapolated start of the time loop on this system (pg_solver.hip): switched on once a solve has used enough products
+  // for the fit's launch to pay (bytes_per_rank: a product's streamed bytes, averaged over the ranks -- the same everywhere)
+  double bytes_per_rank = 0.0, last_products = 0.0;
+  bool guess_on = false;
 };
 // Collective when several ranks run (every rank calls it at the same point: all-reduced activation test, one halo exchange).
 void build_diag_elim(const CsrMatrix& A, const Numbering& nb, const Slab& slab, DiagElim& E);

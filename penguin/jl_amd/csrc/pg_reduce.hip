@@ -381,14 +381,15 @@ void build_diag_elim(const CsrMatrix& A, const Numbering& nb, const Slab& slab, 
   const i64 n_e = ht0, n_c = n - n_e;
   // worth a second matrix?  2 % of the rows -- of ALL ranks' rows: the decision (and the exchange below) is collective
   {
-    unsigned long long h[3] = {(unsigned long long)n_e, (unsigned long long)n, n_c <= 0 ? 1ull : 0ull};
+    unsigned long long h[4] = {(unsigned long long)n_e, (unsigned long long)n, n_c <= 0 ? 1ull : 0ull, (unsigned long long)A.spmv_bytes};
     if (multi) {
-      DevBuf<unsigned long long> d(3);
-      d.upload(h, 3);
-      comm_allreduce_sum_u64(d.p, 3, st);
-      d.download(h, 3);
+      DevBuf<unsigned long long> d(4);
+      d.upload(h, 4);
+      comm_allreduce_sum_u64(d.p, 4, st);
+      d.download(h, 4);
     }
-    if (h[0] * 50 < h[1] || h[2] != 0) return;   // (a rank without remaining rows: every rank takes the full system)
+    E.bytes_per_rank = (double)h[3] / std::max(1, cx.nranks);   // (the same figure on every rank: pg_solver.hip's extrapolated start)
+    if ((double)h[0] < config().diag_elim_frac * (double)h[1] || h[0] == 0 || h[2] != 0) return;   // (a rank without remaining rows: every rank takes the full system)
   }
   // the neighbours' verdicts on my ghost entries
   DevBuf<double> fl(nvec > 0 ? nvec : 1);

@@ -76,6 +76,19 @@ struct pg_solver {
   // the extrapolated start of a quiet step (GuessArgs).  hist_cnt of them are valid, all for the matrix of hist_de.
   DevBuf<double> zh[8], yh[8], guess_coef, guess_partials;
   DevBuf<unsigned> guess_ticket;
+  // k_guess_fit runs beside the solve on a stream of its own (one rank): it reads what the step's first kernel left (b̂, r̂,
+  // the products) and writes the coefficients the NEXT step's first kernel reads; fit_join() orders that kernel behind it
+  struct FitAsync {
+    hipStream_t st = nullptr;
+    hipEvent_t ev_rhs = nullptr, ev_fit = nullptr;
+    bool pending = false;
+    ~FitAsync() {
+      if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+      if (ev_rhs) (void)hipEventDestroy(ev_rhs);
+      if (ev_fit) (void)hipEventDestroy(ev_fit);
+    }
+  } fit;
+  ~pg_solver() { if (fit.st) (void)hipStreamSynchronize(fit.st); }   // (before any buffer it reads goes back to the cache)
   int hist_cnt = 0, hist_k = 0;     // (hist_k: the ring's depth the count refers to)
   const void* hist_de = nullptr;
   bool initial_done = false;
@@ -92,6 +105,14 @@ struct pg_solver {
 namespace {
 
 using pg::BLOCK;   // 256 (pg_spmv.h)
+
+// the compute stream waits for a fit that may still be running beside it (host = true: the host does)
+void fit_join(pg_solver* s, bool host = false) {
+  if (!s->fit.pending) return;
+  if (host) PG_HIP(hipStreamSynchronize(s->fit.st));
+  else PG_HIP(hipStreamWaitEvent(ctx().stream, s->fit.ev_fit, 0));
+  s->fit.pending = false;
+}
 
 struct RowSegs {
   int K;
@@ -498,7 +519,7 @@ __global__ __launch_bounds__(BLOCK) void k_rhs_init_c(i64 n, int scheme, const d
 #pragma unroll
         for (int j = 0; j < KH; ++j) {
           rd2_t a = zz, y2 = yh;
-          if (j < ku) {
+          if (j < ku && (c0 >= 0 || c1 >= 0)) {     // (rows alone on their diagonal take nothing from the older states)
             a = *reinterpret_cast<const rd2_t*>(zo[j] + i);
             y2 = *reinterpret_cast<const rd2_t*>(yo[j] + i);
           }
@@ -1135,6 +1156,7 @@ pg_krylov_opts default_opts() {
 
 void do_initial(pg_solver* s, const pg_krylov_opts* opts, SolveStats& st) {
   const pg_krylov_opts o = opts ? *opts : default_opts();
+  fit_join(s);
   // solve_system!(s) with the constructor's A and b (diffusion.jl:275)
   const i64 n = s->nb.n_own;
   if (s->moving && o.warm_start != 0 && o.method == PG_METHOD_BICGSTAB && n > 0) {
@@ -1162,6 +1184,7 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
   PG_REQUIRE(s->initial_done, "Solver is not initialized. Call pg_solver_initial_solve first.");
   const pg_krylov_opts o = opts ? *opts : default_opts();
   hipStream_t stream = ctx().stream;
+  fit_join(s);
   ensure_run_matrix(s, scheme);
   const CsrMatrix& A = run_matrix(s);
   const i64 n = s->nb.n_own;
@@ -1224,7 +1247,18 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
       // Several ranks: "unchanged data" is the same verdict everywhere, the fit's sums go through an all-reduce and every rank
       // takes the same decision.
       const Config& cfg = config();
-      const int KH = same_data ? cfg.guess_n : 0;                  // older states read at most
+      // Worth its launch?  The fit costs about 20 us per step whatever the size, a product max(5 us, its bytes at 5 TB/s): the
+      // mechanism is switched on (for good, on this system) once a solve has used so many products that a few of them saved
+      // pay for it -- 512^3: from 7 products (the loop needs 26), 64^3 ... 2048^2: from 18 (launch-bound: 26 products of the
+      // 3-D CN loops qualify, +15 ... +50 %; the 8 of the 2-D backward-Euler loops do not, where it cost 5 ... 30 %)
+      if (!DE.guess_on && cfg.guess_n > 0 && DE.last_products > 0.0) {
+        const double t_prod_us = std::max(5.0, DE.bytes_per_rank / 5.0e6);
+        // (and not on systems of a few thousand rows, where every launch is latency and the fit's is one more: 80^2, 1815 rows:
+        //  19 -> 11 products per step and still 6400 instead of 7800 steps/s)
+        if (cfg.guess_always || (DE.bytes_per_rank >= 256.0 * 1024.0 && DE.last_products >= 6.0 + 3.0 * (20.0 / t_prod_us)))
+          DE.guess_on = true;
+      }
+      const int KH = (same_data && DE.guess_on) ? cfg.guess_n : 0; // older states read at most
       const int R = KH > 0 ? cfg.guess_depth : 0;                  // older states kept
       const int hist_had = (s->hist_de == &DE && s->hist_k == R) ? s->hist_cnt : 0;
       s->hist_cnt = 0;    // (stands again below once this step has gone the quiet way to its end)
@@ -1232,8 +1266,8 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
       if (KH > 0) {
         const i64 nva = s->z.n;
         if (s->guess_coef.n == 0) { s->guess_coef.alloc(16 + GUESS_NS); s->guess_coef.zero(); s->guess_ticket.alloc(1); s->guess_ticket.zero(); }
-        for (int j = 0; j < R; ++j) {
-          if (s->zh[j].n != nva) { s->zh[j].alloc(nva); s->zh[j].zero(); }
+        for (int j = 0; j <= R; ++j) {      // (one more product buffer than states: the one retired a step ago takes the next
+          if (j < R && s->zh[j].n != nva) { s->zh[j].alloc(nva); s->zh[j].zero(); }   //  product while the fit still reads the others)
           if (s->yh[j].n != nva) { s->yh[j].alloc(nva); s->yh[j].zero(); }
         }
         if (hist_had == 0) PG_HIP(hipMemsetAsync(s->guess_coef.p, 0, 12 * sizeof(double), stream));   // (the counters stay)
@@ -1273,8 +1307,23 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
           gf.pass_cost = cfg.guess_pass_cost;
           gf.gain = cfg.guess_gain;
           gf.sums = single ? nullptr : s->guess_coef.p + 16;
-          hipLaunchKernelGGL(k_guess_fit, dim3(std::max(gfit, 1)), dim3(BLOCK), 0, stream, n, (const int*)DE.cmap.p, (const double*)A.ds.p,
+          hipStream_t fst = stream;
+          if (single && cfg.guess_async) {
+            if (!s->fit.st) {
+              PG_HIP(hipStreamCreateWithFlags(&s->fit.st, hipStreamNonBlocking));
+              PG_HIP(hipEventCreateWithFlags(&s->fit.ev_rhs, hipEventDisableTiming));
+              PG_HIP(hipEventCreateWithFlags(&s->fit.ev_fit, hipEventDisableTiming));
+            }
+            PG_HIP(hipEventRecord(s->fit.ev_rhs, stream));
+            PG_HIP(hipStreamWaitEvent(s->fit.st, s->fit.ev_rhs, 0));
+            fst = s->fit.st;
+          }
+          hipLaunchKernelGGL(k_guess_fit, dim3(std::max(gfit, 1)), dim3(BLOCK), 0, fst, n, (const int*)DE.cmap.p, (const double*)A.ds.p,
                              (const double*)s->b.p, (const double*)s->y.p, (const double*)w.rhat.p, gf);
+          if (fst != stream) {
+            PG_HIP(hipEventRecord(s->fit.ev_fit, fst));
+            s->fit.pending = true;
+          }
           if (!single) {
             comm_allreduce_sum_f64(gf.sums, GUESS_NS, stream);
             hipLaunchKernelGGL(k_guess_decide, dim3(1), dim3(BLOCK), 0, stream, gf);
@@ -1284,10 +1333,12 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
         // the buffers trade places (stream order keeps the kernels above ahead of whatever writes them next): the state
         // written becomes z, z and ŷ become the newest kept pair, the oldest ŷ is the next product's output
         double* znew = s->zh[R - 1].p;
-        double* yspare = s->yh[R - 1].p;
+        double* yspare = s->yh[R].p;          // retired a step ago
+        double* yretire = s->yh[R - 1].p;
         for (int j = R - 1; j > 0; --j) { s->zh[j].p = s->zh[j - 1].p; s->yh[j].p = s->yh[j - 1].p; }
         s->zh[0].p = s->z.p; s->z.p = znew;
         s->yh[0].p = s->y.p; s->y.p = yspare;
+        s->yh[R].p = yretire;
       }
       if (!same_data) diag_fix(DE, s->nb, s->slab, stamp, !single, w.rhat.p, w.partials.p, w.grid, stream);
       w.start_folded = quiet;
@@ -1316,6 +1367,7 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
       s->spec_y_valid = s->spec_pending && st.polls == 1 && st.converged && st.poly_degree >= 0;
       s->spec_pending = false;
       solved = st.poly_degree >= 0;            // -1: the polynomial stagnated on the compact system -> the full system below
+      DE.last_products = (double)st.products;
       // A quiet step rests on "no row alone on its diagonal moves while the data are unchanged"; k_rhs_init_c checks it
       // anyway and the start phase reports it (S_MOVED): the residual the iteration started from then lacked the coupling
       // term, and the step is finished on the full system from the state reached.
@@ -1338,6 +1390,7 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
       else if (KH > 0) {
         if (config().debug) {
           double hc[16];
+          fit_join(s, true);
           s->guess_coef.download(hc, 16);
           fprintf(stderr, "[pg_solver] extrapolated start: %d older states kept; sampled (r,r)_W plain %.3e, taken %.3e; next step: %d states",
                   hist_had, hc[9], hc[10], (int)hc[4]);
@@ -1700,7 +1753,7 @@ int32_t pg_solver_run(pg_solver* s, double Tend, int32_t scheme, const pg_krylov
   const double wait0 = pg::g_host_wait_us;
   PG_HIP(hipEventRecord(ev.e0, stream));
   double used0 = 0.0;               // older states read by the extrapolated starts so far (device counter, GuessArgs)
-  if (s->guess_coef.n >= 16) s->guess_coef.download(&used0, 1, 13);
+  if (s->guess_coef.n >= 16) { fit_join(s, true); s->guess_coef.download(&used0, 1, 13); }
   SolveStats tot;
   i64 steps = 0, iters = 0, unconverged = 0;
   double worst = 0.0;
@@ -1759,6 +1812,7 @@ int32_t pg_solver_run(pg_solver* s, double Tend, int32_t scheme, const pg_krylov
     info->guess_states_read = 0;
     if (s->guess_coef.n >= 16) {
       double hc[16];
+      fit_join(s, true);
       s->guess_coef.download(hc, 16);
       info->guess_states_read = (int64_t)(hc[13] - used0);
     }
@@ -1969,6 +2023,7 @@ int32_t pg_solver_guess_info(pg_solver* s, int32_t* kept, int32_t* nstates, int3
   for (int j = 0; j < 4; ++j) { offsets[j] = 0; coef[j] = 0.0; }
   if (s->guess_coef.n >= 16 && s->hist_cnt > 0) {
     double hc[16];
+    fit_join(s, true);
     s->guess_coef.download(hc, 16);
     *nstates = (int32_t)hc[4];
     for (int j = 0; j < *nstates && j < 4; ++j) { offsets[j] = (int32_t)hc[5 + j] + 1; coef[j] = hc[j]; }

@@ -898,7 +898,7 @@ def test_extrapolated_start_of_quiet_steps_keeps_the_solution(pj, scheme):
     states (pg_solver.hip, GuessArgs / k_guess_fit).  Only the start changes -- every state still matches the oracle's
     direct solves at the north-star tolerance -- and the fit does what it is there for: the start residual taken is far
     below the plain one."""
-    n, steps = 24, 26
+    n, steps = 32, 26      # (10 k rows: systems of a few thousand rows keep the plain warm start, pg_solver.hip)
     M = (n + 1) ** 3
     dt = 0.75 * (4.0 / n) ** 2
     mesh, omesh = pj.Mesh((n,) * 3, (4.0,) * 3), po.Mesh((n,) * 3, (4.0,) * 3)
@@ -918,8 +918,13 @@ def test_extrapolated_start_of_quiet_steps_keeps_the_solution(pj, scheme):
     g = s.guess_info()
     cfg = dict(kv.split("=", 1) for kv in pj.config_string().split() if "=" in kv)
     states, depth = int(cfg["guess_states"]), int(cfg["guess_depth"])
-    if states == 0:
-        assert g["kept"] == 0 and not g["offsets"]          # switched off (PG_GUESS_STATES=0): nothing kept, nothing read
+    if not s.system_info(1).loop_is_compact:
+        assert g["kept"] == 0          # (PG_DIAG_ELIM=0 / y-space form: the loop that keeps older states is not running)
+        return
+    if states == 0 or (g["kept"] == 0 and scheme == "BE"):
+        # switched off (PG_GUESS_STATES=0), or never switched on: the backward-Euler solves of this small problem use too few
+        # products for the fit's launch to pay (pg_solver.hip; PG_GUESS_ALWAYS=1 forces it): nothing kept, nothing read
+        assert g["kept"] == 0 and not g["offsets"]
         return
     assert g["kept"] == depth and 2 <= len(g["offsets"]) <= states, g
     assert g["rr_taken"] < 1e-2 * g["rr_plain"], g
