@@ -859,6 +859,10 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
   // (444 -> 546 steps/s at 512^3 against 3 x 9 in the same form).  No safety margin: a miss costs one more application
   // once, and the next estimate is made from that solve.
   stats.products = (i64)(2 * stats.iters - stats.half_exit) * (m >= 2 ? m : 1);
+  if (!cg && stats.converged && stats.products > 0) {   // (what a product took off log (r,r)_W: the extrapolated start's cost model)
+    const double rr0 = w.h_sc[S_RR0], rr = w.h_sc[S_HALF] != 0.0 ? w.h_sc[S_RED4] : w.h_sc[S_RR];
+    if (rr0 > 0.0 && rr > 0.0 && rr < rr0) w.last_rate2 = std::log(rr0 / rr) / (double)stats.products;
+  }
   w.adapt_matrix = nullptr;
   if (adaptive && stats.converged && stats.iters > 0) {
     const double rr0 = w.h_sc[S_RR0], rr = w.h_sc[S_HALF] != 0.0 ? w.h_sc[S_RED4] : w.h_sc[S_RR], tol2 = w.h_sc[S_TOL2];

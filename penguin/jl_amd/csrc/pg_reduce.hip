@@ -389,7 +389,7 @@ void build_diag_elim(const CsrMatrix& A, const Numbering& nb, const Slab& slab, 
       d.download(h, 4);
     }
     E.bytes_per_rank = (double)h[3] / std::max(1, cx.nranks);   // (the same figure on every rank: pg_solver.hip's extrapolated start)
-    if ((double)h[0] < config().diag_elim_frac * (double)h[1] || h[0] == 0 || h[2] != 0) return;   // (a rank without remaining rows: every rank takes the full system)
+    if ((double)h[0] < config().diag_elim_frac * (double)h[1] || h[2] != 0) return;   // (a rank without remaining rows: every rank takes the full system)
   }
   // the neighbours' verdicts on my ghost entries
   DevBuf<double> fl(nvec > 0 ? nvec : 1);

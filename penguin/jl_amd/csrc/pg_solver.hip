@@ -90,6 +90,8 @@ struct pg_solver {
   } fit;
   ~pg_solver() { if (fit.st) (void)hipStreamSynchronize(fit.st); }   // (before any buffer it reads goes back to the cache)
   int hist_cnt = 0, hist_k = 0;     // (hist_k: the ring's depth the count refers to)
+  bool plain_guess_on[2] = {false, false};          // the plain warm path's switch and last solve's products, per matrix
+  double plain_last_products[2] = {0.0, 0.0};       // (ctor / run; the compact path keeps its own in DiagElim)
   const void* hist_de = nullptr;
   bool initial_done = false;
   std::vector<DevBuf<double>> states;
@@ -331,86 +333,6 @@ __global__ void k_rhs_block_mf(SysParams P, RowSegs seg, i64 Mloc, i64 nblk, con
   }
 }
 
-// K8 + the BiCGStab start in one pass (loop form, warm start): from the scaled state z and ŷ = Âz
-//   b̂ = S(2 mass∘(S z) + bconst) - ŷ  (CN) | S(mass∘(S z) + bconst) (BE) | S bconst (fixed rows) | as written by k_rhs_block
-//   r = r̂ = p = b̂ - ŷ,  x = z (in place),  partial sums of (r,r) and (b̂,b̂) in slots 0 / 1   (k_rhs_init_c: r̂ only)
-// replaces k_rhs + k_bicg_init: 9.3 instead of 14.1 vector passes, and no separate scaling kernels per step
-typedef double rd2_t __attribute__((ext_vector_type(2)));
-typedef unsigned char ruc2_t __attribute__((ext_vector_type(2)));
-
-// one element of k_rhs_init
-__device__ inline void rhs_init_one(int scheme, double z, double yh, double d, double ms, double bc, bool fx, bool blk, double bold,
-                                    double& bi, double& ri) {
-  if (blk) bi = bold;
-  else if (fx) bi = d * bc;
-  else if (scheme == PG_SCHEME_CN) bi = d * (2.0 * (ms * (d * z)) + bc) - yh;
-  else bi = d * (ms * (d * z) + bc);
-  ri = bi - yh;
-}
-
-// TWO elements per lane (16-byte accesses: half the vector-memory instructions of the 11 streams; the two flag bytes of
-// a pair come with one 2-byte load each); the odd last element and the ghost tail are handled by the same lanes
-__global__ __launch_bounds__(BLOCK) void k_rhs_init(i64 n, i64 nvec, int scheme, const double* __restrict__ z,
-                                                    const double* __restrict__ yhat, const double* __restrict__ ds,
-                                                    const double* __restrict__ mass, const double* __restrict__ bconst,
-                                                    const unsigned char* __restrict__ fixed,
-                                                    const unsigned char* __restrict__ isblk, double* __restrict__ b,
-                                                    double* __restrict__ r, double* __restrict__ rhat,
-                                                    double* __restrict__ p, double* __restrict__ partials) {
-  __shared__ double s_red[BLOCK / 64];
-  double acc = 0.0, accb = 0.0, accw = 0.0;   // (r,r), (b,b)_W, (r,r)_W: slots 0, 1, 2 as k_bicg_init (weights ds²)
-  const i64 npair = (nvec + 1) / 2;
-  for (i64 q = blockIdx.x * (i64)BLOCK + threadIdx.x; q < npair; q += (i64)gridDim.x * BLOCK) {
-    const i64 i = 2 * q;
-    if (i + 1 < n) {
-      // (stream hints: the per-row data is read once per step and b̂ is only kept for inspection -- neither should
-      //  displace the SpMV's matrix data from the Infinity Cache)
-      const rd2_t yh = __builtin_nontemporal_load(reinterpret_cast<const rd2_t*>(yhat + i));
-      const rd2_t d = __builtin_nontemporal_load(reinterpret_cast<const rd2_t*>(ds + i));
-      const rd2_t bc = __builtin_nontemporal_load(reinterpret_cast<const rd2_t*>(bconst + i));
-      const rd2_t ms = __builtin_nontemporal_load(reinterpret_cast<const rd2_t*>(mass + i));
-      const rd2_t zz = *reinterpret_cast<const rd2_t*>(z + i);
-      const ruc2_t fx = *reinterpret_cast<const ruc2_t*>(fixed + i);
-      const ruc2_t bk = *reinterpret_cast<const ruc2_t*>(isblk + i);
-      rd2_t bold;
-      bold.x = 0.0; bold.y = 0.0;
-      if (bk.x | bk.y) bold = *reinterpret_cast<const rd2_t*>(b + i);
-      double b0, r0, b1, r1;
-      rhs_init_one(scheme, zz.x, yh.x, d.x, ms.x, bc.x, fx.x != 0, bk.x != 0, bold.x, b0, r0);
-      rhs_init_one(scheme, zz.y, yh.y, d.y, ms.y, bc.y, fx.y != 0, bk.y != 0, bold.y, b1, r1);
-      rd2_t bi, ri;
-      bi.x = b0; bi.y = b1; ri.x = r0; ri.y = r1;
-      __builtin_nontemporal_store(bi, reinterpret_cast<rd2_t*>(b + i));
-      *reinterpret_cast<rd2_t*>(r + i) = ri;
-      *reinterpret_cast<rd2_t*>(rhat + i) = ri;
-      *reinterpret_cast<rd2_t*>(p + i) = ri;
-      acc += ri.x * ri.x + ri.y * ri.y;
-      accb += (d.x * bi.x) * (d.x * bi.x) + (d.y * bi.y) * (d.y * bi.y);
-      accw += (d.x * ri.x) * (d.x * ri.x) + (d.y * ri.y) * (d.y * ri.y);
-    } else {
-      for (i64 k = i; k < i + 2 && k < nvec; ++k) {
-        if (k < n) {
-          double bi, ri;
-          rhs_init_one(scheme, z[k], yhat[k], ds[k], mass[k], bconst[k], fixed[k] != 0, isblk[k] != 0, isblk[k] ? b[k] : 0.0, bi, ri);
-          b[k] = bi;
-          r[k] = ri; rhat[k] = ri; p[k] = ri;
-          acc += ri * ri;
-          accb += (ds[k] * bi) * (ds[k] * bi);
-          accw += (ds[k] * ri) * (ds[k] * ri);
-        } else {
-          p[k] = 0.0;
-        }
-      }
-    }
-  }
-  const double t = block_sum(acc, s_red);
-  if (threadIdx.x == 0) partials[blockIdx.x] = t;
-  const double tb = block_sum(accb, s_red);
-  if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = tb;
-  const double tw = block_sum(accw, s_red);
-  if (threadIdx.x == 0) partials[2 * (size_t)gridDim.x + blockIdx.x] = tw;
-}
-
 // The start of a quiet step extrapolated from older states.  The solver keeps the last R states z^{n-1} .. z^{n-R} and their
 // products ŷ^{n-o} = Â z^{n-o} (ring buffers; no extra store: the buffers trade places with z / ŷ).  For a choice of
 // offsets o_j, d_j = z^{n-o_j} - z^n and q_j = Â d_j = ŷ^{n-o_j} - ŷ^n cost two reads each, and
@@ -433,6 +355,124 @@ __device__ inline const double* ring_pick(const double* const (&r)[8], int i) {
 #pragma unroll
   for (int q = 1; q < 8; ++q) p = i == q ? r[q] : p;   // (uniform: scalar selects, no private-memory copy of the argument)
   return p;
+}
+
+// K8 + the BiCGStab start in one pass (loop form, warm start): from the scaled state z and ŷ = Âz
+//   b̂ = S(2 mass∘(S z) + bconst) - ŷ  (CN) | S(mass∘(S z) + bconst) (BE) | S bconst (fixed rows) | as written by k_rhs_block
+//   r = r̂ = p = b̂ - ŷ,  x = z (in place),  partial sums of (r,r) and (b̂,b̂) in slots 0 / 1   (k_rhs_init_c: r̂ only)
+// replaces k_rhs + k_bicg_init: 9.3 instead of 14.1 vector passes, and no separate scaling kernels per step
+typedef double rd2_t __attribute__((ext_vector_type(2)));
+typedef unsigned char ruc2_t __attribute__((ext_vector_type(2)));
+
+// one element of k_rhs_init
+__device__ inline void rhs_init_one(int scheme, double z, double yh, double d, double ms, double bc, bool fx, bool blk, double bold,
+                                    double& bi, double& ri) {
+  if (blk) bi = bold;
+  else if (fx) bi = d * bc;
+  else if (scheme == PG_SCHEME_CN) bi = d * (2.0 * (ms * (d * z)) + bc) - yh;
+  else bi = d * (ms * (d * z) + bc);
+  ri = bi - yh;
+}
+
+// TWO elements per lane (16-byte accesses: half the vector-memory instructions of the 11 streams; the two flag bytes of
+// a pair come with one 2-byte load each); the odd last element and the ghost tail are handled by the same lanes
+// KH > 0: the start extrapolated from older states (GuessArgs; every row takes part: no row is left out on this path), the
+// state written out of place
+template <int KH>
+__global__ __launch_bounds__(BLOCK) void k_rhs_init(i64 n, i64 nvec, int scheme, const double* __restrict__ z,
+                                                    const double* __restrict__ yhat, const double* __restrict__ ds,
+                                                    const double* __restrict__ mass, const double* __restrict__ bconst,
+                                                    const unsigned char* __restrict__ fixed,
+                                                    const unsigned char* __restrict__ isblk, double* __restrict__ b,
+                                                    double* __restrict__ r, double* __restrict__ rhat,
+                                                    double* __restrict__ p, double* __restrict__ partials, GuessArgs g) {
+  __shared__ double s_red[BLOCK / 64];
+  double acc = 0.0, accb = 0.0, accw = 0.0;   // (r,r), (b,b)_W, (r,r)_W: slots 0, 1, 2 as k_bicg_init (weights ds²)
+  double cj[KH > 0 ? KH : 1];
+  const double* zo[KH > 0 ? KH : 1];
+  const double* yo[KH > 0 ? KH : 1];
+  int ku = 0;
+  if (KH > 0) {
+    ku = min(KH, (int)g.coef[4]);
+#pragma unroll
+    for (int j = 0; j < KH; ++j) {
+      const int sel = j < ku ? (int)g.coef[5 + j] : 0;
+      cj[j] = j < ku ? g.coef[j] : 0.0;
+      zo[j] = ring_pick(g.zr, sel);
+      yo[j] = ring_pick(g.yr, sel);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) g.coef[13] += (double)ku;
+  }
+  const i64 npair = (nvec + 1) / 2;
+  for (i64 q = blockIdx.x * (i64)BLOCK + threadIdx.x; q < npair; q += (i64)gridDim.x * BLOCK) {
+    const i64 i = 2 * q;
+    if (i + 1 < n) {
+      // (stream hints: the per-row data is read once per step and b̂ is only kept for inspection -- neither should
+      //  displace the SpMV's matrix data from the Infinity Cache)
+      const rd2_t yh = __builtin_nontemporal_load(reinterpret_cast<const rd2_t*>(yhat + i));
+      const rd2_t d = __builtin_nontemporal_load(reinterpret_cast<const rd2_t*>(ds + i));
+      const rd2_t bc = __builtin_nontemporal_load(reinterpret_cast<const rd2_t*>(bconst + i));
+      const rd2_t ms = __builtin_nontemporal_load(reinterpret_cast<const rd2_t*>(mass + i));
+      const rd2_t zz = *reinterpret_cast<const rd2_t*>(z + i);
+      const ruc2_t fx = *reinterpret_cast<const ruc2_t*>(fixed + i);
+      const ruc2_t bk = *reinterpret_cast<const ruc2_t*>(isblk + i);
+      rd2_t bold;
+      bold.x = 0.0; bold.y = 0.0;
+      if (bk.x | bk.y) bold = *reinterpret_cast<const rd2_t*>(b + i);
+      double b0, r0, b1, r1;
+      rhs_init_one(scheme, zz.x, yh.x, d.x, ms.x, bc.x, fx.x != 0, bk.x != 0, bold.x, b0, r0);
+      rhs_init_one(scheme, zz.y, yh.y, d.y, ms.y, bc.y, fx.y != 0, bk.y != 0, bold.y, b1, r1);
+      if (KH > 0) {
+        rd2_t zg = zz;
+#pragma unroll
+        for (int j = 0; j < KH; ++j) {
+          if (j < ku) {
+            const rd2_t a = *reinterpret_cast<const rd2_t*>(zo[j] + i);
+            const rd2_t y2 = *reinterpret_cast<const rd2_t*>(yo[j] + i);
+            r0 -= cj[j] * (y2.x - yh.x); r1 -= cj[j] * (y2.y - yh.y);
+            zg.x += cj[j] * (a.x - zz.x); zg.y += cj[j] * (a.y - zz.y);
+          }
+        }
+        *reinterpret_cast<rd2_t*>(g.znew + i) = zg;
+      }
+      rd2_t bi, ri;
+      bi.x = b0; bi.y = b1; ri.x = r0; ri.y = r1;
+      __builtin_nontemporal_store(bi, reinterpret_cast<rd2_t*>(b + i));
+      *reinterpret_cast<rd2_t*>(r + i) = ri;
+      *reinterpret_cast<rd2_t*>(rhat + i) = ri;
+      *reinterpret_cast<rd2_t*>(p + i) = ri;
+      acc += ri.x * ri.x + ri.y * ri.y;
+      accb += (d.x * bi.x) * (d.x * bi.x) + (d.y * bi.y) * (d.y * bi.y);
+      accw += (d.x * ri.x) * (d.x * ri.x) + (d.y * ri.y) * (d.y * ri.y);
+    } else {
+      for (i64 k = i; k < i + 2 && k < nvec; ++k) {
+        if (k < n) {
+          double bi, ri;
+          rhs_init_one(scheme, z[k], yhat[k], ds[k], mass[k], bconst[k], fixed[k] != 0, isblk[k] != 0, isblk[k] ? b[k] : 0.0, bi, ri);
+          if (KH > 0) {
+            double zg = z[k];
+#pragma unroll
+            for (int j = 0; j < KH; ++j)
+              if (j < ku) { ri -= cj[j] * (yo[j][k] - yhat[k]); zg += cj[j] * (zo[j][k] - z[k]); }
+            g.znew[k] = zg;
+          }
+          b[k] = bi;
+          r[k] = ri; rhat[k] = ri; p[k] = ri;
+          acc += ri * ri;
+          accb += (ds[k] * bi) * (ds[k] * bi);
+          accw += (ds[k] * ri) * (ds[k] * ri);
+        } else {
+          p[k] = 0.0;
+        }
+      }
+    }
+  }
+  const double t = block_sum(acc, s_red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+  const double tb = block_sum(accb, s_red);
+  if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = tb;
+  const double tw = block_sum(accw, s_red);
+  if (threadIdx.x == 0) partials[2 * (size_t)gridDim.x + blockIdx.x] = tw;
 }
 
 // k_rhs_init for a COMPACT loop system (pg_reduce.hip, DiagElim): cmap[i] >= 0: the row stays, r = r̂ = p go to that index of
@@ -710,7 +750,7 @@ __global__ __launch_bounds__(BLOCK) void k_guess_fit(i64 n, const int* __restric
   const i64 nchunk = (n + BLOCK - 1) / BLOCK;
   for (i64 ch = (i64)blockIdx.x * f.stride; ch < nchunk; ch += (i64)gridDim.x * f.stride) {
     const i64 i = ch * BLOCK + threadIdx.x;
-    const int c = i < n ? cmap[i] : -1;
+    const int c = i < n ? (cmap ? cmap[i] : (int)i) : -1;   // (no map: every row is in the loop)
     if (c < 0) continue;
     const double d = ds[i], w = d * d, y0 = yn[i], ru = b[i] - y0, ra = rhat[c];
     double q[RM];
@@ -1175,7 +1215,124 @@ void do_initial(pg_solver* s, const pg_krylov_opts* opts, SolveStats& st) {
   s->x_valid = false;
   s->initial_done = true;
   s->diag_ctor.snapped_version = s->diag_run.snapped_version = -1;   // z was replaced behind the compact path's back
+  s->hist_cnt = 0;
   s->spec_y_valid = false;
+}
+
+// ---- host side of the extrapolated start (GuessArgs), shared by the compact and the plain warm path ---------------------
+// Worth its launch?  The fit costs about 20 us per step whatever the size, a product max(5 us, its bytes at 5 TB/s): the
+// mechanism is switched on (for good, on this system) once a solve has used so many products that a few of them saved pay
+// for it -- 512^3: from 7 products (the loop needs 26), 64^3 ... 2048^2: from 18 (launch-bound: the 26 products of the 3-D CN
+// loops qualify, +15 ... +50 %) -- and not on systems of a few thousand rows, where every launch is latency and the fit's
+// is one more (80^2, 1815 rows: 19 -> 11 products per step and still 6400 instead of 7800 steps/s).
+void guess_policy(bool& on, double last_products, double bytes_per_product) {
+  const Config& cfg = config();
+  if (on || cfg.guess_n <= 0 || last_products <= 0.0) return;
+  const double t_prod_us = std::max(5.0, bytes_per_product / 5.0e6);
+  if (cfg.guess_always || (bytes_per_product >= 256.0 * 1024.0 && last_products >= 6.0 + 3.0 * (20.0 / t_prod_us))) on = true;
+}
+
+struct GuessPlan {
+  int KH = 0, R = 0, hist_had = 0;
+  GuessArgs ga{};
+};
+
+// before the step's first kernel: the ring buffers and the kernel's arguments; the count of valid older states is taken
+// and reset (guess_commit restores it once the step has gone its way to the end)
+GuessPlan guess_prepare(pg_solver* s, const void* owner, bool allowed, hipStream_t stream) {
+  const Config& cfg = config();
+  GuessPlan gp;
+  gp.KH = allowed ? cfg.guess_n : 0;                           // older states read at most
+  gp.R = gp.KH > 0 ? cfg.guess_depth : 0;                      // older states kept
+  gp.hist_had = (s->hist_de == owner && s->hist_k == gp.R) ? s->hist_cnt : 0;
+  s->hist_cnt = 0;
+  if (gp.KH == 0) return gp;
+  const int R = gp.R;
+  const i64 nva = s->z.n;
+  if (s->guess_coef.n == 0) { s->guess_coef.alloc(16 + GUESS_NS); s->guess_coef.zero(); s->guess_ticket.alloc(1); s->guess_ticket.zero(); }
+  for (int j = 0; j <= R; ++j) {      // (one more product buffer than states: the one retired a step ago takes the next
+    if (j < R && s->zh[j].n != nva) { s->zh[j].alloc(nva); s->zh[j].zero(); }   //  product while the fit still reads the others)
+    if (s->yh[j].n != nva) { s->yh[j].alloc(nva); s->yh[j].zero(); }
+  }
+  if (gp.hist_had == 0) PG_HIP(hipMemsetAsync(s->guess_coef.p, 0, 12 * sizeof(double), stream));   // (the counters stay)
+  for (int j = 0; j < 8; ++j) { gp.ga.zr[j] = s->zh[std::min(j, R - 1)].p; gp.ga.yr[j] = s->yh[std::min(j, R - 1)].p; }
+  gp.ga.znew = s->zh[R - 1].p;
+  gp.ga.coef = s->guess_coef.p;
+  return gp;
+}
+
+// after the step's first kernel: the fit for the next step (k_guess_fit; cmap == NULL: every row is in the loop), then the
+// buffers trade places
+void guess_after_rhs(pg_solver* s, const GuessPlan& gp, i64 n, const int* cmap, const double* ds, const double* rhat, bool single,
+                     KrylovWork& w, hipStream_t stream) {
+  if (gp.KH == 0) return;
+  const Config& cfg = config();
+  const int R = gp.R;
+  if (gp.hist_had > 0) {
+    GuessFit gf{};
+    for (int j = 0; j < 8; ++j) gf.yr[j] = s->yh[std::min(j, R - 1)].p;
+    const i64 nchunk = (n + BLOCK - 1) / BLOCK;
+    gf.stride = (int)std::max<i64>(1, std::min<i64>(cfg.guess_monitor, nchunk / 128));   // (small systems: every chunk)
+    const int gfit = (int)std::min<i64>(128, (nchunk + gf.stride - 1) / gf.stride);
+    if (s->guess_partials.n != (i64)GUESS_NS * std::max(gfit, 1)) s->guess_partials.alloc((i64)GUESS_NS * std::max(gfit, 1));
+    gf.partials = s->guess_partials.p;
+    gf.ticket = s->guess_ticket.p;
+    gf.coef = s->guess_coef.p;
+    gf.avail = std::min(gp.hist_had, GUESS_RM);
+    gf.kmax = gp.KH;
+    gf.rate2 = w.last_rate2;
+    gf.pass_cost = cfg.guess_pass_cost;
+    gf.gain = cfg.guess_gain;
+    gf.sums = single ? nullptr : s->guess_coef.p + 16;
+    hipStream_t fst = stream;
+    if (single && cfg.guess_async) {
+      if (!s->fit.st) {
+        PG_HIP(hipStreamCreateWithFlags(&s->fit.st, hipStreamNonBlocking));
+        PG_HIP(hipEventCreateWithFlags(&s->fit.ev_rhs, hipEventDisableTiming));
+        PG_HIP(hipEventCreateWithFlags(&s->fit.ev_fit, hipEventDisableTiming));
+      }
+      PG_HIP(hipEventRecord(s->fit.ev_rhs, stream));
+      PG_HIP(hipStreamWaitEvent(s->fit.st, s->fit.ev_rhs, 0));
+      fst = s->fit.st;
+    }
+    hipLaunchKernelGGL(k_guess_fit, dim3(std::max(gfit, 1)), dim3(BLOCK), 0, fst, n, cmap, ds, (const double*)s->b.p,
+                       (const double*)s->y.p, rhat, gf);
+    if (fst != stream) {
+      PG_HIP(hipEventRecord(s->fit.ev_fit, fst));
+      s->fit.pending = true;
+    }
+    if (!single) {
+      comm_allreduce_sum_f64(gf.sums, GUESS_NS, stream);
+      hipLaunchKernelGGL(k_guess_decide, dim3(1), dim3(BLOCK), 0, stream, gf);
+    }
+    PG_HIP(hipGetLastError());
+  }
+  // the buffers trade places (stream order keeps the kernels above ahead of whatever writes them next): the state written
+  // becomes z, z and ŷ become the newest kept pair, the product buffer retired a step ago is the next product's output
+  double* znew = s->zh[R - 1].p;
+  double* yspare = s->yh[R].p;
+  double* yretire = s->yh[R - 1].p;
+  for (int j = R - 1; j > 0; --j) { s->zh[j].p = s->zh[j - 1].p; s->yh[j].p = s->yh[j - 1].p; }
+  s->zh[0].p = s->z.p; s->z.p = znew;
+  s->yh[0].p = s->y.p; s->y.p = yspare;
+  s->yh[R].p = yretire;
+}
+
+// the step has gone its way to the end: one more older state stands
+void guess_commit(pg_solver* s, const GuessPlan& gp, const void* owner) {
+  if (gp.KH == 0) return;
+  if (config().debug) {
+    double hc[16];
+    fit_join(s, true);
+    s->guess_coef.download(hc, 16);
+    fprintf(stderr, "[pg_solver] extrapolated start: %d older states kept; sampled (r,r)_W plain %.3e, taken %.3e; next step: %d states",
+            gp.hist_had, hc[9], hc[10], (int)hc[4]);
+    for (int j = 0; j < (int)hc[4]; ++j) fprintf(stderr, " z(n-%d)*%.4f", (int)hc[5 + j] + 1, hc[j]);
+    fprintf(stderr, ", fit leaves %.3e\n", hc[11]);
+  }
+  s->hist_cnt = std::min(gp.hist_had + 1, gp.R);
+  s->hist_k = gp.R;
+  s->hist_de = owner;
 }
 
 void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& st) {
@@ -1247,34 +1404,10 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
       // Several ranks: "unchanged data" is the same verdict everywhere, the fit's sums go through an all-reduce and every rank
       // takes the same decision.
       const Config& cfg = config();
-      // Worth its launch?  The fit costs about 20 us per step whatever the size, a product max(5 us, its bytes at 5 TB/s): the
-      // mechanism is switched on (for good, on this system) once a solve has used so many products that a few of them saved
-      // pay for it -- 512^3: from 7 products (the loop needs 26), 64^3 ... 2048^2: from 18 (launch-bound: 26 products of the
-      // 3-D CN loops qualify, +15 ... +50 %; the 8 of the 2-D backward-Euler loops do not, where it cost 5 ... 30 %)
-      if (!DE.guess_on && cfg.guess_n > 0 && DE.last_products > 0.0) {
-        const double t_prod_us = std::max(5.0, DE.bytes_per_rank / 5.0e6);
-        // (and not on systems of a few thousand rows, where every launch is latency and the fit's is one more: 80^2, 1815 rows:
-        //  19 -> 11 products per step and still 6400 instead of 7800 steps/s)
-        if (cfg.guess_always || (DE.bytes_per_rank >= 256.0 * 1024.0 && DE.last_products >= 6.0 + 3.0 * (20.0 / t_prod_us)))
-          DE.guess_on = true;
-      }
-      const int KH = (same_data && DE.guess_on) ? cfg.guess_n : 0; // older states read at most
-      const int R = KH > 0 ? cfg.guess_depth : 0;                  // older states kept
-      const int hist_had = (s->hist_de == &DE && s->hist_k == R) ? s->hist_cnt : 0;
-      s->hist_cnt = 0;    // (stands again below once this step has gone the quiet way to its end)
-      GuessArgs ga{};
-      if (KH > 0) {
-        const i64 nva = s->z.n;
-        if (s->guess_coef.n == 0) { s->guess_coef.alloc(16 + GUESS_NS); s->guess_coef.zero(); s->guess_ticket.alloc(1); s->guess_ticket.zero(); }
-        for (int j = 0; j <= R; ++j) {      // (one more product buffer than states: the one retired a step ago takes the next
-          if (j < R && s->zh[j].n != nva) { s->zh[j].alloc(nva); s->zh[j].zero(); }   //  product while the fit still reads the others)
-          if (s->yh[j].n != nva) { s->yh[j].alloc(nva); s->yh[j].zero(); }
-        }
-        if (hist_had == 0) PG_HIP(hipMemsetAsync(s->guess_coef.p, 0, 12 * sizeof(double), stream));   // (the counters stay)
-        for (int j = 0; j < 8; ++j) { ga.zr[j] = s->zh[std::min(j, R - 1)].p; ga.yr[j] = s->yh[std::min(j, R - 1)].p; }
-        ga.znew = s->zh[R - 1].p;
-        ga.coef = s->guess_coef.p;
-      }
+      guess_policy(DE.guess_on, DE.last_products, DE.bytes_per_rank);
+      const GuessPlan gp = guess_prepare(s, &DE, same_data && DE.guess_on, stream);
+      const int KH = gp.KH;
+      const GuessArgs& ga = gp.ga;
 #define PG_RHS_INIT_C(KHV)                                                                                                        \
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rhs_init_c<KHV>), dim3(w.grid), dim3(BLOCK), 0, stream, n, scheme, s->z.p, s->y.p, A.ds.p,   \
                      s->mass.p, s->bconst.p, s->fixed.p, A.isblk.p, DE.cmap.p, s->b.p, (const double*)DE.gdiag.p, DE.delta.p,     \
@@ -1289,57 +1422,7 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
       }
 #undef PG_RHS_INIT_C
       PG_HIP(hipGetLastError());
-      if (KH > 0) {
-        if (hist_had > 0) {
-          // next step's offsets and coefficients, from this step's plain residual (k_guess_fit)
-          GuessFit gf{};
-          for (int j = 0; j < 8; ++j) gf.yr[j] = s->yh[std::min(j, R - 1)].p;
-          const i64 nchunk = (n + BLOCK - 1) / BLOCK;
-          gf.stride = (int)std::max<i64>(1, std::min<i64>(cfg.guess_monitor, nchunk / 128));   // (small systems: every chunk)
-          const int gfit = (int)std::min<i64>(128, (nchunk + gf.stride - 1) / gf.stride);
-          if (s->guess_partials.n != (i64)GUESS_NS * std::max(gfit, 1)) s->guess_partials.alloc((i64)GUESS_NS * std::max(gfit, 1));
-          gf.partials = s->guess_partials.p;
-          gf.ticket = s->guess_ticket.p;
-          gf.coef = s->guess_coef.p;
-          gf.avail = std::min(hist_had, GUESS_RM);
-          gf.kmax = KH;
-          gf.rate2 = w.last_rate2;
-          gf.pass_cost = cfg.guess_pass_cost;
-          gf.gain = cfg.guess_gain;
-          gf.sums = single ? nullptr : s->guess_coef.p + 16;
-          hipStream_t fst = stream;
-          if (single && cfg.guess_async) {
-            if (!s->fit.st) {
-              PG_HIP(hipStreamCreateWithFlags(&s->fit.st, hipStreamNonBlocking));
-              PG_HIP(hipEventCreateWithFlags(&s->fit.ev_rhs, hipEventDisableTiming));
-              PG_HIP(hipEventCreateWithFlags(&s->fit.ev_fit, hipEventDisableTiming));
-            }
-            PG_HIP(hipEventRecord(s->fit.ev_rhs, stream));
-            PG_HIP(hipStreamWaitEvent(s->fit.st, s->fit.ev_rhs, 0));
-            fst = s->fit.st;
-          }
-          hipLaunchKernelGGL(k_guess_fit, dim3(std::max(gfit, 1)), dim3(BLOCK), 0, fst, n, (const int*)DE.cmap.p, (const double*)A.ds.p,
-                             (const double*)s->b.p, (const double*)s->y.p, (const double*)w.rhat.p, gf);
-          if (fst != stream) {
-            PG_HIP(hipEventRecord(s->fit.ev_fit, fst));
-            s->fit.pending = true;
-          }
-          if (!single) {
-            comm_allreduce_sum_f64(gf.sums, GUESS_NS, stream);
-            hipLaunchKernelGGL(k_guess_decide, dim3(1), dim3(BLOCK), 0, stream, gf);
-          }
-          PG_HIP(hipGetLastError());
-        }
-        // the buffers trade places (stream order keeps the kernels above ahead of whatever writes them next): the state
-        // written becomes z, z and ŷ become the newest kept pair, the oldest ŷ is the next product's output
-        double* znew = s->zh[R - 1].p;
-        double* yspare = s->yh[R].p;          // retired a step ago
-        double* yretire = s->yh[R - 1].p;
-        for (int j = R - 1; j > 0; --j) { s->zh[j].p = s->zh[j - 1].p; s->yh[j].p = s->yh[j - 1].p; }
-        s->zh[0].p = s->z.p; s->z.p = znew;
-        s->yh[0].p = s->y.p; s->y.p = yspare;
-        s->yh[R].p = yretire;
-      }
+      guess_after_rhs(s, gp, n, (const int*)DE.cmap.p, (const double*)A.ds.p, (const double*)w.rhat.p, single, w, stream);
       if (!same_data) diag_fix(DE, s->nb, s->slab, stamp, !single, w.rhat.p, w.partials.p, w.grid, stream);
       w.start_folded = quiet;
       DE.snapped_version = s->bconst_version;
@@ -1387,40 +1470,48 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
         st.iters += first.iters;
         st.products += first.products;
       }
-      else if (KH > 0) {
-        if (config().debug) {
-          double hc[16];
-          fit_join(s, true);
-          s->guess_coef.download(hc, 16);
-          fprintf(stderr, "[pg_solver] extrapolated start: %d older states kept; sampled (r,r)_W plain %.3e, taken %.3e; next step: %d states",
-                  hist_had, hc[9], hc[10], (int)hc[4]);
-          for (int j = 0; j < (int)hc[4]; ++j) fprintf(stderr, " z(n-%d)*%.4f", (int)hc[5 + j] + 1, hc[j]);
-          fprintf(stderr, ", fit leaves %.3e\n", hc[11]);
-        }
-        s->hist_cnt = std::min(hist_had + 1, R);
-        s->hist_k = R;
-        s->hist_de = &DE;
-      }
+      else guess_commit(s, gp, &DE);
       s->x_valid = false;
       s->steps_done += 1;
       return;
     }
-    hipLaunchKernelGGL(k_rhs_init, dim3(w.grid), dim3(BLOCK), 0, stream, n, s->nb.n_vec(), scheme, s->z.p, s->y.p, A.ds.p,
-                       s->mass.p, s->bconst.p, s->fixed.p, A.isblk.p, s->b.p, w.r.p, w.rhat.p, w.p.p, w.partials.p);
-    PG_HIP(hipGetLastError());
     // Dirichlet interface: the γ rows are rows of the identity -- solved here, the iteration runs on Â_ωω (pg_reduce.hip)
     GammaElim& E = (&A == &s->A_ctor) ? s->elim_ctor : s->elim_run;
     if (!E.tried) build_gamma_elim(A, s->nb, E);
+    // The plain warm path (no row left out: diphasic systems, interfaces with Robin / Neumann conditions and no border rows)
+    // takes the extrapolated start as well, on one rank: the kept products are products of whole states whatever the data do,
+    // so steps with changing data qualify too.
+    const bool single = ctx().nranks == 1 && !ctx().comm;
+    const int which = (&A == &s->A_ctor) ? 0 : 1;
+    if (single && !E.active) guess_policy(s->plain_guess_on[which], s->plain_last_products[which], (double)A.spmv_bytes);
+    const GuessPlan gp = guess_prepare(s, &A, single && !E.active && s->plain_guess_on[which], stream);
+#define PG_RHS_INIT(KHV)                                                                                                          \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rhs_init<KHV>), dim3(w.grid), dim3(BLOCK), 0, stream, n, s->nb.n_vec(), scheme, s->z.p,     \
+                     s->y.p, A.ds.p, s->mass.p, s->bconst.p, s->fixed.p, A.isblk.p, s->b.p, w.r.p, w.rhat.p, w.p.p, w.partials.p, \
+                     gp.ga)
+    switch (gp.KH) {
+      case 1: PG_RHS_INIT(1); break;
+      case 2: PG_RHS_INIT(2); break;
+      case 3: PG_RHS_INIT(3); break;
+      case 4: PG_RHS_INIT(4); break;
+      default: PG_RHS_INIT(0); break;
+    }
+#undef PG_RHS_INIT
+    PG_HIP(hipGetLastError());
+    guess_after_rhs(s, gp, n, nullptr, (const double*)A.ds.p, (const double*)w.rhat.p, true, w, stream);
     if (E.active) {
       gamma_fix(E, s->z.p, w.r.p, w.rhat.p, w.p.p, w.partials.p, w.grid, stream);
       krylov_solve(E.A, E.nb, s->slab, s->b.p, s->z.p, w, o, st, nullptr, nullptr, true);
     } else {
       // y0 = z (in place), r0 = b̂ - ŷ: same solution as a zero start, fewer iterations
       krylov_solve(A, s->nb, s->slab, s->b.p, s->z.p, w, o, st, nullptr, nullptr, true);
+      s->plain_last_products[which] = (double)st.products;
+      guess_commit(s, gp, &A);
     }
     s->x_valid = false;
   } else {
     // cold start / CG: the reference's zero initial guess, on the unscaled state
+    s->hist_cnt = 0;
     materialize_x(s);
     if (n > 0) {
       if (scheme == PG_SCHEME_CN) {
