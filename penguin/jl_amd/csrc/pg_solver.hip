@@ -1234,14 +1234,18 @@ void guess_policy(bool& on, double last_products, double bytes_per_product) {
 
 struct GuessPlan {
   int KH = 0, R = 0, hist_had = 0;
+  bool refit = true;      // false: this step keeps the coefficients it has (see guess_prepare)
   GuessArgs ga{};
 };
 
 // before the step's first kernel: the ring buffers and the kernel's arguments; the count of valid older states is taken
 // and reset (guess_commit restores it once the step has gone its way to the end)
-GuessPlan guess_prepare(pg_solver* s, const void* owner, bool allowed, hipStream_t stream) {
+GuessPlan guess_prepare(pg_solver* s, const void* owner, bool allowed, double last_products, hipStream_t stream) {
   const Config& cfg = config();
   GuessPlan gp;
+  // a loop that is down to the smallest polynomial (or meets the tolerance at the start) has nothing left to save: the fit
+  // then runs every eighth step only -- its launch is a third of such a step on small systems
+  gp.refit = last_products > 4.0 || s->steps_done % 8 == 0;
   gp.KH = allowed ? cfg.guess_n : 0;                           // older states read at most
   gp.R = gp.KH > 0 ? cfg.guess_depth : 0;                      // older states kept
   gp.hist_had = (s->hist_de == owner && s->hist_k == gp.R) ? s->hist_cnt : 0;
@@ -1268,7 +1272,7 @@ void guess_after_rhs(pg_solver* s, const GuessPlan& gp, i64 n, const int* cmap, 
   if (gp.KH == 0) return;
   const Config& cfg = config();
   const int R = gp.R;
-  if (gp.hist_had > 0) {
+  if (gp.hist_had > 0 && gp.refit) {
     GuessFit gf{};
     for (int j = 0; j < 8; ++j) gf.yr[j] = s->yh[std::min(j, R - 1)].p;
     const i64 nchunk = (n + BLOCK - 1) / BLOCK;
@@ -1405,7 +1409,7 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
       // takes the same decision.
       const Config& cfg = config();
       guess_policy(DE.guess_on, DE.last_products, DE.bytes_per_rank);
-      const GuessPlan gp = guess_prepare(s, &DE, same_data && DE.guess_on, stream);
+      const GuessPlan gp = guess_prepare(s, &DE, same_data && DE.guess_on, DE.last_products, stream);
       const int KH = gp.KH;
       const GuessArgs& ga = gp.ga;
 #define PG_RHS_INIT_C(KHV)                                                                                                        \
@@ -1484,7 +1488,7 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
     const bool single = ctx().nranks == 1 && !ctx().comm;
     const int which = (&A == &s->A_ctor) ? 0 : 1;
     if (single && !E.active) guess_policy(s->plain_guess_on[which], s->plain_last_products[which], (double)A.spmv_bytes);
-    const GuessPlan gp = guess_prepare(s, &A, single && !E.active && s->plain_guess_on[which], stream);
+    const GuessPlan gp = guess_prepare(s, &A, single && !E.active && s->plain_guess_on[which], s->plain_last_products[which], stream);
 #define PG_RHS_INIT(KHV)                                                                                                          \
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rhs_init<KHV>), dim3(w.grid), dim3(BLOCK), 0, stream, n, s->nb.n_vec(), scheme, s->z.p,     \
                      s->y.p, A.ds.p, s->mass.p, s->bconst.p, s->fixed.p, A.isblk.p, s->b.p, w.r.p, w.rhat.p, w.p.p, w.partials.p, \
