@@ -83,6 +83,7 @@ struct Config {
   int poly_hist = 3;              // PG_POLY_HIST
   bool poly_trend = true;         // PG_POLY_TREND: the degree estimate follows the trend of the last estimates
   int poly_maxdeg = 0;            // PG_POLY_MAXDEG (0: 32 x-space / 10 y-space)
+  int poly_mindeg = 4;            // PG_POLY_MINDEG: the smallest degree the per-solve choice takes (2 .. 8)
   bool recovery_horner = true;    // PG_RECOVERY_HORNER (y-space form)
   int profile_sample = 3;         // PG_PROFILE_SAMPLE
   bool gamma_elim = true;         // PG_GAMMA_ELIM

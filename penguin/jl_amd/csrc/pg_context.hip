@@ -49,6 +49,7 @@ const Config& config() {
     k.poly_slack = getd("PG_POLY_SLACK", -1.0);
     k.poly_hist = (int)std::max<long long>(1, std::min<long long>(3, geti("PG_POLY_HIST", 3)));
     k.poly_maxdeg = (int)geti("PG_POLY_MAXDEG", 0);
+    k.poly_mindeg = (int)std::max<long long>(2, std::min<long long>(8, geti("PG_POLY_MINDEG", 4)));
     k.poly_trend = geti("PG_POLY_TREND", 1) != 0;
     k.recovery_horner = geti("PG_RECOVERY_HORNER", 1) != 0;
     k.profile_sample = (int)std::max<long long>(1, geti("PG_PROFILE_SAMPLE", 3));

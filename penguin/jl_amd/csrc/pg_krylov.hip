@@ -865,7 +865,7 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
   }
   const bool keep_degree = adaptive && stats.converged && stats.iters == 0 && w.adapt_m >= 2;   // met the tolerance at the start:
   w.adapt_matrix = nullptr;                                                                      // the smallest polynomial next time
-  if (keep_degree) { w.adapt_matrix = &A; w.adapt_m = 4; w.adapt_h = 1; }
+  if (keep_degree) { w.adapt_matrix = &A; w.adapt_m = cfg.poly_mindeg; w.adapt_h = 1; }
   if (adaptive && stats.converged && stats.iters > 0) {
     const double rr0 = w.h_sc[S_RR0], rr = w.h_sc[S_HALF] != 0.0 ? w.h_sc[S_RED4] : w.h_sc[S_RR], tol2 = w.h_sc[S_TOL2];
     const double P = (2.0 * stats.iters - stats.half_exit) * m;
@@ -899,7 +899,7 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
         // (a need below the smallest polynomial -- an extrapolated start close to the tolerance, a field close to steady -- takes
         //  the smallest one; it used to find no admissible degree, which sent the next solve back to the first-solve default
         //  and its extra polls: 64^3 near steady state 240 us per step with 3 products, 150 with 16)
-        const int mm = std::max(4, (int)std::ceil(need / h));
+        const int mm = std::max(cfg.poly_mindeg, (int)std::ceil(need / h));
         const int maxdeg = cfg.poly_maxdeg > 0 ? std::min(MAX_POLY_DEGREE, std::max(4, cfg.poly_maxdeg)) : (xspace ? 32 : 10);
         if (mm > maxdeg) continue;
         // x-space: a chain = one lean launch + mm - 2 Horner launches (1.18 lean launches each), closing launch + vector
