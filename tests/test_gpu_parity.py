@@ -962,6 +962,30 @@ def test_extrapolated_start_of_quiet_steps_keeps_the_solution(pj, scheme):
     assert all(1 <= o <= depth for o in g["offsets"]) and sorted(set(g["offsets"])) == g["offsets"], g
 
 
+def test_extrapolated_start_across_a_change_of_the_data(tmp_path):
+    """Quiet steps, new border values, quiet steps again (scripts/data_change_sequence.py): the step with new data drops the
+    kept states (the rows alone on their diagonal move with the data) and they build up again afterwards; the states of the
+    whole sequence equal those of the same sequence run without the extrapolated start (a child process each: the setting is
+    read once per process)."""
+    import subprocess
+    root = pathlib.Path(__file__).resolve().parents[1]
+    outs = {}
+    for tag, env in (("on", {}), ("off", {"PG_GUESS_STATES": "0"})):
+        o = str(tmp_path / tag)
+        r = subprocess.run([sys.executable, str(root / "scripts" / "data_change_sequence.py"), o], cwd=root, env={**os.environ, **env},
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (tag, r.stdout[-1000:], r.stderr[-3000:])
+        outs[tag] = np.load(o + ".npz")
+    on, off = outs["on"], outs["off"]
+    assert list(off["kept"]) == [0, 0, 0, 0, 0]
+    kept = list(on["kept"])
+    if kept[0] > 0:                       # (PG_GUESS_STATES=0 in the environment of the whole run: nothing to see)
+        assert kept[0] >= 7 and kept[1] == 0 and kept[2] >= 7 and kept[3] == 0 and kept[4] >= 7, kept
+    for k in ("s14", "s15", "s28", "s29", "s42"):
+        assert rel_l2(on[k], off[k]) <= TOL_T, (k, rel_l2(on[k], off[k]))
+    assert rel_l2(on["s15"], on["s14"]) > 1e-4            # the data did change
+
+
 # ------------------------------------------------------------------------------------ steady diffusion (SURVEY §8f.1)
 def test_steady_monophasic_reference_test(pj):
     """test/solver/diffusion_test.jl:5-26: 20^2, circle r=0.5 at (0.5,0.5), Dirichlet(1) everywhere, f = 0."""
