@@ -1407,7 +1407,6 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
       // differences of the kept states are differences of the loop's rows alone and the products ŷ^{n-o} combine linearly.
       // Several ranks: "unchanged data" is the same verdict everywhere, the fit's sums go through an all-reduce and every rank
       // takes the same decision.
-      const Config& cfg = config();
       guess_policy(DE.guess_on, DE.last_products, DE.bytes_per_rank);
       const GuessPlan gp = guess_prepare(s, &DE, same_data && DE.guess_on, DE.last_products, stream);
       const int KH = gp.KH;
