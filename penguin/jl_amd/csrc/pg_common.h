@@ -104,6 +104,7 @@ struct Config {
   // the start of a quiet time step extrapolated from older states (pg_solver.hip, GuessArgs / k_guess_fit):
   int guess_n = 4;                // PG_GUESS_STATES: older states read at most (0: off, <= 4)
   int guess_depth = 7;            // PG_GUESS_DEPTH: older states kept to choose from (<= 7)
+  bool guess_defer = true;        // PG_GUESS_DEFER: compact x-space loop: the extrapolated state is formed by the solve's first update of x
   bool guess_always = false;      // PG_GUESS_ALWAYS=1: also where the fit's launch is not expected to pay (small, easy systems)
   bool guess_async = false;       // PG_GUESS_ASYNC=1: one rank: the fit runs on a stream of its own beside the solve (measured: the
                                   // Horner launches beside it slow down by more than the 21 us it takes off the stream: 586 vs 592 steps/s)

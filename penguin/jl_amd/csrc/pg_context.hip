@@ -72,6 +72,7 @@ const Config& config() {
     k.guess_pass_cost = getd("PG_GUESS_PASS_COST", 0.34);
     k.guess_async = geti("PG_GUESS_ASYNC", 0) != 0;
     k.guess_always = geti("PG_GUESS_ALWAYS", 0) != 0;
+    k.guess_defer = geti("PG_GUESS_DEFER", 1) != 0;
     k.guess_gain = getd("PG_GUESS_GAIN", 0.8);
     k.unit_order = (int)geti("PG_SPMV_UNIT_ORDER", 0);
     return k;
@@ -403,11 +404,11 @@ int32_t pg_config_string(char* buf, size_t n) {
            "spmv_variant=%d spmv_xcd=%d spmv_strip=%d spmv_unit_order=%d spmv_march=%d spmv_march_k=%d spmv_minrun=%d spmv_tile_units=%d "
            "spmv_blocks_per_cu=%d halo_overlap=%d speculate=%d poly=%d poly_degree=%d poly_adapt=%d poly_xspace=%d half_test=%d half_batch=%d "
            "krylov_nt=%d fuse_half=%d poly_margin=%g poly_slack=%g poly_hist=%d poly_trend=%d poly_maxdeg=%d recovery_horner=%d gamma_elim=%d diag_elim=%d "
-           "guess_states=%d guess_depth=%d guess_async=%d async_alloc=%d cache_limit_mb=%lld alloc_poison=%d alloc_guard=%d profile_sample=%d debug=%d",
+           "guess_states=%d guess_depth=%d guess_async=%d guess_defer=%d async_alloc=%d cache_limit_mb=%lld alloc_poison=%d alloc_guard=%d profile_sample=%d debug=%d",
            k.spmv_variant, k.spmv_xcd, k.spmv_strip, k.unit_order, (int)k.spmv_march, k.spmv_march_k, k.spmv_minrun, k.spmv_tile_units,
            k.spmv_blocks_per_cu, (int)k.halo_overlap, (int)k.speculate_product, (int)k.poly, k.poly_degree, (int)k.poly_adapt, (int)k.poly_xspace, k.half_test,
            (int)k.half_batch, (int)k.krylov_nt, (int)k.fuse_half_update, k.poly_margin, k.poly_slack, k.poly_hist, (int)k.poly_trend, k.poly_maxdeg, (int)k.recovery_horner,
-           (int)k.gamma_elim, (int)k.diag_elim, k.guess_n, k.guess_depth, (int)k.guess_async, k.async_alloc, k.pool_limit_mb, k.alloc_poison, k.alloc_guard, k.profile_sample, (int)k.debug);
+           (int)k.gamma_elim, (int)k.diag_elim, k.guess_n, k.guess_depth, (int)k.guess_async, (int)k.guess_defer, k.async_alloc, k.pool_limit_mb, k.alloc_poison, k.alloc_guard, k.profile_sample, (int)k.debug);
   if (buf && n > 0) {
     std::strncpy(buf, tmp, n - 1);
     buf[n - 1] = 0;

@@ -6,6 +6,12 @@
 
 namespace pg {
 
+struct XGuess {
+  const double* zbase = nullptr;
+  const double* zr[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const double* coef = nullptr;
+};
+
 struct KrylovWork {
   i64 n = 0, nvec = 0;
   DevBuf<double> r, rhat, p, v, t;      // n_vec each (p and r -- which holds s between the two SpMVs -- carry ghosts)
@@ -29,6 +35,10 @@ struct KrylovWork {
   // set by the caller around one krylov_solve: the system is a compact image of the caller's (pg_reduce.hip, DiagElim) and
   // x is the caller's FULL vector -- the solution update x += q(Â)y lands at x[scatter[i]].  Needs the polynomial path.
   const int* scatter = nullptr;
+  // set by the caller of a compact solve whose start was extrapolated from older states (pg_solver.hip, GuessArgs) and who left
+  // the extrapolated state unformed: the FIRST update of x then writes  x[map] = z_g[map] + α M⁻¹p,  z_g = zbase + Σ c_j (zr[o_j] -
+  // zbase)  (coef: [0..3] c_j, [4] how many, [5..8] which of zr), instead of adding to x.  Reset by krylov_solve.
+  XGuess xguess;
   // set by the caller of a prepared start that wrote r̂ only: p = r = r̂ at the start, so the first iteration reads r̂
   // wherever it needs p or r (k_bicg_s writes r = s, k_bicg_xrp writes p, as always) and the start kernel writes two
   // vectors less.  Reset by krylov_solve.

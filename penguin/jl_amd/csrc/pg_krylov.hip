@@ -130,12 +130,47 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_s_x(i64 n, double* __restrict__ 
                                                     const double* __restrict__ rhat, double* __restrict__ r,
                                                     double* __restrict__ partials, const double* __restrict__ ds,
                                                     unsigned* __restrict__ ticket, int r_in_rhat, const double* __restrict__ phat,
-                                                    double* __restrict__ x, const int* __restrict__ map) {
+                                                    double* x, const int* __restrict__ map, XGuess xg, int first_launch) {
   __shared__ double s_red[BLOCK / 64];
-  if (sc[S_DONE] != 0.0) return;
+  const bool done = sc[S_DONE] != 0.0;
+  if (done && !(xg.zbase != nullptr && first_launch != 0)) return;
   const double alpha = sc[S_ALPHA];
   const bool rrhat = r_in_rhat != 0 && sc[S_ITERS] == 0.0;   // first iteration of a start that left r = r̂ unwritten
   const double* __restrict__ rsrc = rrhat ? rhat : r;
+  // first update of an extrapolated start whose state was left unformed (XGuess): x is written, not added to
+  const bool fresh = xg.zbase != nullptr && rrhat && map != nullptr;
+  int ku = 0;
+  double cj[4] = {0.0, 0.0, 0.0, 0.0};
+  const double* zo[4] = {xg.zbase, xg.zbase, xg.zbase, xg.zbase};
+  if (fresh) {
+    ku = min(4, (int)xg.coef[4]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < ku) {
+        const int sel = (int)xg.coef[5 + j];
+        cj[j] = xg.coef[j];
+        const double* p = xg.zr[0];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) p = sel == q ? xg.zr[q] : p;
+        zo[j] = p;
+      }
+    }
+  }
+  auto base_of = [&](int j) {
+    const double b = xg.zbase[j];
+    double g = b;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (q < ku) g += cj[q] * (zo[q][j] - b);
+    return g;
+  };
+  if (done) {
+    // the start met the tolerance: no update will run, and this -- the first s kernel queued for the solve, ahead of whatever
+    // the caller queues behind the first batch -- is where the extrapolated state of the loop's rows gets written
+    if (fresh)
+      for (i64 i = blockIdx.x * (i64)BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * BLOCK) { const int j = map[i]; x[j] = base_of(j); }
+    return;
+  }
   double a0 = 0.0, a1 = 0.0, aw = 0.0;
   typedef double dd2 __attribute__((ext_vector_type(2)));
   const i64 npair = n / 2;
@@ -152,8 +187,14 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_s_x(i64 n, double* __restrict__ 
     *reinterpret_cast<dd2*>(r + i) = si;
     if (map) {
       const int j0 = map[i], j1 = map[i + 1];
-      x[j0] += alpha * ph.x;
-      x[j1] += alpha * ph.y;
+      if (fresh) {
+        const double g0 = base_of(j0), g1 = base_of(j1);
+        x[j0] = g0 + alpha * ph.x;
+        x[j1] = g1 + alpha * ph.y;
+      } else {
+        x[j0] += alpha * ph.x;
+        x[j1] += alpha * ph.y;
+      }
     } else {
       dd2 xx = *reinterpret_cast<dd2*>(x + i);
       xx.x += alpha * ph.x;
@@ -169,7 +210,8 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_s_x(i64 n, double* __restrict__ 
     const i64 i = n - 1;
     const double rh = rhat[i], si = rsrc[i] - alpha * v[i];
     r[i] = si;
-    x[map ? map[i] : i] += alpha * phat[i];
+    if (fresh) x[map[i]] = base_of(map[i]) + alpha * phat[i];
+    else x[map ? map[i] : i] += alpha * phat[i];
     a0 += rh * si;
     a1 += si * si;
     aw += (ds[i] * si) * (ds[i] * si);
@@ -535,6 +577,8 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
   struct HookReset { KrylovWork& w; ~HookReset() { w.after_first_batch = nullptr; } } hook_reset{w};   // (every exit path)
   const bool p_in_rhat = w.p_in_rhat && preinit && opts.method == PG_METHOD_BICGSTAB;
   w.p_in_rhat = false;
+  const XGuess xg = w.xguess;      // (first update of x out of place: see KrylovWork::xguess)
+  w.xguess = XGuess();
   const bool start_folded = w.start_folded && preinit && opts.method == PG_METHOD_BICGSTAB;
   w.start_folded = false;
   const bool fused_start = !start_folded && preinit && opts.method == PG_METHOD_BICGSTAB && cx.nranks == 1 && !cx.comm;   // k_start below
@@ -591,6 +635,7 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
   const bool half_test = !cg && (half_env < 0 ? m >= 3 : half_env != 0);
   // x-space: the first half's update of x rides with k_bicg_s (k_bicg_s_x): one pass and one launch less per iteration
   const bool fused_x = xspace && cfg.fuse_half_update;
+  PG_REQUIRE(!xg.zbase || (fused_x && p_in_rhat && w.scatter), "an unformed extrapolated state needs the fused x-space update on a compact system");
   PG_REQUIRE(!preinit || !cg, "preinit is a BiCGStab path");
   if (!cg) {
     if (!preinit)
@@ -684,8 +729,8 @@ void krylov_solve(const CsrMatrix& A, const Numbering& nb, const Slab& slab, con
     if (fused_x) {
       // s, its dots, the half-step test AND x += α M⁻¹p in one pass; without the test in this iteration the sums of slot 4
       // are simply not looked at
-      if (ntv) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_s_x<true>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p, (const double*)A.ds.p, tk, p_in_rhat ? 1 : 0, (const double*)w.ya.p, xit, xmap);
-      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_s_x<false>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p, (const double*)A.ds.p, tk, p_in_rhat ? 1 : 0, (const double*)w.ya.p, xit, xmap);
+      if (ntv) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_s_x<true>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p, (const double*)A.ds.p, tk, p_in_rhat ? 1 : 0, (const double*)w.ya.p, xit, xmap, xg, itn == 0 ? 1 : 0);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bicg_s_x<false>), dim3(G), dim3(BLOCK), 0, st, n, w.sc.p, w.v.p, w.rhat.p, w.r.p, w.partials.p, (const double*)A.ds.p, tk, p_in_rhat ? 1 : 0, (const double*)w.ya.p, xit, xmap, xg, itn == 0 ? 1 : 0);
       if (half_test && !tk) finalize(PH_BICG_S, 1, w, st, true, 4);
       return;
     }

@@ -348,7 +348,11 @@ struct GuessArgs {
   double* znew;             // z^{n+1}'s buffer: z_g for the rows of the loop, the solved value for a row alone on its diagonal
   double* coef;             // [0..3] c_j, [4] how many, [5..8] their ring indices o_j - 1   (k_guess_fit); [13] += the number of
                             // older states this launch read (a running total for the bench's byte count)
+  int defer;                // 1: z_g is NOT formed here -- the older states are not read for it and znew gets the rows alone on
+                            // their diagonal only; the solve's first update of x writes z_g + α M⁻¹p (KrylovWork::xguess) from
+                            // the copy of [0..8] this launch leaves at coef[GUESS_USED ..] (the fit rewrites [0..8] meanwhile)
 };
+constexpr int GUESS_USED = 64;
 
 __device__ inline const double* ring_pick(const double* const (&r)[8], int i) {
   const double* p = r[0];
@@ -499,6 +503,7 @@ __global__ __launch_bounds__(BLOCK) void k_rhs_init_c(i64 n, int scheme, const d
   const double* zo[KH > 0 ? KH : 1];
   const double* yo[KH > 0 ? KH : 1];
   int ku = 0;
+  const bool defer = KH > 0 && g.defer != 0;
   if (KH > 0) {
     ku = min(KH, (int)g.coef[4]);
 #pragma unroll
@@ -508,6 +513,7 @@ __global__ __launch_bounds__(BLOCK) void k_rhs_init_c(i64 n, int scheme, const d
       zo[j] = ring_pick(g.zr, sel);
       yo[j] = ring_pick(g.yr, sel);
     }
+    if (defer && blockIdx.x == 0 && threadIdx.x < 9) g.coef[GUESS_USED + threadIdx.x] = g.coef[threadIdx.x];
   }
   int moved = 0;
   double* zw = KH > 0 ? g.znew : const_cast<double*>(z);   // (in place: a lane writes only elements it has read itself)
@@ -526,7 +532,7 @@ __global__ __launch_bounds__(BLOCK) void k_rhs_init_c(i64 n, int scheme, const d
           zg += cj[j] * (zh[j] - zi);
         }
         ri -= corr;
-        zw[i] = zg;
+        if (!defer) zw[i] = zg;
       }
       rhat[c] = ri;
       acc += ri * ri;
@@ -560,7 +566,7 @@ __global__ __launch_bounds__(BLOCK) void k_rhs_init_c(i64 n, int scheme, const d
         for (int j = 0; j < KH; ++j) {
           rd2_t a = zz, y2 = yh;
           if (j < ku && (c0 >= 0 || c1 >= 0)) {     // (rows alone on their diagonal take nothing from the older states)
-            a = *reinterpret_cast<const rd2_t*>(zo[j] + i);
+            if (!defer) a = *reinterpret_cast<const rd2_t*>(zo[j] + i);
             y2 = *reinterpret_cast<const rd2_t*>(yo[j] + i);
           }
           zh0[j] = a.x; zh1[j] = a.y; yv0[j] = y2.x; yv1[j] = y2.y;
@@ -580,7 +586,7 @@ __global__ __launch_bounds__(BLOCK) void k_rhs_init_c(i64 n, int scheme, const d
       if (KH > 0) {
 #pragma unroll
         for (int j = 0; j < KH; ++j) {
-          zh0[j] = j < ku ? zo[j][i] : zi;
+          zh0[j] = (j < ku && !defer) ? zo[j][i] : zi;
           yv0[j] = j < ku ? yo[j][i] : yh;
         }
       }
@@ -1253,7 +1259,7 @@ GuessPlan guess_prepare(pg_solver* s, const void* owner, bool allowed, double la
   if (gp.KH == 0) return gp;
   const int R = gp.R;
   const i64 nva = s->z.n;
-  if (s->guess_coef.n == 0) { s->guess_coef.alloc(16 + GUESS_NS); s->guess_coef.zero(); s->guess_ticket.alloc(1); s->guess_ticket.zero(); }
+  if (s->guess_coef.n == 0) { s->guess_coef.alloc(GUESS_USED + 16); s->guess_coef.zero(); s->guess_ticket.alloc(1); s->guess_ticket.zero(); }
   for (int j = 0; j <= R; ++j) {      // (one more product buffer than states: the one retired a step ago takes the next
     if (j < R && s->zh[j].n != nva) { s->zh[j].alloc(nva); s->zh[j].zero(); }   //  product while the fit still reads the others)
     if (s->yh[j].n != nva) { s->yh[j].alloc(nva); s->yh[j].zero(); }
@@ -1408,9 +1414,17 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
       // Several ranks: "unchanged data" is the same verdict everywhere, the fit's sums go through an all-reduce and every rank
       // takes the same decision.
       guess_policy(DE.guess_on, DE.last_products, DE.bytes_per_rank);
-      const GuessPlan gp = guess_prepare(s, &DE, same_data && DE.guess_on, DE.last_products, stream);
+      GuessPlan gp = guess_prepare(s, &DE, same_data && DE.guess_on, DE.last_products, stream);
       const int KH = gp.KH;
+      // the extrapolated state itself is formed by the solve's first update of x (KrylovWork::xguess): the older states are
+      // then read there through the compact system's index map, once, and this kernel neither reads them nor writes the state
+      const Config& cfg = config();
+      // (not after a solve that met the tolerance at its start: the next one probably will too, no update of x runs then, and
+      //  writing the state from the first s kernel's early exit costs more than writing it here -- 64^3 BE near steady state)
+      const bool defer = KH > 0 && cfg.guess_defer && cfg.poly_xspace && cfg.fuse_half_update && DE.last_products > 0.0;
+      gp.ga.defer = defer ? 1 : 0;
       const GuessArgs& ga = gp.ga;
+      const double* zprev = s->z.p;      // z^n (the buffers trade places below)
 #define PG_RHS_INIT_C(KHV)                                                                                                        \
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rhs_init_c<KHV>), dim3(w.grid), dim3(BLOCK), 0, stream, n, scheme, s->z.p, s->y.p, A.ds.p,   \
                      s->mass.p, s->bconst.p, s->fixed.p, A.isblk.p, DE.cmap.p, s->b.p, (const double*)DE.gdiag.p, DE.delta.p,     \
@@ -1440,6 +1454,13 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
           s->spec_pending = true;
           s->spec_matrix = &A;
         };
+      XGuess xg;
+      if (defer) {
+        xg.zbase = zprev;
+        for (int j = 0; j < 8; ++j) xg.zr[j] = ga.zr[j];
+        xg.coef = s->guess_coef.p + GUESS_USED;
+        w.xguess = xg;
+      }
       try {
         krylov_solve(DE.A, DE.nb, s->slab, nullptr, s->z.p, w, o, st, nullptr, nullptr, true);
       } catch (...) {
@@ -1454,6 +1475,7 @@ void do_step(pg_solver* s, int scheme, const pg_krylov_opts* opts, SolveStats& s
       s->spec_pending = false;
       solved = st.poly_degree >= 0;            // -1: the polynomial stagnated on the compact system -> the full system below
       DE.last_products = (double)st.products;
+
       // A quiet step rests on "no row alone on its diagonal moves while the data are unchanged"; k_rhs_init_c checks it
       // anyway and the start phase reports it (S_MOVED): the residual the iteration started from then lacked the coupling
       // term, and the step is finished on the full system from the state reached.

@@ -989,6 +989,31 @@ def test_extrapolated_start_across_a_change_of_the_data(tmp_path):
     assert rel_l2(on["s15"], on["s14"]) > 1e-4            # the data did change
 
 
+@pytest.mark.parametrize("scheme", ["BE", "CN"])
+def test_extrapolated_start_up_to_the_steady_state(tmp_path, scheme):
+    """900 steps at 32^3, until late solves meet the tolerance at their start (scripts/steady_state_sequence.py): there the
+    extrapolated state is written by the first s kernel's early exit, ahead of the product queued for the next step, the degree
+    sits at its floor and the fit runs every eighth step.  Same end state as the run without the extrapolated start, every
+    solve converged, the same extremum -- and far fewer products."""
+    import subprocess
+    root = pathlib.Path(__file__).resolve().parents[1]
+    res = {}
+    for tag, env in (("on", {}), ("off", {"PG_GUESS_STATES": "0"})):
+        o = str(tmp_path / tag)
+        r = subprocess.run([sys.executable, str(root / "scripts" / "steady_state_sequence.py"), o, "32", "900", scheme], cwd=root,
+                           env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (tag, r.stdout[-1000:], r.stderr[-3000:])
+        res[tag] = np.load(o + ".npz")
+    on, off = res["on"], res["off"]
+    assert int(on["unconverged"]) == 0 and int(off["unconverged"]) == 0
+    assert rel_l2(on["x"], off["x"]) <= 1e-10, rel_l2(on["x"], off["x"])
+    if scheme == "BE":
+        assert float(np.max(on["x"])) <= 1.0 + 1e-9       # backward Euler keeps the maximum principle (Crank-Nicolson does not)
+    assert abs(float(np.max(on["x"])) - float(np.max(off["x"]))) <= 1e-9
+    if int(on["kept"]) > 0:                                # (not with PG_GUESS_STATES=0 in the environment of the whole run)
+        assert int(on["products"]) < 0.6 * int(off["products"]), (int(on["products"]), int(off["products"]))
+
+
 # ------------------------------------------------------------------------------------ steady diffusion (SURVEY §8f.1)
 def test_steady_monophasic_reference_test(pj):
     """test/solver/diffusion_test.jl:5-26: 20^2, circle r=0.5 at (0.5,0.5), Dirichlet(1) everywhere, f = 0."""
