@@ -349,11 +349,16 @@ def main() -> None:
     # extrapolated start lowers it from step to step)
     apps = 2.0 * run.total_iters - run.half_exits            # applications of the preconditioned operator in the window
     m_mean = (run.products / apps) if (m >= 2 and apps > 0 and getattr(run, "products", 0) > 0) else float(m)
-    # extrapolated start of the quiet steps (pg_solver_guess_info): per older state read, two more vector reads of the step's
-    # first kernel (full-system length), and the new state written out of place (one more write) whenever the feature is on
+    # extrapolated start of the quiet steps (pg_solver_guess_info): per older state read, its product in the step's first
+    # kernel (full-system length) and the state itself in the solve's first update of x (through the loop system's map); with
+    # PG_GUESS_DEFER=0 both in the first kernel, which then also writes the new state out of place (one more write)
     guess_reads = getattr(run, "guess_states_read", 0) / max(run.steps, 1)
-    guess_on = "guess_states=0" not in pj.config_string()
-    guess_bytes = (16.0 * guess_reads + (8.0 if guess_on else 0.0)) * n_full
+    cfgs = pj.config_string()
+    guess_on = "guess_states=0" not in cfgs
+    if "guess_defer=1" in cfgs:
+        guess_bytes = guess_reads * (8.0 * n_full + 8.0 * n_rows)
+    else:
+        guess_bytes = (16.0 * guess_reads + (8.0 if guess_on else 0.0)) * n_full
     if xspace:
         half_per_step = run.half_exits / max(run.steps, 1)
         mm = m_mean
