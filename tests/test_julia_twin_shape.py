@@ -5,6 +5,8 @@ pg_solver_run, that it has as many fields as the C struct."""
 import re
 from pathlib import Path
 
+import pytest
+
 ROOT = Path(__file__).resolve().parent.parent
 JL = (ROOT / "julia" / "PenguinHIP.jl").read_text(encoding="utf-8")
 HDR = (ROOT / "include" / "penguin_hip.h").read_text(encoding="utf-8")
@@ -77,10 +79,39 @@ def test_every_ccall_binds_a_declared_symbol():
     assert not (called - declared), f"ccall'ed but not declared in include/penguin_hip.h: {sorted(called - declared)}"
 
 
-def test_run_info_struct_has_the_c_fields():
-    c = re.search(r"typedef struct \{([^}]*)\} pg_run_info;", HDR, re.S).group(1)
-    c = re.sub(r"/\*.*?\*/", "", c, flags=re.S)
-    c_fields = re.findall(r"\b(?:int64_t|int32_t|double)\s+(\w+)\s*;", c)
-    j = re.search(r"mutable struct pg_run_info\n(.*?)\n\s*pg_run_info\(\)", JL, re.S).group(1)
-    j_fields = re.findall(r"(\w+)::(?:Int64|Int32|Float64)", j)
-    assert j_fields == c_fields, (j_fields, c_fields)
+def _c_fields(name):
+    body = re.search(r"typedef struct \{([^}]*)\} %s;" % name, HDR, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    out = []
+    for typ, decl in re.findall(r"\b(const double\s*\*|int64_t|int32_t|double)\s*([^;]+);", body):
+        for nm in decl.split(","):
+            nm = nm.strip()
+            m = re.match(r"(\w+)\s*(?:\[(\d+)\])?$", nm)
+            assert m, (name, nm)
+            out.append((m.group(1), typ.replace(" ", ""), int(m.group(2)) if m.group(2) else 0))   # (name, C type, array length)
+    return out
+
+
+def _jl_fields(name):
+    m = re.search(r"struct %s\b(.*?)\bend\b" % name, JL, re.S)
+    assert m, name
+    body = m.group(1)
+    body = body.split("%s(" % name)[0]            # (an inner constructor follows the fields)
+    return re.findall(r"(\w+)::((?:NTuple\{\d+,\s*\w+\})|(?:Ptr\{\w+\})|\w+)", body)
+
+
+_JL_OF_C = {"int64_t": "Int64", "int32_t": "Int32", "double": "Float64", "constdouble*": "Ptr{Float64}"}
+
+
+@pytest.mark.parametrize("name", ["pg_bc_desc", "pg_border_desc", "pg_jump_desc", "pg_krylov_opts", "pg_step_info", "pg_run_info",
+                                  "pg_motion_desc"])
+def test_structs_passed_across_the_abi_match_field_for_field(name):
+    """Same field names, order and types as the C struct (arrays as NTuple of the element type)."""
+    c, j = _c_fields(name), _jl_fields(name)
+    assert [f[0] for f in c] == [f[0] for f in j], (c, j)
+    for (cn, ct, cl), (jn, jt) in zip(c, j):
+        want = _JL_OF_C[ct]
+        if cl:
+            assert re.fullmatch(r"NTuple\{%d,\s*%s\}" % (cl, want), jt), (name, cn, jt)
+        else:
+            assert jt == want, (name, cn, ct, jt)
