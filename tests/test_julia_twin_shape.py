@@ -115,3 +115,58 @@ def test_structs_passed_across_the_abi_match_field_for_field(name):
             assert re.fullmatch(r"NTuple\{%d,\s*%s\}" % (cl, want), jt), (name, cn, jt)
         else:
             assert jt == want, (name, cn, ct, jt)
+
+
+def _top_level_split(txt):
+    parts, depth, cur = [], 0, []
+    for ch in txt:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            parts.append("".join(cur).strip())
+            cur = []
+        else:
+            cur.append(ch)
+    last = "".join(cur).strip()
+    if last:
+        parts.append(last)
+    return parts
+
+
+def _balanced(txt, start):
+    """txt[start] == '(' -> index just past its partner."""
+    depth = 0
+    for k in range(start, len(txt)):
+        if txt[k] == "(":
+            depth += 1
+        elif txt[k] == ")":
+            depth -= 1
+            if depth == 0:
+                return k + 1
+    raise AssertionError("unbalanced")
+
+
+def test_every_ccall_passes_as_many_arguments_as_the_c_prototype_takes():
+    hdr = re.sub(r"/\*.*?\*/", "", HDR, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\bint32_t\s+(pg_[a-z0-9_]+)\s*\(", hdr):
+        end = _balanced(hdr, m.end() - 1)
+        args = hdr[m.end():end - 1].strip()
+        protos[m.group(1)] = 0 if args in ("", "void") else len(_top_level_split(args))
+    txt = _strip(JL)
+    seen = 0
+    for m in re.finditer(r"ccall\(\(:(pg_[a-z0-9_]+),\s*libpg\),\s*(\w+),\s*\(", txt):
+        name = m.group(1)
+        tend = _balanced(txt, m.end() - 1)
+        types = _top_level_split(txt[m.end():tend - 1])
+        call_end = _balanced(txt, m.start() + len("ccall"))
+        rest = txt[tend:call_end - 1].lstrip()
+        assert rest.startswith(","), (name, rest[:40])
+        values = _top_level_split(rest[1:])
+        assert len(types) == protos[name], (name, "types", len(types), "C parameters", protos[name])
+        assert len(values) == len(types), (name, "values", len(values), "types", len(types))
+        assert m.group(2) == "Int32", (name, m.group(2))
+        seen += 1
+    assert seen >= 45
