@@ -170,3 +170,48 @@ def test_every_ccall_passes_as_many_arguments_as_the_c_prototype_takes():
         assert m.group(2) == "Int32", (name, m.group(2))
         seen += 1
     assert seen >= 45
+
+
+_J_OF_C = {"int32_t": "Int32", "int64_t": "Int64", "double": "Float64", "size_t": "Csize_t", "char": "UInt8", "unsigned char": "UInt8",
+           "uint8_t": "UInt8", "void": "Cvoid", "uint64_t": "UInt64", "unsigned long long": "UInt64"}
+_ABI_STRUCTS = {"pg_bc_desc", "pg_border_desc", "pg_jump_desc", "pg_krylov_opts", "pg_step_info", "pg_run_info", "pg_motion_desc",
+                "pg_system_info"}
+
+
+def _c_param(arg):
+    """(base type, pointer level) of one C parameter declaration."""
+    a = re.sub(r"\s+", " ", arg.replace("const", " ").strip())
+    m = re.match(r"(.*?)(\w+)\s*(\[\d*\])?$", a)
+    base, arr = m.group(1).strip(), m.group(3)
+    return base.replace("*", "").strip(), base.count("*") + (1 if arr else 0)
+
+
+def _jl_param(ty):
+    lvl = 0
+    while True:
+        m = re.fullmatch(r"(?:Ptr|Ref)\{(.*)\}", ty.strip())
+        if not m:
+            return ty.strip(), lvl
+        ty, lvl = m.group(1), lvl + 1
+
+
+def test_every_ccall_argument_type_matches_the_c_parameter():
+    """Base type and pointer level of every argument: Int32 / Int64 / Float64 / Csize_t by value, Ptr or Ref of them for
+    pointers, Ptr{Cvoid} for the opaque handles (Ref{Ptr{Cvoid}} for handle outputs), the ABI structs by their own name."""
+    hdr = re.sub(r"/\*.*?\*/", "", HDR, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\bint32_t\s+(pg_[a-z0-9_]+)\s*\(", hdr):
+        end = _balanced(hdr, m.end() - 1)
+        args = hdr[m.end():end - 1].strip()
+        protos[m.group(1)] = [] if args in ("", "void") else _top_level_split(args)
+    txt = _strip(JL)
+    bad = []
+    for m in re.finditer(r"ccall\(\(:(pg_[a-z0-9_]+),\s*libpg\),\s*(\w+),\s*\(", txt):
+        name = m.group(1)
+        tend = _balanced(txt, m.end() - 1)
+        for k, (ca, jt) in enumerate(zip(protos[name], _top_level_split(txt[m.end():tend - 1]))):
+            cb, cl = _c_param(ca)
+            want = ("Cvoid", cl) if (cb.startswith("pg_") and cb not in _ABI_STRUCTS) else (_J_OF_C.get(cb, cb), cl)
+            if _jl_param(jt) != want:
+                bad.append((name, k, ca, jt))
+    assert not bad, bad
