@@ -136,3 +136,29 @@ def test_library_is_not_linked_against_rccl(L):
     out = subprocess.run(["readelf", "-d", str(L.LIB_PATH)], capture_output=True, text=True, check=True).stdout
     needed = [l for l in out.splitlines() if "NEEDED" in l]
     assert needed and not any("rccl" in l for l in needed), needed
+
+
+@pytest.mark.parametrize("name", ["pg_bc_desc", "pg_border_desc", "pg_jump_desc", "pg_motion_desc", "pg_krylov_opts", "pg_step_info",
+                                  "pg_run_info", "pg_system_info"])
+def test_ctypes_structs_match_the_header_field_for_field(L, name):
+    """The Python binding's ctypes mirror of every struct that crosses the ABI: same field names, order and types as
+    include/penguin_hip.h (a field appended on one side only shifts everything behind it silently)."""
+    import re
+
+    hdr = (ROOT / "include" / "penguin_hip.h").read_text()
+    body = re.search(r"typedef struct \{([^}]*)\} %s;" % name, hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    c_fields = []
+    for typ, decl in re.findall(r"\b(const double\s*\*|int64_t|int32_t|double)\s*([^;]+);", body):
+        for nm in decl.split(","):
+            m = re.match(r"\s*(\w+)\s*(?:\[(\d+)\])?\s*$", nm)
+            assert m, (name, nm)
+            c_fields.append((m.group(1), typ.replace(" ", ""), int(m.group(2)) if m.group(2) else 0))
+    want = {"int64_t": C.c_int64, "int32_t": C.c_int32, "double": C.c_double, "constdouble*": C.POINTER(C.c_double)}
+    py_fields = getattr(L, name)._fields_
+    assert [f[0] for f in py_fields] == [f[0] for f in c_fields], (py_fields, c_fields)
+    for (pn, pt), (cn, ct, cl) in zip(py_fields, c_fields):
+        if cl:
+            assert issubclass(pt, C.Array) and pt._length_ == cl and pt._type_ is want[ct], (name, pn, pt)
+        else:
+            assert pt is want[ct] or (ct == "constdouble*" and pt._type_ is C.c_double), (name, pn, pt, ct)
